@@ -1,0 +1,836 @@
+"""CPU ORACLE for the FLUX MM-DiT denoise hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+this file.  The product (`reflectionflow_amd/`) never does: it runs hand-written HIP
+kernels and fails loudly when they are missing.
+
+What this is
+------------
+A plain-PyTorch restatement (dtype-generic: fp32 is the oracle, bf16 the "what eager
+PyTorch would give" noise-floor yardstick) of the path that ReflectionFlow's test-time
+search runs N candidates x R rounds x T steps:
+
+    reference (read-only, /root/reference)            restated here as
+    ------------------------------------------------  ---------------------------------
+    train_flux/flux/block.py:7-170   attn_forward      attn_forward
+    train_flux/flux/block.py:173-272 block_forward     block_forward
+    train_flux/flux/block.py:275-333 single_block_...  single_block_forward
+    train_flux/flux/transformer.py:47-252              tranformer_forward  (sic)
+    train_flux/flux/generate.py:193-299 (loop)         denoise
+    train_flux/flux/lora_controller.py:5-42            enable_lora
+    tts/utils.py:71-87,131-155                         prepare_latents_for_flux, get_noises
+
+The leaves those functions call live in two un-vendored, un-pinned third-party packages
+(`diffusers` ~0.32-0.33, `peft`; reference requirements.txt:1,3) that are NOT present in
+/root/reference nor installed.  Their published semantics are restated below as the
+module tree (`Attention`, `AdaLayerNormZero*`, `RMSNorm`, `FeedForward`, `FluxPosEmbed`,
+`CombinedTimestepGuidanceTextProjEmbeddings`, `FlowMatchEulerDiscreteScheduler`,
+`LoraLinear`), following SURVEY.md Appendix A.
+
+Pinning status
+--------------
+* Block/transformer/loop level: PINNED.  `tests/golden/make_golden.py` imports the
+  reference's own block.py / transformer.py / generate.py (under stub `diffusers`/`peft`
+  namespaces, in the build container only) and drives them with THIS module tree; the
+  restated functions here must agree bit-for-bit in fp32 and the outputs are committed
+  as fixtures under tests/golden/.
+* Leaf level (diffusers/peft arithmetic): PARITY UNPINNED.  The reference ships no
+  tests, golden vectors or fixtures at that boundary, and the
+  packages cannot be installed here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# Leaves (diffusers / peft restatement -- SURVEY.md Appendix A)
+# --------------------------------------------------------------------------------------
+class RMSNorm(nn.Module):
+    """diffusers.models.normalization.RMSNorm (Appendix A.5). Call sites: block.py:38-41,60-67."""
+
+    def __init__(self, dim: int, eps: float = 1e-6, elementwise_affine: bool = True):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim)) if elementwise_affine else None
+
+    def forward(self, hidden_states):
+        input_dtype = hidden_states.dtype
+        variance = hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)
+        hidden_states = hidden_states * torch.rsqrt(variance + self.eps)
+        if self.weight is not None:
+            if self.weight.dtype in (torch.float16, torch.bfloat16):
+                hidden_states = hidden_states.to(self.weight.dtype)
+            hidden_states = hidden_states * self.weight
+        else:
+            hidden_states = hidden_states.to(input_dtype)
+        return hidden_states
+
+
+class AdaLayerNormZero(nn.Module):
+    """Appendix A.4 (Zero). Call sites: block.py:186,191,201."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(dim, 6 * dim, bias=True)
+        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+
+    def forward(self, x, emb=None):
+        emb = self.linear(self.silu(emb))
+        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa, shift_mlp, scale_mlp, gate_mlp
+
+
+class AdaLayerNormZeroSingle(nn.Module):
+    """Appendix A.4 (ZeroSingle). Call site: block.py:295,299."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(dim, 3 * dim, bias=True)
+        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+
+    def forward(self, x, emb=None):
+        emb = self.linear(self.silu(emb))
+        shift_msa, scale_msa, gate_msa = emb.chunk(3, dim=1)
+        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+        return x, gate_msa
+
+
+class AdaLayerNormContinuous(nn.Module):
+    """Appendix A.4 (Continuous): scale FIRST. Call site: transformer.py:243."""
+
+    def __init__(self, dim: int, cond_dim: int):
+        super().__init__()
+        self.silu = nn.SiLU()
+        self.linear = nn.Linear(cond_dim, 2 * dim, bias=True)
+        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+
+    def forward(self, x, conditioning_embedding):
+        emb = self.linear(self.silu(conditioning_embedding).to(x.dtype))
+        scale, shift = torch.chunk(emb, 2, dim=1)
+        x = self.norm(x) * (1 + scale)[:, None, :] + shift[:, None, :]
+        return x
+
+
+class GELU(nn.Module):
+    """diffusers.models.activations.GELU(approximate='tanh'): proj then gelu."""
+
+    def __init__(self, dim_in: int, dim_out: int):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out, bias=True)
+
+    def forward(self, x):
+        return F.gelu(self.proj(x), approximate="tanh")
+
+
+class FeedForward(nn.Module):
+    """Appendix A.2: net = [GELU(proj, tanh), Dropout(0), Linear]. Call sites: block.py:252-259."""
+
+    def __init__(self, dim: int, mult: int = 4):
+        super().__init__()
+        self.net = nn.ModuleList([GELU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class Attention(nn.Module):
+    """Attribute container matching diffusers' Attention for FLUX (Appendix A.2/A.3).
+
+    The arithmetic is in `attn_forward` below (the reference overrides the processor,
+    block.py:7-170); this class only owns the parameters.
+    """
+
+    def __init__(self, dim: int, heads: int, head_dim: int, pre_only: bool = False, eps: float = 1e-6):
+        super().__init__()
+        self.heads = heads
+        inner = heads * head_dim
+        self.to_q = nn.Linear(dim, inner)
+        self.to_k = nn.Linear(dim, inner)
+        self.to_v = nn.Linear(dim, inner)
+        self.norm_q = RMSNorm(head_dim, eps)
+        self.norm_k = RMSNorm(head_dim, eps)
+        if not pre_only:
+            self.add_q_proj = nn.Linear(dim, inner)
+            self.add_k_proj = nn.Linear(dim, inner)
+            self.add_v_proj = nn.Linear(dim, inner)
+            self.norm_added_q = RMSNorm(head_dim, eps)
+            self.norm_added_k = RMSNorm(head_dim, eps)
+            self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Dropout(0.0)])
+            self.to_add_out = nn.Linear(inner, dim)
+
+
+class FluxTransformerBlock(nn.Module):
+    """Appendix A.2 (double-stream block)."""
+
+    def __init__(self, dim: int, heads: int, head_dim: int):
+        super().__init__()
+        self.norm1 = AdaLayerNormZero(dim)
+        self.norm1_context = AdaLayerNormZero(dim)
+        self.attn = Attention(dim, heads, head_dim, pre_only=False)
+        self.norm2 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.ff = FeedForward(dim)
+        self.norm2_context = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
+        self.ff_context = FeedForward(dim)
+
+
+class FluxSingleTransformerBlock(nn.Module):
+    """Appendix A.3 (single-stream block)."""
+
+    def __init__(self, dim: int, heads: int, head_dim: int, mlp_ratio: float = 4.0):
+        super().__init__()
+        self.mlp_hidden_dim = int(dim * mlp_ratio)
+        self.norm = AdaLayerNormZeroSingle(dim)
+        self.proj_mlp = nn.Linear(dim, self.mlp_hidden_dim)
+        self.act_mlp = nn.GELU(approximate="tanh")
+        self.proj_out = nn.Linear(dim + self.mlp_hidden_dim, dim)
+        self.attn = Attention(dim, heads, head_dim, pre_only=True)
+
+
+def get_1d_rotary_pos_embed(dim: int, pos: torch.Tensor, theta: float = 10000.0):
+    """Appendix A.6 (use_real=True, repeat_interleave_real=True, freqs float64)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: (dim // 2)] / dim))
+    freqs = torch.outer(pos.to(torch.float64), freqs)
+    freqs_cos = freqs.cos().repeat_interleave(2, dim=1).float()
+    freqs_sin = freqs.sin().repeat_interleave(2, dim=1).float()
+    return freqs_cos, freqs_sin
+
+
+class FluxPosEmbed(nn.Module):
+    """Appendix A.6. Call site: transformer.py:131,134."""
+
+    def __init__(self, theta: int, axes_dim: Tuple[int, ...]):
+        super().__init__()
+        self.theta = theta
+        self.axes_dim = tuple(axes_dim)
+
+    def forward(self, ids: torch.Tensor):
+        n_axes = ids.shape[-1]
+        cos_out, sin_out = [], []
+        pos = ids.float()
+        for i in range(n_axes):
+            cos, sin = get_1d_rotary_pos_embed(self.axes_dim[i], pos[:, i], theta=self.theta)
+            cos_out.append(cos)
+            sin_out.append(sin)
+        freqs_cos = torch.cat(cos_out, dim=-1).to(ids.device)
+        freqs_sin = torch.cat(sin_out, dim=-1).to(ids.device)
+        return freqs_cos, freqs_sin
+
+
+def apply_rotary_emb(x: torch.Tensor, freqs_cis) -> torch.Tensor:
+    """Appendix A.6: interleaved pairs, fp32 math, one rounding. Call site: block.py:75-78."""
+    cos, sin = freqs_cis
+    cos = cos[None, None]
+    sin = sin[None, None]
+    cos, sin = cos.to(x.device), sin.to(x.device)
+    x_real, x_imag = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rotated = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
+    out = (x.float() * cos + x_rotated.float() * sin).to(x.dtype)
+    return out
+
+
+def get_timestep_embedding(timesteps: torch.Tensor, embedding_dim: int = 256, max_period: int = 10000):
+    """Appendix A.7: flip_sin_to_cos=True, downscale_freq_shift=0, scale=1."""
+    half_dim = embedding_dim // 2
+    exponent = -math.log(max_period) * torch.arange(0, half_dim, dtype=torch.float32, device=timesteps.device)
+    exponent = exponent / (half_dim - 0.0)
+    emb = torch.exp(exponent)
+    emb = timesteps[:, None].float() * emb[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    emb = torch.cat([emb[:, half_dim:], emb[:, :half_dim]], dim=-1)
+    return emb
+
+
+class _TwoLayerSiLU(nn.Module):
+    """TimestepEmbedding / PixArtAlphaTextProjection: linear_2(silu(linear_1(x)))."""
+
+    def __init__(self, in_dim: int, dim: int):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
+    """Appendix A.7. Call site: transformer.py:102-114."""
+
+    def __init__(self, dim: int, pooled_dim: int, guidance_embeds: bool = True):
+        super().__init__()
+        self.timestep_embedder = _TwoLayerSiLU(256, dim)
+        if guidance_embeds:
+            self.guidance_embedder = _TwoLayerSiLU(256, dim)
+        self.text_embedder = _TwoLayerSiLU(pooled_dim, dim)
+        self.guidance_embeds = guidance_embeds
+
+    def forward(self, timestep, *rest):
+        if self.guidance_embeds:
+            guidance, pooled_projection = rest
+        else:
+            (pooled_projection,) = rest
+            guidance = None
+        timesteps_proj = get_timestep_embedding(timestep)
+        emb = self.timestep_embedder(timesteps_proj.to(dtype=pooled_projection.dtype))
+        if guidance is not None:
+            guidance_proj = get_timestep_embedding(guidance)
+            emb = emb + self.guidance_embedder(guidance_proj.to(dtype=pooled_projection.dtype))
+        return emb + self.text_embedder(pooled_projection)
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+FLUX_DEV_CONFIG = dict(
+    in_channels=64, num_layers=19, num_single_layers=38, attention_head_dim=128,
+    num_attention_heads=24, joint_attention_dim=4096, pooled_projection_dim=768,
+    guidance_embeds=True, axes_dims_rope=(16, 56, 56),
+)
+
+
+class FluxTransformer2DModel(nn.Module):
+    """Appendix A.1 module tree with diffusers state-dict key names."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        c = dict(FLUX_DEV_CONFIG)
+        c.update(cfg)
+        self.config = _Config(c)
+        dim = c["num_attention_heads"] * c["attention_head_dim"]
+        self.inner_dim = dim
+        self.pos_embed = FluxPosEmbed(theta=10000, axes_dim=c["axes_dims_rope"])
+        self.time_text_embed = CombinedTimestepGuidanceTextProjEmbeddings(
+            dim, c["pooled_projection_dim"], c["guidance_embeds"])
+        self.context_embedder = nn.Linear(c["joint_attention_dim"], dim)
+        self.x_embedder = nn.Linear(c["in_channels"], dim)
+        self.transformer_blocks = nn.ModuleList(
+            [FluxTransformerBlock(dim, c["num_attention_heads"], c["attention_head_dim"])
+             for _ in range(c["num_layers"])])
+        self.single_transformer_blocks = nn.ModuleList(
+            [FluxSingleTransformerBlock(dim, c["num_attention_heads"], c["attention_head_dim"])
+             for _ in range(c["num_single_layers"])])
+        self.norm_out = AdaLayerNormContinuous(dim, dim)
+        self.proj_out = nn.Linear(dim, c["in_channels"])
+        self.gradient_checkpointing = False
+
+
+# --------------------------------------------------------------------------------------
+# PEFT LoRA restatement (Appendix A.9) and the reference's gating (lora_controller.py:5-42)
+# --------------------------------------------------------------------------------------
+class BaseTunerLayer:
+    """peft.tuners.tuners_utils.BaseTunerLayer surface used by lora_controller.py."""
+
+    scaling: Dict[str, float]
+    active_adapters: List[str]
+
+    def scale_layer(self, scale: float) -> None:
+        if scale == 1:
+            return
+        for a in self.active_adapters:
+            self.scaling[a] *= scale
+
+
+class LoraLinear(nn.Module, BaseTunerLayer):
+    """PEFT lora.Linear: y = base(x) + lora_B(lora_A(x)) * scaling  (Appendix A.9)."""
+
+    def __init__(self, base: nn.Linear, r: int, alpha: float, adapter: str = "default"):
+        super().__init__()
+        self.base_layer = base
+        self.lora_A = nn.ModuleDict({adapter: nn.Linear(base.in_features, r, bias=False)})
+        self.lora_B = nn.ModuleDict({adapter: nn.Linear(r, base.out_features, bias=False)})
+        self.scaling = {adapter: alpha / r}
+        self.active_adapters = [adapter]
+
+    @property
+    def weight(self):
+        return self.base_layer.weight
+
+    @property
+    def bias(self):
+        return self.base_layer.bias
+
+    def forward(self, x):
+        result = self.base_layer(x)
+        for a in self.active_adapters:
+            A, B = self.lora_A[a], self.lora_B[a]
+            result = result + B(A(x.to(A.weight.dtype))) * self.scaling[a]
+        return result
+
+
+# Modules that carry LoRA in the FLUX-Corrector checkpoint: the regex at
+# train_flux/config.yaml:53, expanded against the tree above.
+def lora_target_names(model: FluxTransformer2DModel) -> List[str]:
+    names = ["x_embedder"]
+    for i in range(len(model.transformer_blocks)):
+        p = f"transformer_blocks.{i}."
+        names += [p + "norm1.linear", p + "attn.to_q", p + "attn.to_k", p + "attn.to_v",
+                  p + "attn.to_out.0", p + "ff.net.2"]
+    for i in range(len(model.single_transformer_blocks)):
+        p = f"single_transformer_blocks.{i}."
+        names += [p + "norm.linear", p + "proj_mlp", p + "proj_out",
+                  p + "attn.to_q", p + "attn.to_k", p + "attn.to_v"]
+    return names
+
+
+def _get_parent(model: nn.Module, dotted: str):
+    parts = dotted.split(".")
+    parent = model
+    for p in parts[:-1]:
+        parent = parent[int(p)] if p.isdigit() else getattr(parent, p)
+    return parent, parts[-1]
+
+
+def inject_lora(model: FluxTransformer2DModel, r: int = 32, alpha: float = 32.0, adapter: str = "default"):
+    """Wrap every LoRA-bearing Linear with LoraLinear (what pipe.load_lora_weights does,
+    tts_reflectionflow.py:503-505).  A ~ N(0, 1/r), B ~ N(0, 0.02^2) so the delta is non-zero."""
+    for name in lora_target_names(model):
+        parent, leaf = _get_parent(model, name)
+        base = parent[int(leaf)] if leaf.isdigit() else getattr(parent, leaf)
+        wrapped = LoraLinear(base, r, alpha, adapter)
+        wrapped.to(base.weight.dtype)
+        nn.init.normal_(wrapped.lora_A[adapter].weight, std=1.0 / r)
+        nn.init.normal_(wrapped.lora_B[adapter].weight, std=0.02)
+        if leaf.isdigit():
+            parent[int(leaf)] = wrapped
+        else:
+            setattr(parent, leaf, wrapped)
+    return model
+
+
+class enable_lora:
+    """lora_controller.py:5-42: scale LoRA to 0 inside the context unless `activated`."""
+
+    def __init__(self, lora_modules, activated: bool) -> None:
+        self.activated = activated
+        if activated:
+            return
+        self.lora_modules = [m for m in lora_modules if isinstance(m, BaseTunerLayer)]
+        self.scales = [{a: m.scaling[a] for a in m.active_adapters} for m in self.lora_modules]
+
+    def __enter__(self):
+        if self.activated:
+            return
+        for m in self.lora_modules:
+            m.scale_layer(0)
+
+    def __exit__(self, *exc):
+        if self.activated:
+            return
+        for i, m in enumerate(self.lora_modules):
+            for a in m.active_adapters:
+                m.scaling[a] = self.scales[i][a]
+
+
+# --------------------------------------------------------------------------------------
+# The reference's own four functions, restated (same torch ops, same order)
+# --------------------------------------------------------------------------------------
+def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_latents=None,
+                 attention_mask=None, image_rotary_emb=None, cond_rotary_emb=None, model_config=None):
+    """block.py:7-170."""
+    model_config = model_config or {}
+    latent_lora = model_config.get("latent_lora", False)
+    B = hidden_states.shape[0] if encoder_hidden_states is None else encoder_hidden_states.shape[0]
+    H = attn.heads
+
+    def heads(x):
+        return x.view(B, -1, H, x.shape[-1] // H).transpose(1, 2)
+
+    with enable_lora((attn.to_q, attn.to_k, attn.to_v), latent_lora):      # :23-29
+        query = attn.to_q(hidden_states)
+        key = attn.to_k(hidden_states)
+        value = attn.to_v(hidden_states)
+    head_dim = key.shape[-1] // H
+    query, key, value = heads(query), heads(key), heads(value)            # :34-36
+    if attn.norm_q is not None:
+        query = attn.norm_q(query)                                         # :38-41
+    if attn.norm_k is not None:
+        key = attn.norm_k(key)
+
+    if encoder_hidden_states is not None:                                  # :44-72 text FIRST
+        eq = heads(attn.add_q_proj(encoder_hidden_states))
+        ek = heads(attn.add_k_proj(encoder_hidden_states))
+        ev = heads(attn.add_v_proj(encoder_hidden_states))
+        if attn.norm_added_q is not None:
+            eq = attn.norm_added_q(eq)
+        if attn.norm_added_k is not None:
+            ek = attn.norm_added_k(ek)
+        query = torch.cat([eq, query], dim=2)
+        key = torch.cat([ek, key], dim=2)
+        value = torch.cat([ev, value], dim=2)
+
+    if image_rotary_emb is not None:                                       # :74-78
+        query = apply_rotary_emb(query, image_rotary_emb)
+        key = apply_rotary_emb(key, image_rotary_emb)
+
+    if condition_latents is not None:                                      # :80-104 cond LAST, LoRA on
+        cq = heads(attn.to_q(condition_latents))
+        ck = heads(attn.to_k(condition_latents))
+        cv = heads(attn.to_v(condition_latents))
+        if attn.norm_q is not None:
+            cq = attn.norm_q(cq)
+        if attn.norm_k is not None:
+            ck = attn.norm_k(ck)
+        if cond_rotary_emb is not None:
+            cq = apply_rotary_emb(cq, cond_rotary_emb)
+            ck = apply_rotary_emb(ck, cond_rotary_emb)
+        query = torch.cat([query, cq], dim=2)
+        key = torch.cat([key, ck], dim=2)
+        value = torch.cat([value, cv], dim=2)
+
+    if not model_config.get("union_cond_attn", True):                      # :106-114
+        attention_mask = torch.ones(query.shape[2], key.shape[2], device=query.device, dtype=torch.bool)
+        n = cq.shape[2]
+        attention_mask[-n:, :-n] = False
+        attention_mask[:-n, -n:] = False
+    if hasattr(attn, "c_factor"):                                          # :115-122
+        attention_mask = torch.zeros(query.shape[2], key.shape[2], device=query.device, dtype=query.dtype)
+        n = cq.shape[2]
+        bias = torch.log(attn.c_factor[0])
+        attention_mask[-n:, :-n] = bias
+        attention_mask[:-n, -n:] = bias
+    hs = F.scaled_dot_product_attention(query, key, value, dropout_p=0.0, is_causal=False,
+                                        attn_mask=attention_mask)           # :123-125
+    hs = hs.transpose(1, 2).reshape(B, -1, H * head_dim).to(query.dtype)   # :126-129
+
+    if encoder_hidden_states is not None:                                  # :131-161
+        St = encoder_hidden_states.shape[1]
+        if condition_latents is not None:
+            Sc = condition_latents.shape[1]
+            enc, hid, cond = hs[:, :St], hs[:, St:-Sc], hs[:, -Sc:]
+        else:
+            enc, hid, cond = hs[:, :St], hs[:, St:], None
+        with enable_lora((attn.to_out[0],), latent_lora):
+            hid = attn.to_out[1](attn.to_out[0](hid))
+        enc = attn.to_add_out(enc)
+        if cond is not None:
+            cond = attn.to_out[1](attn.to_out[0](cond))
+            return hid, enc, cond
+        return hid, enc
+    elif condition_latents is not None:                                    # :162-168
+        Sc = condition_latents.shape[1]
+        return hs[:, :-Sc], hs[:, -Sc:]
+    return hs
+
+
+def block_forward(self, hidden_states, encoder_hidden_states, condition_latents, temb, cond_temb,
+                  cond_rotary_emb=None, image_rotary_emb=None, model_config=None):
+    """block.py:173-272."""
+    model_config = model_config or {}
+    latent_lora = model_config.get("latent_lora", False)
+    use_cond = condition_latents is not None
+    with enable_lora((self.norm1.linear,), latent_lora):                   # :185-188
+        norm_h, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, emb=temb)
+    norm_e, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(
+        encoder_hidden_states, emb=temb)                                   # :190-192
+    if use_cond:                                                           # :194-201
+        norm_c, cond_gate_msa, cond_shift_mlp, cond_scale_mlp, cond_gate_mlp = self.norm1(
+            condition_latents, emb=cond_temb)
+
+    result = attn_forward(self.attn, model_config=model_config, hidden_states=norm_h,
+                          encoder_hidden_states=norm_e,
+                          condition_latents=norm_c if use_cond else None,
+                          image_rotary_emb=image_rotary_emb,
+                          cond_rotary_emb=cond_rotary_emb if use_cond else None)    # :204-214
+    attn_output, context_attn_output = result[:2]
+    cond_attn_output = result[2] if use_cond else None
+
+    attn_output = gate_msa.unsqueeze(1) * attn_output                       # :218-226
+    hidden_states = hidden_states + attn_output
+    context_attn_output = c_gate_msa.unsqueeze(1) * context_attn_output
+    encoder_hidden_states = encoder_hidden_states + context_attn_output
+    if use_cond:
+        cond_attn_output = cond_gate_msa.unsqueeze(1) * cond_attn_output
+        condition_latents = condition_latents + cond_attn_output
+        if model_config.get("add_cond_attn", False):                       # :227-228
+            hidden_states = hidden_states + cond_attn_output
+
+    norm_h = self.norm2(hidden_states)                                      # :232-247
+    norm_h = norm_h * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    norm_e = self.norm2_context(encoder_hidden_states)
+    norm_e = norm_e * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+    if use_cond:
+        norm_c = self.norm2(condition_latents)
+        norm_c = norm_c * (1 + cond_scale_mlp[:, None]) + cond_shift_mlp[:, None]
+
+    with enable_lora((self.ff.net[2],), latent_lora):                      # :250-253
+        ff_output = self.ff(norm_h)
+        ff_output = gate_mlp.unsqueeze(1) * ff_output
+    context_ff_output = self.ff_context(norm_e)
+    context_ff_output = c_gate_mlp.unsqueeze(1) * context_ff_output
+    if use_cond:
+        cond_ff_output = self.ff(norm_c)
+        cond_ff_output = cond_gate_mlp.unsqueeze(1) * cond_ff_output
+
+    hidden_states = hidden_states + ff_output                               # :263-266
+    encoder_hidden_states = encoder_hidden_states + context_ff_output
+    if use_cond:
+        condition_latents = condition_latents + cond_ff_output
+    if encoder_hidden_states.dtype == torch.float16:                        # :269-270
+        encoder_hidden_states = encoder_hidden_states.clip(-65504, 65504)
+    return encoder_hidden_states, hidden_states, condition_latents if use_cond else None
+
+
+def single_block_forward(self, hidden_states, temb, image_rotary_emb=None, condition_latents=None,
+                         cond_temb=None, cond_rotary_emb=None, model_config=None):
+    """block.py:275-333."""
+    model_config = model_config or {}
+    latent_lora = model_config.get("latent_lora", False)
+    using_cond = condition_latents is not None
+    residual = hidden_states
+    with enable_lora((self.norm.linear, self.proj_mlp), latent_lora):      # :288-296
+        norm_h, gate = self.norm(hidden_states, emb=temb)
+        mlp_h = self.act_mlp(self.proj_mlp(norm_h))
+    if using_cond:                                                          # :297-300
+        residual_cond = condition_latents
+        norm_c, cond_gate = self.norm(condition_latents, emb=cond_temb)
+        mlp_c = self.act_mlp(self.proj_mlp(norm_c))
+
+    kw = dict(condition_latents=norm_c, cond_rotary_emb=cond_rotary_emb) if using_cond else {}
+    attn_output = attn_forward(self.attn, model_config=model_config, hidden_states=norm_h,
+                               image_rotary_emb=image_rotary_emb, **kw)     # :302-317
+    if using_cond:
+        attn_output, cond_attn_output = attn_output
+
+    with enable_lora((self.proj_out,), latent_lora):                       # :319-323
+        hidden_states = torch.cat([attn_output, mlp_h], dim=2)
+        hidden_states = gate.unsqueeze(1) * self.proj_out(hidden_states)
+        hidden_states = residual + hidden_states
+    if using_cond:                                                          # :324-328
+        condition_latents = torch.cat([cond_attn_output, mlp_c], dim=2)
+        condition_latents = cond_gate.unsqueeze(1) * self.proj_out(condition_latents)
+        condition_latents = residual_cond + condition_latents
+    if hidden_states.dtype == torch.float16:
+        hidden_states = hidden_states.clip(-65504, 65504)
+    return hidden_states if not using_cond else (hidden_states, condition_latents)
+
+
+def tranformer_forward(transformer, condition_latents, condition_ids, condition_type_ids=None,
+                       model_config=None, c_t=0, *, hidden_states, encoder_hidden_states,
+                       pooled_projections, timestep, img_ids, txt_ids, guidance=None,
+                       joint_attention_kwargs=None, return_dict=False, **_):
+    """transformer.py:47-252 (inference branch; ControlNet hooks unused by the tts scripts)."""
+    self = transformer
+    model_config = model_config or {}
+    use_condition = condition_latents is not None
+    with enable_lora((self.x_embedder,), model_config.get("latent_lora", False)):   # :91-93
+        hidden_states = self.x_embedder(hidden_states)
+    condition_latents = self.x_embedder(condition_latents) if use_condition else None
+
+    timestep = timestep.to(hidden_states.dtype) * 1000                      # :95-100
+    guidance = guidance.to(hidden_states.dtype) * 1000 if guidance is not None else None
+    if guidance is None:                                                    # :102-114
+        temb = self.time_text_embed(timestep, pooled_projections)
+        cond_temb = self.time_text_embed(torch.ones_like(timestep) * c_t * 1000, pooled_projections)
+    else:
+        temb = self.time_text_embed(timestep, guidance, pooled_projections)
+        cond_temb = self.time_text_embed(torch.ones_like(timestep) * c_t * 1000,
+                                         torch.ones_like(guidance) * 1000, pooled_projections)
+    encoder_hidden_states = self.context_embedder(encoder_hidden_states)    # :115
+    if txt_ids.ndim == 3:
+        txt_ids = txt_ids[0]
+    if img_ids.ndim == 3:
+        img_ids = img_ids[0]
+    ids = torch.cat((txt_ids, img_ids), dim=0)                              # :129-134
+    image_rotary_emb = self.pos_embed(ids)
+    cond_rotary_emb = self.pos_embed(condition_ids) if use_condition else None
+
+    for block in self.transformer_blocks:                                   # :138-170
+        encoder_hidden_states, hidden_states, condition_latents = block_forward(
+            block, model_config=model_config, hidden_states=hidden_states,
+            encoder_hidden_states=encoder_hidden_states,
+            condition_latents=condition_latents if use_condition else None,
+            temb=temb, cond_temb=cond_temb if use_condition else None,
+            cond_rotary_emb=cond_rotary_emb if use_condition else None,
+            image_rotary_emb=image_rotary_emb)
+    hidden_states = torch.cat([encoder_hidden_states, hidden_states], dim=1)  # :182
+    for block in self.single_transformer_blocks:                            # :184-228
+        kw = dict(condition_latents=condition_latents, cond_temb=cond_temb,
+                  cond_rotary_emb=cond_rotary_emb) if use_condition else {}
+        result = single_block_forward(block, model_config=model_config, hidden_states=hidden_states,
+                                      temb=temb, image_rotary_emb=image_rotary_emb, **kw)
+        if use_condition:
+            hidden_states, condition_latents = result
+        else:
+            hidden_states = result
+    hidden_states = hidden_states[:, encoder_hidden_states.shape[1]:, ...]  # :241
+    hidden_states = self.norm_out(hidden_states, temb)                      # :243-244
+    output = self.proj_out(hidden_states)
+    return (output,)
+
+
+# --------------------------------------------------------------------------------------
+# Scheduler + pipeline helpers (Appendix A.8, A.10) and the denoise loop (generate.py)
+# --------------------------------------------------------------------------------------
+def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15):
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    b = base_shift - m * base_seq_len
+    return image_seq_len * m + b
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """Appendix A.8, FLUX.1-dev config."""
+
+    order = 1
+
+    def __init__(self):
+        self.config = _Config(num_train_timesteps=1000, use_dynamic_shifting=True, base_shift=0.5,
+                              max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096)
+        self.timesteps = None
+        self.sigmas = None
+        self._step_index = None
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        sigmas = np.array(sigmas).astype(np.float32)
+        if self.config.use_dynamic_shifting:
+            sigmas = math.exp(mu) / (math.exp(mu) + (1 / sigmas - 1) ** 1.0)
+        sigmas = torch.from_numpy(np.asarray(sigmas, dtype=np.float32)).to(dtype=torch.float32, device=device)
+        self.timesteps = (sigmas * self.config.num_train_timesteps).to(device=device)
+        self.sigmas = torch.cat([sigmas, torch.zeros(1, device=sigmas.device)])
+        self._step_index = None
+
+    def step(self, model_output, timestep, sample, return_dict=False):
+        if self._step_index is None:
+            self._step_index = 0
+        sample = sample.to(torch.float32)
+        sigma = self.sigmas[self._step_index]
+        sigma_next = self.sigmas[self._step_index + 1]
+        prev_sample = sample + (sigma_next - sigma) * model_output
+        prev_sample = prev_sample.to(model_output.dtype)
+        self._step_index += 1
+        return (prev_sample,)
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kw):
+    scheduler.set_timesteps(sigmas=sigmas, device=device, **kw)
+    return scheduler.timesteps, len(scheduler.timesteps)
+
+
+def pack_latents(latents, batch_size, num_channels_latents, height, width):
+    """FluxPipeline._pack_latents (Appendix A.10)."""
+    latents = latents.view(batch_size, num_channels_latents, height // 2, 2, width // 2, 2)
+    latents = latents.permute(0, 2, 4, 1, 3, 5)
+    return latents.reshape(batch_size, (height // 2) * (width // 2), num_channels_latents * 4)
+
+
+def unpack_latents(latents, height, width, vae_scale_factor=8):
+    batch_size, _, channels = latents.shape
+    height = 2 * (int(height) // (vae_scale_factor * 2))
+    width = 2 * (int(width) // (vae_scale_factor * 2))
+    latents = latents.view(batch_size, height // 2, width // 2, channels // 4, 2, 2)
+    latents = latents.permute(0, 3, 1, 4, 2, 5)
+    return latents.reshape(batch_size, channels // 4, height, width)
+
+
+def prepare_latent_image_ids(height, width, device=None, dtype=torch.float32):
+    ids = torch.zeros(height, width, 3)
+    ids[..., 1] = ids[..., 1] + torch.arange(height)[:, None]
+    ids[..., 2] = ids[..., 2] + torch.arange(width)[None, :]
+    return ids.reshape(height * width, 3).to(device=device, dtype=dtype)
+
+
+def prepare_latents_for_flux(batch_size, height, width, generator, device, dtype):
+    """tts/utils.py:71-87 (randn_tensor with a CPU generator draws on CPU in `dtype`, then moves)."""
+    h = 2 * (int(height) // 16)
+    w = 2 * (int(width) // 16)
+    latents = torch.randn((batch_size, 16, h, w), generator=generator, dtype=dtype).to(device)
+    return pack_latents(latents, batch_size, 16, h, w)
+
+
+def get_noises(seeds, height, width, device="cpu", dtype=torch.bfloat16):
+    """tts/utils.py:131-155 with the seeds given instead of drawn by torch.randint."""
+    return {int(s): prepare_latents_for_flux(1, height, width, torch.manual_seed(int(s)), device, dtype)
+            for s in seeds}
+
+
+def condition_ids_for(cond_size: int, position_delta=None, dtype=torch.float32):
+    """condition.py:126-130 + pipeline_tools.py:15-29: grid ids shifted by position_delta."""
+    n = cond_size // 16
+    ids = prepare_latent_image_ids(n, n, dtype=dtype)
+    if position_delta is None:
+        position_delta = [0, -n]
+    ids[:, 1] += position_delta[0]
+    ids[:, 2] += position_delta[1]
+    return ids
+
+
+@torch.no_grad()
+def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_inference_steps,
+            guidance_scale=3.5, condition_latents=None, condition_ids=None, model_config=None,
+            image_hw=None, scheduler=None, callback=None):
+    """generate.py:193-299 with output_type='latent' (the T-step hot loop + Euler step)."""
+    scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
+    B, S_i, _ = latents.shape
+    dtype, device = prompt_embeds.dtype, latents.device
+    text_ids = torch.zeros(prompt_embeds.shape[1], 3).to(device=device, dtype=dtype)
+    if image_hw is None:
+        side = int(round(math.sqrt(S_i)))
+        image_hw = (side, side)
+    latent_image_ids = prepare_latent_image_ids(image_hw[0], image_hw[1], device, dtype)
+    sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)   # :193
+    mu = calculate_shift(S_i, scheduler.config.base_image_seq_len, scheduler.config.max_image_seq_len,
+                         scheduler.config.base_shift, scheduler.config.max_shift)  # :194-201
+    timesteps, _ = retrieve_timesteps(scheduler, num_inference_steps, device, None, sigmas, mu=mu)
+    use_condition = condition_latents is not None
+    for i, t in enumerate(timesteps):                                        # :217
+        timestep = t.expand(latents.shape[0]).to(latents.dtype)              # :222
+        if transformer.config.guidance_embeds:                               # :225-229
+            guidance = torch.tensor([guidance_scale], device=device).expand(latents.shape[0])
+        else:
+            guidance = None
+        noise_pred = tranformer_forward(
+            transformer, model_config=model_config,
+            condition_latents=condition_latents if use_condition else None,
+            condition_ids=condition_ids if use_condition else None,
+            condition_type_ids=None, hidden_states=latents, timestep=timestep / 1000,
+            guidance=guidance, pooled_projections=pooled_prompt_embeds,
+            encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
+            joint_attention_kwargs=None, return_dict=False)[0]               # :230-248
+        latents = scheduler.step(noise_pred, t, latents, return_dict=False)[0]   # :276
+        if callback is not None:
+            callback(i, t, latents)
+    return latents
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic weights: N(0, 0.02^2) linears, RMSNorm weights 1 + N(0, 0.02^2)
+# --------------------------------------------------------------------------------------
+def init_synthetic_(model: nn.Module, seed: int = 0, std: float = 0.02, lora_std=None):
+    """Per-parameter seeding (seed, crc32(canonical name)) so the base weights are the same
+    tensor whether or not LoRA wrappers are present, and independent of module order."""
+    import zlib
+
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            canon = name.replace(".base_layer", "")
+            g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(canon.encode())) % (2 ** 31))
+            noise = torch.randn(p.shape, generator=g, dtype=torch.float32)
+            if ".lora_A." in name:
+                p.copy_((noise * (lora_std[0] if lora_std else 1.0 / p.shape[0])).to(p.dtype))
+            elif ".lora_B." in name:
+                p.copy_((noise * (lora_std[1] if lora_std else std)).to(p.dtype))
+            elif name.endswith("weight") and p.ndim == 1:  # RMSNorm scale
+                p.copy_((1.0 + noise * std).to(p.dtype))
+            else:
+                p.copy_((noise * std).to(p.dtype))
+    return model
+
+
+def tiny_config(**over):
+    """A small FLUX-shaped config (head_dim stays 128 so the HIP kernels run the same code path)."""
+    c = dict(in_channels=64, num_layers=2, num_single_layers=2, attention_head_dim=128,
+             num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64,
+             guidance_embeds=True, axes_dims_rope=(16, 56, 56))
+    c.update(over)
+    return c

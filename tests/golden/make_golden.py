@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Golden-vector generator  (runs ONLY in the build container; never on the GPU box).
+
+Imports the REFERENCE's own hot-path code from /root/reference/train_flux/flux
+(block.py, transformer.py, generate.py, lora_controller.py) under stub `diffusers` /
+`peft` / `cv2` namespaces, drives it with the oracle's module tree
+(oracle/flux_oracle.py), and
+
+  1. asserts the oracle's restated functions agree BIT-FOR-BIT in fp32 with the
+     reference functions (same torch build, same op order), and
+  2. writes the inputs/outputs as small .npz fixtures next to this file.
+
+Nothing from the reference is copied: fixtures hold only tensors (inputs, outputs,
+weight checksums) and the seeds needed to rebuild the synthetic weights.
+
+    python tests/golden/make_golden.py            # regenerate all fixtures
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/train_flux"
+
+from oracle import flux_oracle as O  # noqa: E402
+
+
+# ------------------------------------------------------------------ stub namespaces
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    import logging
+    import torch.nn.functional as F
+
+    logger = logging.getLogger("stub-diffusers")
+
+    class Transformer2DModelOutput:
+        def __init__(self, sample):
+            self.sample = sample
+
+    class FluxPipelineOutput:
+        def __init__(self, images):
+            self.images = images
+
+    _mod("diffusers", FluxPipeline=object)
+    _mod("diffusers.models")
+    _mod("diffusers.models.attention_processor", Attention=O.Attention, F=F)
+    _mod("diffusers.models.embeddings", apply_rotary_emb=O.apply_rotary_emb)
+    _mod("diffusers.pipelines", FluxPipeline=object)
+    _mod("diffusers.pipelines.flux")
+    _mod("diffusers.pipelines.flux.pipeline_flux", FluxPipelineOutput=FluxPipelineOutput,
+         calculate_shift=O.calculate_shift, retrieve_timesteps=O.retrieve_timesteps, np=np, logger=logger)
+    _mod("diffusers.models.transformers")
+    _mod("diffusers.models.transformers.transformer_flux",
+         FluxTransformer2DModel=O.FluxTransformer2DModel, Transformer2DModelOutput=Transformer2DModelOutput,
+         USE_PEFT_BACKEND=False, scale_lora_layers=lambda *a, **k: None,
+         unscale_lora_layers=lambda *a, **k: None, logger=logger)
+    _mod("diffusers.utils", logging=logging)
+    _mod("peft")
+    _mod("peft.tuners")
+    _mod("peft.tuners.tuners_utils", BaseTunerLayer=O.BaseTunerLayer)
+    _mod("cv2")
+    sys.path.insert(0, REF)
+
+
+install_stubs()
+from flux import block as RB          # noqa: E402  (the reference's block.py)
+from flux import transformer as RT    # noqa: E402  (the reference's transformer.py)
+from flux import generate as RG       # noqa: E402  (the reference's generate.py)
+
+
+# ------------------------------------------------------------------ helpers
+GEOMS = {
+    # head_dim 32: cheap CPU pin.  head_dim 128: the geometry the HIP kernels are built for.
+    "hd32": dict(num_attention_heads=2, attention_head_dim=32, axes_dims_rope=(4, 14, 14),
+                 joint_attention_dim=48, pooled_projection_dim=24, in_channels=64,
+                 num_layers=2, num_single_layers=2),
+    "hd128": dict(num_attention_heads=2, attention_head_dim=128, axes_dims_rope=(16, 56, 56),
+                  joint_attention_dim=256, pooled_projection_dim=64, in_channels=64,
+                  num_layers=2, num_single_layers=2),
+}
+SHAPES = {"hd32": dict(St=8, gh=4, gw=4, gc=2), "hd128": dict(St=32, gh=8, gw=8, gc=4)}
+
+
+def wsum(model):
+    h = hashlib.sha256()
+    for k, v in sorted(model.state_dict().items()):
+        h.update(k.encode())
+        h.update(v.detach().float().numpy().tobytes())
+    return h.hexdigest()
+
+
+def build(geom, lora=False, seed=0):
+    torch.manual_seed(1234)
+    m = O.FluxTransformer2DModel(**GEOMS[geom]).float().eval()
+    if lora:
+        O.inject_lora(m, r=4, alpha=4.0)
+    O.init_synthetic_(m, seed=seed, std=0.05)
+    return m
+
+
+def rnd(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().float().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def eq(a, b, what):
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.equal(a, b), f"{what}: oracle != reference (max abs diff {(a - b).abs().max().item():.3e})"
+
+
+def inputs_for(geom, gen, D):
+    s = SHAPES[geom]
+    St, Si, Sc = s["St"], s["gh"] * s["gw"], s["gc"] * s["gc"]
+    x = rnd(gen, 1, Si, D)
+    e = rnd(gen, 1, St, D)
+    c = rnd(gen, 1, Sc, D)
+    temb = rnd(gen, 1, D)
+    ctemb = rnd(gen, 1, D)
+    txt_ids = torch.zeros(St, 3)
+    img_ids = O.prepare_latent_image_ids(s["gh"], s["gw"])
+    cond_ids = O.prepare_latent_image_ids(s["gc"], s["gc"])
+    cond_ids[:, 2] -= s["gc"]
+    return x, e, c, temb, ctemb, txt_ids, img_ids, cond_ids
+
+
+# ------------------------------------------------------------------ G1-G3: attention / blocks
+@torch.no_grad()
+def gen_blocks(geom):
+    print(f"[{geom}] attn / block / single_block")
+    m = build(geom, lora=False)
+    D = m.inner_dim
+    gen = torch.Generator().manual_seed(7)
+    x, e, c, temb, ctemb, txt_ids, img_ids, cond_ids = inputs_for(geom, gen, D)
+    rope = m.pos_embed(torch.cat([txt_ids, img_ids]))
+    crope = m.pos_embed(cond_ids)
+    blk, sblk = m.transformer_blocks[0], m.single_transformer_blocks[0]
+    out = dict(x=x, e=e, c=c, temb=temb, ctemb=ctemb, txt_ids=txt_ids, img_ids=img_ids, cond_ids=cond_ids)
+    out["weights_sha256"] = np.frombuffer(bytes.fromhex(wsum(m)), dtype=np.uint8)
+
+    modes = {
+        "nocond": (False, {}, None),
+        "cond_union": (True, {"union_cond_attn": True}, None),
+        "cond_nounion": (True, {"union_cond_attn": False}, None),
+        "cond_cfactor": (True, {"union_cond_attn": True}, 1.5),
+        "cond_addattn": (True, {"union_cond_attn": True, "add_cond_attn": True}, None),
+    }
+    for mode, (use_c, cfg, cf) in modes.items():
+        if mode == "cond_addattn" and c.shape[1] != x.shape[1]:
+            # add_cond_attn needs S_c == S_i (block.py:227-228): use the image tokens' shape
+            cc = rnd(torch.Generator().manual_seed(11), *x.shape)
+            ccrope = m.pos_embed(img_ids)
+            out["c_addattn"] = cc
+        else:
+            cc, ccrope = c, crope
+        for a in (blk.attn, sblk.attn):
+            if cf is not None:
+                a.c_factor = torch.ones(1, 1) * cf
+            elif hasattr(a, "c_factor"):
+                del a.c_factor
+        kw = dict(condition_latents=cc if use_c else None, cond_rotary_emb=ccrope if use_c else None)
+        # G1 attn_forward (double-block flavour: with text stream)
+        r = RB.attn_forward(blk.attn, hidden_states=x, encoder_hidden_states=e, image_rotary_emb=rope,
+                            model_config=cfg, **kw)
+        o = O.attn_forward(blk.attn, hidden_states=x, encoder_hidden_states=e, image_rotary_emb=rope,
+                           model_config=cfg, **kw)
+        for i, (a, b) in enumerate(zip(r, o)):
+            eq(b, a, f"attn[{mode}][{i}]")
+            out[f"attn_{mode}_{i}"] = a
+        # G2 block_forward
+        r = RB.block_forward(blk, hidden_states=x, encoder_hidden_states=e, temb=temb,
+                             cond_temb=ctemb if use_c else None, image_rotary_emb=rope,
+                             model_config=cfg, **kw)
+        o = O.block_forward(blk, hidden_states=x, encoder_hidden_states=e, temb=temb,
+                            cond_temb=ctemb if use_c else None, image_rotary_emb=rope,
+                            model_config=cfg, **kw)
+        for i, (a, b) in enumerate(zip(r, o)):
+            if a is None:
+                assert b is None
+                continue
+            eq(b, a, f"block[{mode}][{i}]")
+            out[f"block_{mode}_{i}"] = a
+        # G3 single_block_forward on [txt; img]
+        if mode == "cond_addattn":
+            continue
+        xs = torch.cat([e, x], dim=1)
+        skw = dict(condition_latents=cc, cond_temb=ctemb, cond_rotary_emb=ccrope) if use_c else {}
+        r = RB.single_block_forward(sblk, hidden_states=xs, temb=temb, image_rotary_emb=rope,
+                                    model_config=cfg, **skw)
+        o = O.single_block_forward(sblk, hidden_states=xs, temb=temb, image_rotary_emb=rope,
+                                   model_config=cfg, **skw)
+        r = r if isinstance(r, tuple) else (r,)
+        o = o if isinstance(o, tuple) else (o,)
+        for i, (a, b) in enumerate(zip(r, o)):
+            eq(b, a, f"single[{mode}][{i}]")
+            out[f"single_{mode}_{i}"] = a
+    for a in (blk.attn, sblk.attn):
+        if hasattr(a, "c_factor"):
+            del a.c_factor
+    save(f"blocks_{geom}", **out)
+
+
+# ------------------------------------------------------------------ G4/G5: transformer (+LoRA gating)
+@torch.no_grad()
+def gen_transformer(geom):
+    print(f"[{geom}] tranformer_forward (+ LoRA gating)")
+    s = SHAPES[geom]
+    St, Si, Sc = s["St"], s["gh"] * s["gw"], s["gc"] * s["gc"]
+    gen = torch.Generator().manual_seed(21)
+    cfgm = GEOMS[geom]
+    lat = rnd(gen, 1, Si, 64)
+    cond = rnd(gen, 1, Sc, 64)
+    pe = rnd(gen, 1, St, cfgm["joint_attention_dim"])
+    pooled = rnd(gen, 1, cfgm["pooled_projection_dim"])
+    txt_ids = torch.zeros(St, 3)
+    img_ids = O.prepare_latent_image_ids(s["gh"], s["gw"])
+    cond_ids = O.prepare_latent_image_ids(s["gc"], s["gc"])
+    cond_ids[:, 2] -= s["gc"]
+    t = torch.tensor([0.7])
+    g = torch.tensor([3.5])
+    out = dict(lat=lat, cond=cond, pe=pe, pooled=pooled, txt_ids=txt_ids, img_ids=img_ids,
+               cond_ids=cond_ids, t=t, g=g)
+    for lora in (False, True):
+        m = build(geom, lora=lora)
+        tag = "lora" if lora else "base"
+        out[f"weights_sha256_{tag}"] = np.frombuffer(bytes.fromhex(wsum(m)), dtype=np.uint8)
+        for use_c in (False, True):
+            for latent_lora in ((False, True) if lora else (False,)):
+                cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": latent_lora}
+                kw = dict(hidden_states=lat, encoder_hidden_states=pe, pooled_projections=pooled,
+                          timestep=t, guidance=g, img_ids=img_ids, txt_ids=txt_ids,
+                          joint_attention_kwargs=None, return_dict=False)
+                a = RT.tranformer_forward(m, condition_latents=cond if use_c else None,
+                                          condition_ids=cond_ids if use_c else None,
+                                          condition_type_ids=None, model_config=cfg, **kw)[0]
+                b = O.tranformer_forward(m, condition_latents=cond if use_c else None,
+                                         condition_ids=cond_ids if use_c else None,
+                                         condition_type_ids=None, model_config=cfg, **kw)[0]
+                key = f"out_{tag}_{'cond' if use_c else 'nocond'}_{'latlora' if latent_lora else 'nolatlora'}"
+                eq(b, a, key)
+                out[key] = a
+    # G5 property: with latent_lora=False and no condition, LoRA must not touch the output
+    eq(torch.from_numpy(np.asarray(out["out_lora_nocond_nolatlora"])),
+       torch.from_numpy(np.asarray(out["out_base_nocond_nolatlora"])), "lora gating (img rows unaffected)")
+    assert not np.array_equal(out["out_lora_cond_nolatlora"], out["out_base_cond_nolatlora"])
+    save(f"transformer_{geom}", **out)
+
+
+# ------------------------------------------------------------------ G6: scheduler + generate() loop
+class _OraclePipe:
+    """Just enough FluxPipeline surface for the reference's generate() (generate.py:114-310)."""
+
+    def __init__(self, transformer):
+        self.transformer = transformer
+        self.scheduler = O.FlowMatchEulerDiscreteScheduler()
+        self.vae_scale_factor = 8
+        self.default_sample_size = 128
+        self._execution_device = torch.device("cpu")
+        self.device = torch.device("cpu")
+        self.dtype = torch.float32
+        self.interrupt = False
+        self.joint_attention_kwargs = None
+
+    def check_inputs(self, *a, **k):
+        pass
+
+    def encode_prompt(self, prompt=None, prompt_2=None, prompt_embeds=None, pooled_prompt_embeds=None, **k):
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3).to(dtype=prompt_embeds.dtype)
+        return prompt_embeds, pooled_prompt_embeds, text_ids
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        h = 2 * (int(height) // 16)
+        w = 2 * (int(width) // 16)
+        assert latents is not None
+        return latents.to(device=device, dtype=dtype), O.prepare_latent_image_ids(h // 2, w // 2, device, dtype)
+
+    class _PB:
+        def __init__(self, total):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            pass
+
+        def update(self):
+            pass
+
+    def progress_bar(self, total):
+        return self._PB(total)
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    def set_adapters(self, *a):
+        pass
+
+
+class _FixedCondition:
+    """Stands in for Condition.encode (condition.py:96-132): VAE encode is stochastic and
+    stays PyTorch; the hot path only sees the returned (tokens, ids, type_id)."""
+
+    condition_type = "cot"
+
+    def __init__(self, tokens, ids):
+        self.tokens, self.ids = tokens, ids
+
+    def encode(self, pipe, empty=False):
+        return self.tokens, self.ids.clone(), torch.ones_like(self.ids[:, :1]) * 12
+
+
+@torch.no_grad()
+def gen_loop(geom):
+    print(f"[{geom}] scheduler + generate() loop")
+    s = SHAPES[geom]
+    St, Si, Sc = s["St"], s["gh"] * s["gw"], s["gc"] * s["gc"]
+    H, W = s["gh"] * 16, s["gw"] * 16
+    cfgm = GEOMS[geom]
+    gen = torch.Generator().manual_seed(33)
+    lat = rnd(gen, 1, Si, 64)
+    cond = rnd(gen, 1, Sc, 64)
+    pe = rnd(gen, 1, St, cfgm["joint_attention_dim"])
+    pooled = rnd(gen, 1, cfgm["pooled_projection_dim"])
+    cond_ids = O.prepare_latent_image_ids(s["gc"], s["gc"])
+    cond_ids[:, 2] -= s["gc"]
+    out = dict(lat=lat, cond=cond, pe=pe, pooled=pooled, cond_ids=cond_ids)
+    T = 4
+    for use_c in (False, True):
+        m = build(geom, lora=use_c)
+        pipe = _OraclePipe(m)
+        cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+        a = RG.generate(pipe, conditions=[_FixedCondition(cond, cond_ids)] if use_c else None,
+                        model_config=cfg, default_lora=True, height=H, width=W,
+                        num_inference_steps=T, guidance_scale=3.5, latents=lat.clone(),
+                        prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent").images
+        traj = []
+        b = O.denoise(m, lat.clone(), pe, pooled, T, guidance_scale=3.5,
+                      condition_latents=cond if use_c else None,
+                      condition_ids=cond_ids if use_c else None, model_config=cfg,
+                      image_hw=(s["gh"], s["gw"]), callback=lambda i, t, x: traj.append(x.clone()))
+        key = "cond" if use_c else "nocond"
+        eq(b, a, f"generate loop [{key}]")
+        out[f"final_{key}"] = a
+        out[f"traj_{key}"] = torch.stack(traj)
+    save(f"loop_{geom}", **out)
+
+
+def gen_schedule():
+    print("[*] sigma schedules / mu")
+    out = {}
+    for Si in (256, 1024, 4096, 16384):
+        for T in (4, 28, 50):
+            sch = O.FlowMatchEulerDiscreteScheduler()
+            mu = O.calculate_shift(Si)
+            ts, n = O.retrieve_timesteps(sch, T, None, None, np.linspace(1.0, 1 / T, T), mu=mu)
+            assert n == T
+            out[f"mu_{Si}"] = np.float64(mu)
+            out[f"timesteps_{Si}_{T}"] = ts
+            out[f"sigmas_{Si}_{T}"] = sch.sigmas
+    save("schedule", **out)
+
+
+def gen_noise():
+    print("[*] noise protocol (tts/utils.py:131-155) hashes")
+    out = {}
+    for dtype, tag in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        for seed in (0, 1, 12345):
+            n = O.get_noises([seed], 256, 256, device="cpu", dtype=dtype)[seed]
+            assert n.shape == (1, 256, 64)
+            out[f"sha_{tag}_{seed}"] = np.frombuffer(
+                hashlib.sha256(n.float().numpy().tobytes()).digest(), dtype=np.uint8)
+            out[f"head_{tag}_{seed}"] = n[0, :2, :8].float()
+    save("noise", **out)
+
+
+@torch.no_grad()
+def gen_fullwidth():
+    """G8: one FLUX-dev-width single block (D=3072, S=768) -- checksum only."""
+    print("[*] full-width single block checksum (D=3072)")
+    torch.manual_seed(0)
+    blk = O.FluxSingleTransformerBlock(3072, 24, 128).float().eval()
+    O.init_synthetic_(blk, seed=5, std=0.02)
+    pe = O.FluxPosEmbed(10000, (16, 56, 56))
+    gen = torch.Generator().manual_seed(9)
+    x = rnd(gen, 1, 768, 3072)
+    temb = rnd(gen, 1, 3072)
+    ids = torch.cat([torch.zeros(512, 3), O.prepare_latent_image_ids(16, 16)])
+    rope = pe(ids)
+    a = RB.single_block_forward(blk, hidden_states=x, temb=temb, image_rotary_emb=rope, model_config={})
+    b = O.single_block_forward(blk, hidden_states=x, temb=temb, image_rotary_emb=rope, model_config={})
+    eq(b, a, "full-width single block")
+    save("fullwidth_single", mean=a.mean(), absmean=a.abs().mean(), probe=a[0, ::97, ::389],
+         x_probe=x[0, ::97, ::389])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    for geom in ("hd32", "hd128"):
+        gen_blocks(geom)
+        gen_transformer(geom)
+        gen_loop(geom)
+    gen_schedule()
+    gen_noise()
+    gen_fullwidth()
+    print("all reference-vs-oracle comparisons were bit-exact; fixtures written.")
