@@ -1,0 +1,240 @@
+/* rf_flux.h -- C ABI of librf_flux.so: the MI355X (gfx950) hot path of ReflectionFlow's
+ * FLUX MM-DiT denoise loop.
+ *
+ * The reference (/root/reference, 100 % Python) has no FFI: its "plugin interface" for
+ * this path is four duck-typed Python functions.  Each entry point below names the
+ * reference call it replaces; the Python host side (reflectionflow_amd/flux/*.py) keeps
+ * the reference's function names/signatures and binds these symbols with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never
+ *     allocates, frees or synchronises in a launch path (hipGraph-capturable);
+ *   - all matrices are bf16 row-major unless stated; accumulation is fp32;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued asynchronously;
+ *   - return value: 0 = ok, <0 = rf_status; rf_last_error() gives a thread-local message;
+ *   - one process per GPU; calls on one stream are not re-entrant.
+ */
+#ifndef RF_FLUX_H
+#define RF_FLUX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rf_status {
+  RF_OK = 0,
+  RF_ERR_SHAPE = -1,       /* unsupported / inconsistent shape                      */
+  RF_ERR_ALIGN = -2,       /* pointer or leading dimension not 16-byte aligned      */
+  RF_ERR_NULL = -3,        /* required pointer is NULL                              */
+  RF_ERR_HIP = -4,         /* HIP runtime error (message in rf_last_error)          */
+  RF_ERR_UNSUPPORTED = -5, /* feature not built                                     */
+  RF_ERR_WORKSPACE = -6    /* workspace too small                                   */
+} rf_status;
+
+const char* rf_last_error(void);
+/* ABI version: bump on any struct/signature change. */
+int rf_abi_version(void);
+/* Returns 950 when the library was compiled for gfx950. */
+int rf_target_arch(void);
+
+/* ------------------------------------------------------------------------------------
+ * GEMM with fused epilogues  (replaces nn.Linear + the element-wise ops around it)
+ *   out[m,n] = epi( sum_s sum_k A_s[m,k] W_s[n,k]  + bias[n] )        s = K-segment 0..2
+ * W is nn.Linear's [out,in] layout.  Extra K-segments (per token group) carry
+ *   - the LoRA low-rank term  (A_s = x.lora_A^T, W_s = scaling*lora_B; PEFT lora.Linear,
+ *     active only on the token groups lora_controller.py:5-42 leaves it on for), and
+ *   - the single-block proj_out whose input is cat([attn, mlp]) (block.py:320-322)
+ *     without materialising the concat.
+ * Requirements: every segment K % 64 == 0, 16-byte aligned rows.  M, N arbitrary.
+ * ---------------------------------------------------------------------------------- */
+typedef enum rf_epilogue {
+  RF_EPI_STORE = 0,     /* out = acc + bias                               (nn.Linear)             */
+  RF_EPI_GELU = 1,      /* out = gelu_tanh(acc + bias)       (block.py:252,296 ff.net[0]/proj_mlp) */
+  RF_EPI_GATE_RES = 2,  /* out = residual + gate[n]*(acc+bias)  (block.py:218-226,263-266,320-323) */
+  RF_EPI_QKV = 3,       /* cols split into q|k|v, written head-major  (block.py:27-36,46-58,81-91) */
+  RF_EPI_QKV_GELU = 4   /* cols < n_split: QKV; cols >= n_split: GELU -> out  (single block fused) */
+} rf_epilogue;
+
+typedef struct rf_kseg {
+  const void* A; int64_t lda;         /* [M x K] activations */
+  const void* W; int64_t ldw;         /* [N x K] weights     */
+  int32_t K; int32_t _pad;            /* 0 = segment unused  */
+} rf_kseg;
+
+typedef struct rf_gemm_group {
+  rf_kseg seg[3];
+  const void* bias;                   /* [N] or NULL */
+  int32_t M;
+  int32_t tok_offset;                 /* QKV: first token row of this group in the joint sequence */
+  void* out; int64_t ldo;             /* STORE/GELU/GATE_RES: [M x N];  QKV_GELU: [M x (N-n_split)] */
+  const void* residual; int64_t ldr;  /* GATE_RES: [M x N] (may alias out); NULL = 0 */
+  const void* gate;                   /* GATE_RES: [N] */
+} rf_gemm_group;
+
+typedef struct rf_gemm_desc {
+  int32_t N;
+  int32_t epilogue;                   /* rf_epilogue */
+  int32_t num_groups;                 /* 1..4 token groups sharing N and epilogue (txt/img/cond) */
+  int32_t n_split;                    /* QKV_GELU: first GELU column (= 3*heads*128) */
+  /* QKV epilogues: joint attention operands, S_pad = round_up(S_total, 64) rows per head */
+  void* q;  void* k;                  /* [heads][S_pad][128] */
+  void* vt;                           /* [heads][S_pad/64][128][64] key-permuted, see rf_attention_fwd */
+  int32_t heads; int32_t s_pad;
+  rf_gemm_group g[4];
+} rf_gemm_desc;
+
+int rf_gemm_bf16(const rf_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused per-head RMSNorm(q,k) + interleaved-pair RoPE, in place on head-major q,k
+ * (replaces attn.norm_q/k, norm_added_q/k and apply_rotary_emb: block.py:38-41,60-67,74-78,92-99)
+ *   rows [0, n_added) use w_added_* (text stream), rows [n_added, S) use w_* .
+ *   cos,sin: fp32 [S][128] (FluxPosEmbed tables for [txt|img|cond] rows, transformer.py:130-134)
+ * ---------------------------------------------------------------------------------- */
+int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,
+                       const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k,
+                       const float* cos_tab, const float* sin_tab, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Non-causal flash attention forward, head_dim 128
+ * (replaces F.scaled_dot_product_attention + the transposes, block.py:106-129)
+ *   q,k : [heads][S_pad][128] bf16;  vt : [heads][S_pad/64][128][64] bf16 where the 64 keys of a
+ *         tile are stored at position  p(kv) = (kv & ~12) | ((kv & 4) << 1) | ((kv & 8) >> 1)
+ *         (bits 2 and 3 swapped) -- the order the PV MFMA consumes them in.
+ *   out : [S][heads*128] bf16 (token-major, ready for the out-projection GEMM)
+ *   n_main: rows [0,n_main) are text+image tokens, [n_main,S) condition tokens.
+ *   mode: 0 = plain; 1 = additive bias `cross_bias` on (main<->cond) blocks (attn.c_factor,
+ *         block.py:115-122); 2 = mask (main<->cond) blocks (union_cond_attn=False, block.py:106-114)
+ * ---------------------------------------------------------------------------------- */
+int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
+                     int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
+                     float cross_bias, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm(no affine, eps) + (1+scale)*x + shift, row-wise over D
+ * (replaces AdaLayerNormZero/ZeroSingle/Continuous' norm+modulate and norm2+modulate:
+ *  block.py:186-201,232-247,295-299; transformer.py:243)
+ * ---------------------------------------------------------------------------------- */
+int rf_layernorm_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows, int32_t D,
+                          const void* scale, const void* shift, float eps, void* stream);
+
+/* Euler step of FlowMatchEulerDiscreteScheduler.step (generate.py:276):
+ *   x <- bf16( float(x) + dt * float(v) ),  dt = sigma_next - sigma */
+int rf_euler_step(void* x, const void* v, int64_t n, float dt, void* stream);
+
+/* out = bf16(silu(float(x)))  (the SiLU in front of every AdaLN linear) */
+int rf_silu(const void* x, void* out, int64_t n, void* stream);
+
+/* out[i] += x[i] (bf16): `hidden_states += cond_attn_output` when add_cond_attn (block.py:227-228) */
+int rf_add_inplace(void* out, const void* x, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Whole blocks / whole forward / whole denoise loop
+ * ---------------------------------------------------------------------------------- */
+typedef struct rf_lora_seg {          /* second K-segment for one fused linear (NULL W2 = no LoRA) */
+  const void* A;  /* [r_pad x K]   stacked lora_A rows, zero padded to r_pad % 64 == 0            */
+  const void* B;  /* [N x r_pad]   block-diagonal scaling*lora_B                                   */
+  int32_t r_pad;
+  int32_t _pad;
+} rf_lora_seg;
+
+typedef struct rf_double_block_weights {   /* FluxTransformerBlock, SURVEY Appendix A.2 */
+  const void *w_qkv, *b_qkv;           /* cat(to_q,to_k,to_v)             [3D x D], [3D] */
+  const void *w_add_qkv, *b_add_qkv;   /* cat(add_q,add_k,add_v)_proj     [3D x D], [3D] */
+  const void *norm_q, *norm_k, *norm_added_q, *norm_added_k;   /* [128] */
+  const void *w_out, *b_out;           /* attn.to_out.0   [D x D] */
+  const void *w_add_out, *b_add_out;   /* attn.to_add_out [D x D] */
+  const void *w_ff1, *b_ff1;           /* ff.net.0.proj   [4D x D] */
+  const void *w_ff2, *b_ff2;           /* ff.net.2        [D x 4D] */
+  const void *w_ffc1, *b_ffc1;         /* ff_context.net.0.proj */
+  const void *w_ffc2, *b_ffc2;         /* ff_context.net.2 */
+  rf_lora_seg lora_qkv, lora_out, lora_ff2;   /* FLUX-Corrector LoRA (config.yaml:53) */
+} rf_double_block_weights;
+
+typedef struct rf_single_block_weights {   /* FluxSingleTransformerBlock, Appendix A.3 */
+  const void *w_qkv_mlp, *b_qkv_mlp;   /* cat(to_q,to_k,to_v,proj_mlp)   [(3D+4D) x D] */
+  const void *norm_q, *norm_k;
+  const void *w_out, *b_out;           /* proj_out [D x 5D]: columns [0,D) attn, [D,5D) mlp */
+  rf_lora_seg lora_qkv_mlp, lora_out;
+} rf_single_block_weights;
+
+typedef struct rf_flux_dims {
+  int32_t D, heads, mlp;               /* 3072, 24, 12288 */
+  int32_t S_txt, S_img, S_cond;        /* token counts; S_cond = 0 without a condition */
+  int32_t attn_mode;                   /* rf_attention_fwd mode */
+  float cross_bias;                    /* log(c_factor) */
+  int32_t lora_on_main;                /* model_config["latent_lora"] */
+  int32_t add_cond_attn;               /* model_config["add_cond_attn"] (needs S_cond == S_img) */
+} rf_flux_dims;
+
+typedef struct rf_workspace {
+  void* base; int64_t bytes;           /* scratch owned by the caller, 256-byte aligned */
+} rf_workspace;
+
+int64_t rf_workspace_bytes(const rf_flux_dims* dims);
+
+/* One DoubleStream block, in place on x_txt/x_img/x_cond  (block.py:173-272).
+ *   mod_*: bf16 [6][D] = linear(silu(temb)) chunks in AdaLayerNormZero order
+ *          (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp). */
+int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_block_weights* w,
+                        void* x_txt, void* x_img, void* x_cond, int64_t ldx,
+                        const void* mod_txt, const void* mod_img, const void* mod_cond,
+                        const float* cos_tab, const float* sin_tab,
+                        const rf_workspace* ws, void* stream);
+
+/* One SingleStream block, in place on x_main = [txt;img] rows and x_cond  (block.py:275-333).
+ *   mod_*: bf16 [3][D] = (shift, scale, gate) of AdaLayerNormZeroSingle. */
+int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_block_weights* w,
+                        void* x_main, void* x_cond, int64_t ldx,
+                        const void* mod_main, const void* mod_cond,
+                        const float* cos_tab, const float* sin_tab,
+                        const rf_workspace* ws, void* stream);
+
+typedef struct rf_flux_model {
+  int32_t num_double, num_single;
+  const rf_double_block_weights* dbl;   /* HOST array [num_double] */
+  const rf_single_block_weights* sgl;   /* HOST array [num_single] */
+  const void *w_x_embed, *b_x_embed;    /* x_embedder   [D x in_ch]   (transformer.py:92) */
+  rf_lora_seg lora_x_embed;
+  const void *w_ctx_embed, *b_ctx_embed;/* context_embedder [D x joint] (transformer.py:115) */
+  const void *w_proj_out, *b_proj_out;  /* proj_out [in_ch x D]        (transformer.py:244) */
+  int32_t in_ch, joint_dim;
+} rf_flux_model;
+
+/* Per-forward modulation table produced by ONE skinny GEMM over all AdaLN linears
+ * (norm1.linear / norm1_context.linear / norm.linear / norm_out.linear; they all see the
+ * same temb: transformer.py:166,213).  Layout (bf16, row per call):
+ *   [dbl0.img 6D | dbl0.txt 6D | ... | sgl0 3D | ... | norm_out 2D (scale, shift)] */
+int64_t rf_mod_table_cols(const rf_flux_model* m, int32_t D);
+
+/* Whole transformer forward (transformer.py:47-252) for one sample:
+ *   latents [S_img x in_ch], cond_latents [S_cond x in_ch] or NULL, ctx [S_txt x joint]
+ *   mod_main: modulation table row for temb; mod_cond: table row for cond_temb
+ *             (cond rows use norm1/norm, i.e. the img/single slots of the table)
+ *   out: velocity [S_img x in_ch] */
+int rf_flux_forward(const rf_flux_dims* dims, const rf_flux_model* m,
+                    const void* latents, const void* cond_latents, const void* ctx,
+                    const void* mod_main, const void* mod_cond,
+                    const float* cos_tab, const float* sin_tab,
+                    void* out, const rf_workspace* ws, void* stream);
+
+/* T-step denoise loop (generate.py:216-296): forward + Euler per step, latents updated in place.
+ *   mod_main_steps: [T] table rows (one per timestep); dts: HOST array [T] of sigma_{i+1}-sigma_i */
+int rf_flux_denoise(const rf_flux_dims* dims, const rf_flux_model* m,
+                    void* latents, const void* cond_latents, const void* ctx,
+                    const void* mod_main_steps, int64_t mod_stride, const void* mod_cond,
+                    const float* cos_tab, const float* sin_tab,
+                    const float* dts, int32_t T, void* vel_scratch,
+                    const rf_workspace* ws, void* stream);
+
+/* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
+ * shape with hipEvents on `stream`; returns average microseconds in *us. */
+int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RF_FLUX_H */

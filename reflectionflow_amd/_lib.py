@@ -1,0 +1,140 @@
+"""ctypes binding of librf_flux.so (the C ABI declared in include/rf_flux.h).
+
+The product path has NO fallback: if the shared library is missing or was not built for
+gfx950, importing any op raises.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C reflectionflow_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librf_flux.so")
+ABI_VERSION = 2
+
+RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
+
+
+class RFError(RuntimeError):
+    pass
+
+
+class rf_kseg(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("W", C.c_void_p), ("ldw", C.c_int64),
+                ("K", C.c_int32), ("_pad", C.c_int32)]
+
+
+class rf_gemm_group(C.Structure):
+    _fields_ = [("seg", rf_kseg * 3), ("bias", C.c_void_p), ("M", C.c_int32), ("tok_offset", C.c_int32),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
+                ("gate", C.c_void_p)]
+
+
+class rf_gemm_desc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("epilogue", C.c_int32), ("num_groups", C.c_int32), ("n_split", C.c_int32),
+                ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("heads", C.c_int32), ("s_pad", C.c_int32),
+                ("g", rf_gemm_group * 4)]
+
+
+class rf_lora_seg(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("r_pad", C.c_int32), ("_pad", C.c_int32)]
+
+
+_P = C.c_void_p
+
+
+class rf_double_block_weights(C.Structure):
+    _fields_ = [(n, _P) for n in (
+        "w_qkv", "b_qkv", "w_add_qkv", "b_add_qkv", "norm_q", "norm_k", "norm_added_q", "norm_added_k",
+        "w_out", "b_out", "w_add_out", "b_add_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
+        "w_ffc1", "b_ffc1", "w_ffc2", "b_ffc2")] + [
+        ("lora_qkv", rf_lora_seg), ("lora_out", rf_lora_seg), ("lora_ff2", rf_lora_seg)]
+
+
+class rf_single_block_weights(C.Structure):
+    _fields_ = [(n, _P) for n in ("w_qkv_mlp", "b_qkv_mlp", "norm_q", "norm_k", "w_out", "b_out")] + [
+        ("lora_qkv_mlp", rf_lora_seg), ("lora_out", rf_lora_seg)]
+
+
+class rf_flux_dims(C.Structure):
+    _fields_ = [("D", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32), ("S_txt", C.c_int32),
+                ("S_img", C.c_int32), ("S_cond", C.c_int32), ("attn_mode", C.c_int32), ("cross_bias", C.c_float),
+                ("lora_on_main", C.c_int32), ("add_cond_attn", C.c_int32)]
+
+
+class rf_workspace(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("bytes", C.c_int64)]
+
+
+class rf_flux_model(C.Structure):
+    _fields_ = [("num_double", C.c_int32), ("num_single", C.c_int32),
+                ("dbl", C.POINTER(rf_double_block_weights)), ("sgl", C.POINTER(rf_single_block_weights)),
+                ("w_x_embed", _P), ("b_x_embed", _P), ("lora_x_embed", rf_lora_seg),
+                ("w_ctx_embed", _P), ("b_ctx_embed", _P), ("w_proj_out", _P), ("b_proj_out", _P),
+                ("in_ch", C.c_int32), ("joint_dim", C.c_int32)]
+
+
+# every symbol include/rf_flux.h declares: (restype, argtypes)
+_SIGS = {
+    "rf_last_error": (C.c_char_p, []),
+    "rf_abi_version": (C.c_int, []),
+    "rf_target_arch": (C.c_int, []),
+    "rf_gemm_bf16": (C.c_int, [C.POINTER(rf_gemm_desc), _P]),
+    "rf_qk_rmsnorm_rope": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
+                                     C.c_float, _P]),
+    "rf_attention_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_float, C.c_float, _P]),
+    "rf_layernorm_modulate": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, _P]),
+    "rf_euler_step": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "rf_silu": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "rf_add_inplace": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "rf_workspace_bytes": (C.c_int64, [C.POINTER(rf_flux_dims)]),
+    "rf_double_block_fwd": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_double_block_weights), _P, _P, _P,
+                                      C.c_int64, _P, _P, _P, _P, _P, C.POINTER(rf_workspace), _P]),
+    "rf_single_block_fwd": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_single_block_weights), _P, _P,
+                                      C.c_int64, _P, _P, _P, _P, C.POINTER(rf_workspace), _P]),
+    "rf_mod_table_cols": (C.c_int64, [C.POINTER(rf_flux_model), C.c_int32]),
+    "rf_flux_forward": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_flux_model), _P, _P, _P, _P, _P, _P, _P, _P,
+                                  C.POINTER(rf_workspace), _P]),
+    "rf_flux_denoise": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_flux_model), _P, _P, _P, _P, C.c_int64, _P,
+                                  _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.POINTER(rf_workspace), _P]),
+    "rf_time_gemm": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
+}
+# test / tuning hook, not part of the declared drop-in surface
+_EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int])}
+
+_lib = None
+
+
+def load():
+    """dlopen librf_flux.so and bind every declared symbol; raises RFError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RFError(f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; "
+                      "run `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in {**_SIGS, **_EXTRA_SIGS}.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RFError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.rf_abi_version() != ABI_VERSION:
+        raise RFError(f"librf_flux ABI {lib.rf_abi_version()} != binding {ABI_VERSION}: rebuild")
+    if lib.rf_target_arch() != 950:
+        raise RFError("librf_flux was not built for gfx950")
+    _lib = lib
+    return lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().rf_last_error().decode(errors="replace")
+        raise RFError(f"{what or 'librf_flux'} failed with status {rc}: {msg}")

@@ -1,0 +1,252 @@
+// Non-causal flash attention forward for gfx950, head_dim 128, bf16 in / fp32 softmax.
+// Replaces F.scaled_dot_product_attention + the head transposes of the reference
+// (train_flux/flux/block.py:106-129), including its two condition-token variants:
+//   mode 1: additive bias log(c_factor) on the (main <-> condition) blocks  (block.py:115-122)
+//   mode 2: (main <-> condition) blocks masked out, union_cond_attn=False   (block.py:106-114)
+//
+// Design (DESIGN.md "K3"):
+//   * one workgroup = 4 waves x 32 query rows; the 64-key K tile [64][128] and V^T tile
+//     [128][64] are streamed HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered,
+//     one barrier per tile; both images are XOR-swizzled through the DMA source address so the
+//     ds_read_b128 fragment reads are bank-conflict free;
+//   * scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_32x32x16_bf16 with A=K, B=Q):
+//     every lane then owns ONE query row (q = lane & 31) and 16 of the 32 keys of a fragment,
+//     so the online softmax is lane-local (one cross-lane exchange per tile for the row max);
+//   * the output is accumulated transposed as well (O^T = V^T P^T): the softmax rescale factor
+//     of a query is a per-lane scalar, and P feeds the MFMA B operand straight from the
+//     registers it was exponentiated in.  The key order inside a tile is whatever the S^T
+//     accumulator layout yields; the producer GEMM stores V^T with the matching key
+//     permutation (bits 2,3 of the key index swapped), so no in-kernel transpose or permute
+//     of V or P is needed.
+#include "common.hpp"
+
+namespace rf {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+struct AttnParams {
+  const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
+  int heads, S, s_pad, n_main, mode, nqb;
+  int64_t ldo;
+  float cross_bias_l2;  // bias * log2(e)
+  float sl2;            // softmax scale * log2(e)
+};
+
+constexpr int ATT_QBLK = 128;        // query rows per workgroup (4 waves x 32)
+constexpr int ATT_KV = 64;           // keys per tile
+constexpr int ATT_K_BYTES = ATT_KV * 256;    // 16 KiB
+constexpr int ATT_V_BYTES = 128 * 128;       // 16 KiB
+constexpr int ATT_STAGE = ATT_K_BYTES + ATT_V_BYTES;
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // all query blocks of one head run on one XCD (block b -> XCD b % 8; heads % 8 == 0 in FLUX),
+  // so that head's K/V (2.4 MB at S=4608) stay resident in that XCD's L2.
+  const int head = blockIdx.x % p.heads;
+  const int qb = blockIdx.x / p.heads;
+  const int S = p.S;
+  const int q_row = qb * ATT_QBLK + w * 32 + l31;
+  const int q_ld = q_row < S ? q_row : S - 1;
+  const int ntiles = (S + ATT_KV - 1) / ATT_KV;
+
+  const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
+  const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q, h) holds d = ks*16 + h*8 .. +8 ---
+  bf16x8 qf[8];
+  {
+    const bf16_t* qp = p.q + ((int64_t)head * p.s_pad + q_ld) * 128 + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  // ---- LDS-DMA source offsets (elements) -------------------------------------------------
+  // K tile: instruction i of wave w fills rows (i*4+w)*4 + lane/16, physical chunk lane%16
+  int k_row[4], k_chunk[4];
+  int v_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + w) * 4 + (lane >> 4);
+    k_row[i] = row;
+    k_chunk[i] = ((lane & 15) ^ (row & 15)) * 8;
+    const int vrow = (i * 4 + w) * 8 + (lane >> 3);
+    v_off[i] = vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8);
+  }
+
+  auto stage = [&](int t, int buf) {
+    char* base = smem + buf * ATT_STAGE;
+    const int kv0 = t * ATT_KV;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int kv = kv0 + k_row[i];
+      kv = kv < S ? kv : S - 1;
+      __builtin_amdgcn_global_load_lds((glb_void*)(Kh + (int64_t)kv * 128 + k_chunk[i]),
+                                       (lds_void*)(base + (i * 4 + w) * 1024), 16, 0, 0);
+    }
+    const bf16_t* vt = Vh + (int64_t)t * (128 * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(vt + v_off[i]),
+                                       (lds_void*)(base + ATT_K_BYTES + (i * 4 + w) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- per-lane bias for the two key regions (log2 domain) -------------------------------
+  const float NEG_INF = -__builtin_huge_valf();
+  const bool q_is_cond = q_row >= p.n_main;
+  float badd_main = 0.f, badd_cond = 0.f;
+  if (p.mode == 1) {
+    badd_main = q_is_cond ? p.cross_bias_l2 : 0.f;
+    badd_cond = q_is_cond ? 0.f : p.cross_bias_l2;
+  } else if (p.mode == 2) {
+    badd_main = q_is_cond ? NEG_INF : 0.f;
+    badd_cond = q_is_cond ? 0.f : NEG_INF;
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -1e30f;  // running max (log2 domain), finite so that (-inf) - m is well defined
+  float l_run = 0.f;     // this lane's partial row sum (its 32 of the 64 keys per tile)
+
+  const int k_swz = l31 & 15;
+  const int v_swz = (l31 >> 1) & 7;
+
+  stage(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();  // tile t landed (vmcnt(0) inside); all waves finished tile t-1
+    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+    const char* kb = smem + (t & 1) * ATT_STAGE;
+    const char* vb = kb + ATT_K_BYTES;
+    const int kv0 = t * ATT_KV;
+
+    // ---- S^T = K Q^T : 2 key blocks x 8 k-steps -----------------------------------------
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kvb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kb + (kvb * 32 + l31) * 256 + (((ks * 2 + h) ^ k_swz) << 4));
+        sacc[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kvb], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax (lane-local: this lane's query, 32 of the tile's 64 keys) --------
+    const bool special = (kv0 + ATT_KV > S) || (p.mode != 0 && kv0 < p.n_main && kv0 + ATT_KV > p.n_main);
+    float tmax = NEG_INF;
+    if (!special) {
+      const float badd = (p.mode != 0 && kv0 >= p.n_main) ? badd_cond : badd_main;
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = sacc[kvb][r] * p.sl2 + badd;
+          sacc[kvb][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    } else {
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + kvb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float badd = kv >= S ? NEG_INF : (kv >= p.n_main ? badd_cond : badd_main);
+          const float x = sacc[kvb][r] * p.sl2 + badd;
+          sacc[kvb][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 t8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(sacc[kvb][s2 * 8 + j] - m_new);
+          psum += pv;
+          t8[j] = f2bf(pv);
+        }
+        pf[kvb * 2 + s2] = t8;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+    // ---- O^T += V^T P^T : 4 d-blocks x 4 key steps ---------------------------------------
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 vf = *(const bf16x8*)(vb + (db * 32 + l31) * 128 + (((s * 2 + h) ^ v_swz) << 4));
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[db], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane owns query q_row, d = db*32 + 8*rg + 4*h + (0..3) ----------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (q_row < S) {
+    bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        u32x2 v;
+        v[0] = pack2(oacc[db][rg * 4 + 0] * inv, oacc[db][rg * 4 + 1] * inv);
+        v[1] = pack2(oacc[db][rg * 4 + 2] * inv, oacc[db][rg * 4 + 3] * inv);
+        *(u32x2*)(orow + db * 32 + rg * 8) = v;
+      }
+  }
+}
+
+}  // namespace rf
+
+extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
+                                int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
+                                float cross_bias, float scale, void* stream) {
+  using namespace rf;
+  RF_REQUIRE(q && k && vt && out, RF_ERR_NULL, "rf_attention_fwd: NULL pointer");
+  RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0, RF_ERR_SHAPE,
+             "rf_attention_fwd: bad shape heads=%d S=%d s_pad=%d", heads, S, s_pad);
+  RF_REQUIRE(mode >= 0 && mode <= 2, RF_ERR_SHAPE, "rf_attention_fwd: mode=%d", mode);
+  RF_REQUIRE(aligned16(q) && aligned16(k) && aligned16(vt) && aligned16(out) && ldo % 4 == 0, RF_ERR_ALIGN,
+             "rf_attention_fwd: operands must be 16-byte aligned");
+  RF_REQUIRE(ldo >= (int64_t)heads * 128, RF_ERR_SHAPE, "rf_attention_fwd: ldo < heads*128");
+  if (mode == 0) n_main = S;
+  RF_REQUIRE(n_main >= 0 && n_main <= S, RF_ERR_SHAPE, "rf_attention_fwd: n_main=%d", n_main);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     2 * ATT_STAGE));
+    attr_set = true;
+  }
+  AttnParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
+  p.heads = heads; p.S = S; p.s_pad = s_pad; p.n_main = n_main; p.mode = mode;
+  p.nqb = cdiv(S, ATT_QBLK); p.ldo = ldo;
+  p.cross_bias_l2 = cross_bias * 1.4426950408889634f;
+  p.sl2 = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads * p.nqb), dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}

@@ -1,0 +1,94 @@
+// Shared device/host helpers for librf_flux (gfx950 only -- no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "rf_flux.h"
+
+namespace rf {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing (thread-local message, never throws across the C ABI) -------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define RF_CHECK_HIP(expr)                                   \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return ::rf::hip_fail(_e, #expr);  \
+  } while (0)
+
+#define RF_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) {                    \
+      ::rf::set_error(__VA_ARGS__);   \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+#define RF_LAUNCH_CHECK() RF_CHECK_HIP(hipGetLastError())
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---- bf16 <-> f32 (round-to-nearest-even, the same rounding torch uses) ---------------
+__device__ __forceinline__ float bf2f(bf16_t x) { return static_cast<float>(x); }
+__device__ __forceinline__ bf16_t f2bf(float x) { return static_cast<bf16_t>(x); }
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t lo16) { return __uint_as_float(lo16 << 16); }
+
+// unpack 8 bf16 (held as 4 x u32) to 8 floats
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(v[i] << 16);
+    f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+}
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  bf16x2 t;
+  t[0] = static_cast<bf16_t>(lo);
+  t[1] = static_cast<bf16_t>(hi);
+  return __builtin_bit_cast(uint32_t, t);
+}
+
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = pack2(f[2 * i], f[2 * i + 1]);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  // tanh(u) = 1 - 2 / (exp(2u) + 1); exp overflow -> inf -> tanh = 1 (correct limit)
+  const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+
+// XCD-aware, bijective block-id remap (8 XCDs, block b runs on XCD b % 8): give each XCD a
+// contiguous chunk of the logical tile space so neighbouring tiles share its private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  const int xcd = bid % nx, idx = bid / nx;
+  const int q = nwg / nx, r = nwg % nx;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+}  // namespace rf

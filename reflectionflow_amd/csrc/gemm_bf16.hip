@@ -1,0 +1,390 @@
+// bf16 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+//   out[m,n] = epi( sum_k A[m,k] W[n,k] (+ sum_k2 A2[m,k2] W2[n,k2]) + bias[n] )
+//
+// Design (CDNA4-first, see DESIGN.md "K1"):
+//   * block tile BM x BN x 64, 64-lane waves in a WM x WN grid, each wave owns a
+//     (BM/WM) x (BN/WN) sub-tile built from v_mfma_f32_32x32x16_bf16 fragments
+//     (fp32 accumulators stay in registers for the whole K loop);
+//   * operands are staged HBM -> LDS with the LDS-DMA path (global_load_lds_dwordx4, 16 B per
+//     lane, no VGPR round trip).  The DMA writes LDS lane-linearly, so the bank-conflict-free
+//     XOR swizzle is applied on the per-lane SOURCE address and mirrored on the ds_read_b128
+//     side (chunk' = chunk ^ ((row >> 1) & 7) for 128-byte rows);
+//   * two LDS stages, ONE barrier per K-tile: the DMA of tile t+1 flies while tile t is
+//     multiplied;
+//   * up to 4 token groups (text / image / condition streams) with their own A, W, bias, gate
+//     and output pointers ride in one launch, so the small text stream fills the tail of the
+//     grid instead of costing its own under-filled launch;
+//   * up to three K segments per group: segment 1/2 carry the second half of a concatenated
+//     input (single-block proj_out = [attn | mlp]) and/or LoRA (A = x.lora_A^T,
+//     W = scaling*lora_B) without materialising a concat or a merged weight;
+//   * blockIdx is remapped so that every XCD works on a contiguous chunk of tiles (private L2).
+#include "common.hpp"
+
+namespace rf {
+
+struct KSegDev {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  int nk;  // K-tiles (of 64) in this segment
+  int _pad;
+};
+
+struct GemmGroupDev {
+  KSegDev seg[3];
+  const bf16_t* bias;
+  bf16_t* out; int64_t ldo;
+  const bf16_t* residual; int64_t ldr;
+  const bf16_t* gate;
+  int M, tok_offset, tile_start, tiles_m;
+};
+
+struct GemmParams {
+  int N, epi, ngroups, n_split, heads, s_pad, tiles_n, total_tiles;
+  bf16_t* q; bf16_t* k; bf16_t* vt;
+  GemmGroupDev g[4];
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 32, FN = TN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int IA = BM * 8 / NT, IB = BN * 8 / NT;  // LDS-DMA instructions per thread per stage
+  static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
+  static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / WN, wn = w % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- tile decode (wave-uniform) -------------------------------------------------------
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  const int lt = tile - G.tile_start;
+  const int tn = lt % p.tiles_n, tm = lt / p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int M = G.M, N = p.N;
+
+  // ---- per-lane DMA source pointers -----------------------------------------------------
+  // DMA instruction i of wave w fills LDS bytes [(i*NW + w)*1024, +1024): 8 rows of 128 B.
+  // lane -> (row = +lane/8, physical chunk = lane%8); it fetches logical chunk = pc ^ swz(row).
+  const bf16_t* srcA[IA];
+  const bf16_t* srcB[IB];
+  auto setup_ptrs = [&](const bf16_t* Ab, int64_t lda, const bf16_t* Wb, int64_t ldw) {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int row = (i * NW + w) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int gm = m0 + row;
+      gm = gm < M ? gm : M - 1;
+      srcA[i] = Ab + (int64_t)gm * lda + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int row = (i * NW + w) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int gn = n0 + row;
+      gn = gn < N ? gn : N - 1;
+      srcB[i] = Wb + (int64_t)gn * ldw + chunk * 8;
+    }
+  };
+
+  auto stage = [&](int kt_in_seg, int buf) {
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[i] + (int64_t)kt_in_seg * 64),
+                                       (lds_void*)(base + (i * NW + w) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcB[i] + (int64_t)kt_in_seg * 64),
+                                       (lds_void*)(base + A_BYTES + (i * NW + w) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (bytes): row*128 + ((ks*2 + h) ^ swz)*16, swz = (l31>>1)&7
+  const int swz = (l31 >> 1) & 7;
+  const int a_row_off = (wm * TM + l31) * 128;
+  const int b_row_off = A_BYTES + (wn * TN + l31) * 128;
+
+  // K loop over the concatenation of this group's segments; (seg, kk) is the NEXT tile to stage
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  int seg = 0, kk = 0, cur_nk = G.seg[0].nk;
+  auto advance = [&]() {  // move (seg,kk) to the next tile; re-point the DMA sources at a boundary.
+    ++kk;                 // (host side compacts segments, so a used segment is never followed by an empty one)
+    if (kk >= cur_nk) {
+      kk = 0;
+      ++seg;
+      if (seg == 1 && G.seg[1].nk > 0) {
+        cur_nk = G.seg[1].nk;
+        setup_ptrs(G.seg[1].A, G.seg[1].lda, G.seg[1].W, G.seg[1].ldw);
+      } else if (seg == 2 && G.seg[2].nk > 0) {
+        cur_nk = G.seg[2].nk;
+        setup_ptrs(G.seg[2].A, G.seg[2].lda, G.seg[2].W, G.seg[2].ldw);
+      }
+    }
+  };
+  setup_ptrs(G.seg[0].A, G.seg[0].lda, G.seg[0].W, G.seg[0].ldw);  // segment 0 is never empty
+  stage(0, 0);
+  advance();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();  // tile kt has landed (vmcnt(0) inside); every wave is done with tile kt-1
+    if (kt + 1 < nk) {
+      stage(kk, (kt + 1) & 1);
+      advance();
+    }
+    const char* base = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((ks * 2 + h) ^ swz) << 4;
+      bf16x8 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(base + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(base + b_row_off + j * 32 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------
+  // accumulator layout (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  int epi = p.epi;
+  int ncol_base = 0;  // column offset subtracted for the GELU half of QKV_GELU
+  if (epi == RF_EPI_QKV_GELU) {
+    if (n0 >= p.n_split) {
+      epi = RF_EPI_GELU;
+      ncol_base = p.n_split;
+    } else {
+      epi = RF_EPI_QKV;
+    }
+  }
+  const int DH = p.heads * 128;
+
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * TN + j * 32 + l31;
+    const bool nok = n < N;
+    const float bias_v = (G.bias != nullptr && nok) ? bf2f(G.bias[n]) : 0.f;
+    float gate_v = 0.f;
+    if (epi == RF_EPI_GATE_RES && nok) gate_v = bf2f(G.gate[n]);
+    // QKV destination decode for this column
+    int which = 0, head = 0, d = 0;
+    if (epi == RF_EPI_QKV && nok) {
+      which = n / DH;
+      const int rem = n - which * DH;
+      head = rem >> 7;
+      d = rem & 127;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int mrow0 = m0 + wm * TM + i * 32 + 4 * h;
+      if (epi == RF_EPI_QKV) {
+        if (!nok) continue;
+        if (which < 2) {
+          bf16_t* dst = (which == 0 ? p.q : p.k) + ((int64_t)head * p.s_pad) * 128 + d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < M) dst[(int64_t)(G.tok_offset + m) * 128] = f2bf(acc[i][j][r] + bias_v);
+          }
+        } else {
+          // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped
+          bf16_t* dst = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64) + d * 64;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int m = mrow0 + 8 * rg;
+            const int tok = G.tok_offset + m;
+            if (((tok & 3) == 0) && (m + 3 < M)) {
+              const int pos = (tok & 51) | ((tok & 4) << 1) | ((tok & 8) >> 1);  // within tile
+              u32x2 v;
+              v[0] = pack2(acc[i][j][rg * 4 + 0] + bias_v, acc[i][j][rg * 4 + 1] + bias_v);
+              v[1] = pack2(acc[i][j][rg * 4 + 2] + bias_v, acc[i][j][rg * 4 + 3] + bias_v);
+              *(u32x2*)(dst + (int64_t)(tok >> 6) * (128 * 64) + pos) = v;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int t2 = tok + e;
+                if (m + e < M) {
+                  const int pos = (t2 & 51) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
+                  dst[(int64_t)(t2 >> 6) * (128 * 64) + pos] = f2bf(acc[i][j][rg * 4 + e] + bias_v);
+                }
+              }
+            }
+          }
+        }
+      } else {
+        if (!nok) continue;
+        bf16_t* orow = G.out + (n - ncol_base);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+          if (m < M) {
+            float v = acc[i][j][r] + bias_v;
+            if (epi == RF_EPI_GELU) {
+              v = gelu_tanh(v);
+            } else if (epi == RF_EPI_GATE_RES) {
+              v = (G.residual != nullptr ? bf2f(G.residual[(int64_t)m * G.ldr + n]) : 0.f) + gate_v * v;
+            }
+            orow[(int64_t)m * G.ldo] = f2bf(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  p.tiles_n = cdiv(p.N, BN);
+  int start = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    p.g[g].tiles_m = cdiv(p.g[g].M, BM);
+    p.g[g].tile_start = start;
+    start += p.g[g].tiles_m * p.tiles_n;
+  }
+  p.total_tiles = start;
+  if (start == 0) return RF_OK;
+  hipLaunchKernelGGL(kern, dim3(start), dim3(WM * WN * 64), LDS, stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 = forced (used by tests and the tuner)
+
+static int build_params(const rf_gemm_desc* d, GemmParams& p) {
+  RF_REQUIRE(d != nullptr, RF_ERR_NULL, "rf_gemm_bf16: desc is NULL");
+  RF_REQUIRE(d->N > 0, RF_ERR_SHAPE, "rf_gemm_bf16: N=%d", d->N);
+  RF_REQUIRE(d->num_groups >= 1 && d->num_groups <= 4, RF_ERR_SHAPE, "rf_gemm_bf16: num_groups=%d", d->num_groups);
+  RF_REQUIRE(d->epilogue >= RF_EPI_STORE && d->epilogue <= RF_EPI_QKV_GELU, RF_ERR_SHAPE, "rf_gemm_bf16: bad epilogue %d",
+             d->epilogue);
+  memset(&p, 0, sizeof(p));
+  p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
+  p.heads = d->heads; p.s_pad = d->s_pad;
+  p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
+  const bool qkv = d->epilogue == RF_EPI_QKV || d->epilogue == RF_EPI_QKV_GELU;
+  if (qkv) {
+    RF_REQUIRE(d->q && d->k && d->vt, RF_ERR_NULL, "rf_gemm_bf16: QKV epilogue needs q,k,vt");
+    RF_REQUIRE(d->heads > 0 && d->s_pad > 0 && d->s_pad % 64 == 0, RF_ERR_SHAPE, "rf_gemm_bf16: bad heads/s_pad");
+    const int qkv_cols = d->epilogue == RF_EPI_QKV ? d->N : d->n_split;
+    RF_REQUIRE(qkv_cols == 3 * d->heads * 128, RF_ERR_SHAPE, "rf_gemm_bf16: QKV columns %d != 3*heads*128", qkv_cols);
+    if (d->epilogue == RF_EPI_QKV_GELU)
+      RF_REQUIRE(d->n_split % 256 == 0 && d->n_split < d->N, RF_ERR_SHAPE, "rf_gemm_bf16: n_split must be tile aligned");
+  }
+  int ng = 0;
+  for (int g = 0; g < d->num_groups; ++g) {
+    const rf_gemm_group& s = d->g[g];
+    if (s.M <= 0) continue;  // empty token group (e.g. no condition): skip
+    GemmGroupDev& t = p.g[ng++];
+    RF_REQUIRE(s.seg[0].K > 0, RF_ERR_SHAPE, "rf_gemm_bf16: group %d segment 0 is empty", g);
+    int ns = 0;
+    for (int k = 0; k < 3; ++k) {
+      const rf_kseg& ks = s.seg[k];
+      if (ks.K <= 0) continue;
+      RF_REQUIRE(ks.K % 64 == 0, RF_ERR_SHAPE, "rf_gemm_bf16: group %d segment %d K=%d not a multiple of 64", g, k, ks.K);
+      RF_REQUIRE(ks.A && ks.W, RF_ERR_NULL, "rf_gemm_bf16: group %d segment %d A/W NULL", g, k);
+      RF_REQUIRE(aligned16(ks.A) && aligned16(ks.W) && ks.lda % 8 == 0 && ks.ldw % 8 == 0, RF_ERR_ALIGN,
+                 "rf_gemm_bf16: group %d segment %d operands must be 16-byte aligned", g, k);
+      KSegDev& kd = t.seg[ns++];  // compact: empty segments are dropped
+      kd.A = (const bf16_t*)ks.A; kd.lda = ks.lda; kd.W = (const bf16_t*)ks.W; kd.ldw = ks.ldw; kd.nk = ks.K / 64;
+    }
+    t.bias = (const bf16_t*)s.bias;
+    t.M = s.M; t.tok_offset = s.tok_offset;
+    t.out = (bf16_t*)s.out; t.ldo = s.ldo;
+    t.residual = (const bf16_t*)s.residual; t.ldr = s.ldr; t.gate = (const bf16_t*)s.gate;
+    if (d->epilogue != RF_EPI_QKV) RF_REQUIRE(s.out != nullptr, RF_ERR_NULL, "rf_gemm_bf16: group %d out NULL", g);
+    if (d->epilogue == RF_EPI_GATE_RES) RF_REQUIRE(s.gate != nullptr, RF_ERR_NULL, "rf_gemm_bf16: GATE_RES needs gate");
+    if (qkv) RF_REQUIRE(s.tok_offset >= 0 && s.tok_offset + s.M <= d->s_pad, RF_ERR_SHAPE, "rf_gemm_bf16: tokens exceed s_pad");
+  }
+  p.ngroups = ng;
+  return RF_OK;
+}
+
+static int dispatch(GemmParams& p, hipStream_t stream) {
+  if (p.ngroups == 0) return RF_OK;
+  int64_t rows = 0;
+  for (int g = 0; g < p.ngroups; ++g) rows += p.g[g].M;
+  int tile = g_force_tile;
+  if (tile == 0) {
+    // 256^2 tiles only pay when they still fill the 256 CUs; small problems get 128^2.
+    const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
+    tile = (t256 >= 200) ? 256 : 128;
+  }
+  if (tile == 256) return launch_gemm<256, 256, 2, 4>(p, stream);
+  return launch_gemm<128, 128, 2, 2>(p, stream);
+}
+
+}  // namespace rf
+
+extern "C" int rf_gemm_bf16(const rf_gemm_desc* d, void* stream) {
+  rf::GemmParams p;
+  int rc = rf::build_params(d, p);
+  if (rc != RF_OK) return rc;
+  return rf::dispatch(p, (hipStream_t)stream);
+}
+
+// test / tuning hook (not part of the drop-in surface): force a tile config (0 = heuristic)
+extern "C" int rf_debug_force_gemm_tile(int tile) {
+  if (tile != 0 && tile != 128 && tile != 256) return RF_ERR_SHAPE;
+  rf::g_force_tile = tile;
+  return RF_OK;
+}
+
+extern "C" int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream) {
+  rf::GemmParams p;
+  int rc = rf::build_params(d, p);
+  if (rc != RF_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  RF_CHECK_HIP(hipEventCreate(&e0));
+  RF_CHECK_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) {
+    rc = rf::dispatch(p, s);
+    if (rc != RF_OK) return rc;
+  }
+  RF_CHECK_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) rf::dispatch(p, s);
+  RF_CHECK_HIP(hipEventRecord(e1, s));
+  RF_CHECK_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  RF_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *us = ms * 1000.f / (float)iters;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return RF_OK;
+}

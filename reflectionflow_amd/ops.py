@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the librf_flux C ABI.
+
+Every function takes bf16 tensors resident on a HIP device, enqueues the kernel on torch's
+CURRENT stream and returns immediately.  There is no CPU path: a CPU tensor or a missing
+library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import (RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, RF_EPI_STORE, RFError)
+
+__all__ = ["linear", "gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
+           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError"]
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+    if not isinstance(t, torch.Tensor):
+        raise RFError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RFError(f"{name}: tensor is on {t.device}; the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise RFError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    return t
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    _chk(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RFError(f"{name}: need a 2-D row-major tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+class Seg:
+    """One K-segment: activations A [M,K] and weights W [N,K] (nn.Linear layout)."""
+
+    def __init__(self, A: torch.Tensor, W: torch.Tensor):
+        self.A, self.W = _rows2d(A, "A"), _rows2d(W, "W")
+        if A.shape[1] != W.shape[1]:
+            raise RFError(f"segment K mismatch: A {tuple(A.shape)} vs W {tuple(W.shape)}")
+
+
+class Group:
+    """One token group of a grouped GEMM."""
+
+    def __init__(self, segs: Sequence[Seg], bias=None, out=None, residual=None, gate=None, tok_offset=0):
+        self.segs, self.bias, self.out, self.residual, self.gate, self.tok_offset = (
+            list(segs), bias, out, residual, gate, tok_offset)
+
+
+def gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
+         q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0):
+    lib = L.load()
+    d = L.rf_gemm_desc()
+    d.N, d.epilogue, d.num_groups, d.n_split = N, epilogue, len(groups), n_split
+    d.q, d.k, d.vt, d.heads, d.s_pad = ptr(q), ptr(k), ptr(vt), heads, s_pad
+    keep = []
+    for gi, g in enumerate(groups):
+        G = d.g[gi]
+        G.M = g.segs[0].A.shape[0]
+        G.tok_offset = g.tok_offset
+        for si, s in enumerate(g.segs):
+            if s.A.shape[0] != G.M:
+                raise RFError("all segments of a group must have the same M")
+            if s.W.shape[0] != N:
+                raise RFError(f"W has {s.W.shape[0]} rows, expected N={N}")
+            S = G.seg[si]
+            S.A, S.lda, S.W, S.ldw, S.K = s.A.data_ptr(), s.A.stride(0), s.W.data_ptr(), s.W.stride(0), s.A.shape[1]
+        if g.bias is not None:
+            G.bias = _chk(g.bias, "bias").data_ptr()
+        if g.out is not None:
+            o = _rows2d(g.out, "out")
+            G.out, G.ldo = o.data_ptr(), o.stride(0)
+        if g.residual is not None:
+            r = _rows2d(g.residual, "residual")
+            G.residual, G.ldr = r.data_ptr(), r.stride(0)
+        if g.gate is not None:
+            G.gate = _chk(g.gate, "gate").data_ptr()
+        keep.append(g)
+    L.check(lib.rf_gemm_bf16(C.byref(d), stream_ptr()), "rf_gemm_bf16")
+
+
+def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = RF_EPI_STORE,
+           residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
+           extra: Sequence[Seg] = (), out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epi(x @ W^T (+ extra segments) + bias), x [M,K] bf16, W [N,K] bf16."""
+    x = _rows2d(x, "x")
+    N = W.shape[0]
+    if out is None:
+        out = torch.empty(x.shape[0], N, dtype=torch.bfloat16, device=x.device)
+    gemm([Group([Seg(x, W), *extra], bias=bias, out=out, residual=residual, gate=gate)], N, epilogue)
+    return out
+
+
+def alloc_attn_operands(heads: int, S: int, device) -> tuple:
+    """q, k [H, S_pad, 128] and vt [H, S_pad/64, 128, 64]; zero-filled so padded keys are finite."""
+    s_pad = (S + 63) // 64 * 64
+    q = torch.zeros(heads, s_pad, 128, dtype=torch.bfloat16, device=device)
+    k = torch.zeros_like(q)
+    vt = torch.zeros(heads, s_pad // 64, 128, 64, dtype=torch.bfloat16, device=device)
+    return q, k, vt, s_pad
+
+
+def qk_rmsnorm_rope(q, k, S: int, n_added: int, w_q, w_k, w_added_q, w_added_k, cos, sin, eps: float = 1e-6):
+    lib = L.load()
+    _chk(q, "q"), _chk(k, "k"), _chk(cos, "cos", torch.float32), _chk(sin, "sin", torch.float32)
+    if cos.shape != (S, 128) or sin.shape != (S, 128) or not cos.is_contiguous() or not sin.is_contiguous():
+        raise RFError(f"cos/sin must be contiguous fp32 [{S},128], got {tuple(cos.shape)}")
+    heads, s_pad = q.shape[0], q.shape[1]
+    L.check(lib.rf_qk_rmsnorm_rope(q.data_ptr(), k.data_ptr(), heads, S, s_pad, n_added, ptr(w_q), ptr(w_k),
+                                   ptr(w_added_q), ptr(w_added_k), cos.data_ptr(), sin.data_ptr(), eps,
+                                   stream_ptr()), "rf_qk_rmsnorm_rope")
+
+
+def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
+              cross_bias: float = 0.0, scale: Optional[float] = None) -> torch.Tensor:
+    lib = L.load()
+    _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
+    heads, s_pad = q.shape[0], q.shape[1]
+    if out is None:
+        out = torch.empty(S, heads * 128, dtype=torch.bfloat16, device=q.device)
+    _rows2d(out, "out")
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    L.check(lib.rf_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), heads, S, s_pad,
+                                 out.stride(0), S if n_main is None else n_main, mode, cross_bias, scale,
+                                 stream_ptr()), "rf_attention_fwd")
+    return out
+
+
+def layernorm_modulate(x, scale, shift, out: Optional[torch.Tensor] = None, eps: float = 1e-6) -> torch.Tensor:
+    lib = L.load()
+    x = _rows2d(x, "x")
+    _chk(scale, "scale"), _chk(shift, "shift")
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(lib.rf_layernorm_modulate(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1],
+                                      scale.data_ptr(), shift.data_ptr(), eps, stream_ptr()), "rf_layernorm_modulate")
+    return out
+
+
+def euler_step_(x: torch.Tensor, v: torch.Tensor, dt: float):
+    lib = L.load()
+    _chk(x, "x"), _chk(v, "v")
+    if not (x.is_contiguous() and v.is_contiguous()) or x.numel() != v.numel():
+        raise RFError("euler_step_: x and v must be contiguous and equally sized")
+    L.check(lib.rf_euler_step(x.data_ptr(), v.data_ptr(), x.numel(), float(dt), stream_ptr()), "rf_euler_step")
+    return x
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    lib = L.load()
+    _chk(x, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    L.check(lib.rf_silu(x.data_ptr(), out.data_ptr(), x.numel(), stream_ptr()), "rf_silu")
+    return out
+
+
+def add_(out: torch.Tensor, x: torch.Tensor):
+    lib = L.load()
+    _chk(out, "out"), _chk(x, "x")
+    if not (out.is_contiguous() and x.is_contiguous()) or x.numel() != out.numel():
+        raise RFError("add_: tensors must be contiguous and equally sized")
+    L.check(lib.rf_add_inplace(out.data_ptr(), x.data_ptr(), x.numel(), stream_ptr()), "rf_add_inplace")
+    return out

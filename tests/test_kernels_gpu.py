@@ -1,0 +1,303 @@
+"""GPU parity of every HIP kernel behind the C ABI, one op at a time.
+
+Reference = fp32 torch math on the same inputs (for the leaf semantics: the oracle's own
+RMSNorm / apply_rotary_emb / F.scaled_dot_product_attention restatement).  Tolerances are
+stated against the fp32 result and sized by bf16 output rounding (rel 2^-8 = 3.9e-3).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from reflectionflow_amd import _lib
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dev, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else (hash(shape) % 100000))
+    return (torch.randn(*shape, generator=g) * scale).to(dev).to(BF)
+
+
+def assert_close(got, ref, what, rtol=1.2e-2, atol=None):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    if atol is None:
+        atol = 1.2e-2 * float(ref.abs().mean()) + 1e-6
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    rel_l2 = float((got - ref).norm() / (ref.norm() + 1e-12))
+    if bad.any():
+        idx = torch.nonzero(bad)[:8].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} elements off, max err {float(err.max()):.4g}, "
+                             f"rel-L2 {rel_l2:.3e}, first bad idx {idx}, got {got[bad][:4].tolist()} ref {ref[bad][:4].tolist()}")
+    assert rel_l2 < 4e-3, f"{what}: rel-L2 {rel_l2:.3e}"
+    return rel_l2
+
+
+# ------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 768, 512), (512, 64, 256), (1, 512, 256),
+                                   (1024, 1536, 1024)])
+def test_gemm_store(dev, tile, M, N, K):
+    from reflectionflow_amd import _lib, ops
+    _lib.load().rf_debug_force_gemm_tile(tile)
+    try:
+        x, W, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.05), rnd(N, dev=dev)
+        y = ops.linear(x, W, b)
+        ref = x.float() @ W.float().t() + b.float()
+        assert_close(y, ref, f"gemm store {M}x{N}x{K} tile{tile}")
+        y2 = ops.linear(x, W, None)
+        assert_close(y2, x.float() @ W.float().t(), "gemm no-bias")
+    finally:
+        _lib.load().rf_debug_force_gemm_tile(0)
+
+
+def test_gemm_transpose_detecting(dev):
+    """A = I against an asymmetric W catches a swapped C layout (guide G9)."""
+    from reflectionflow_amd import ops
+    K = 128
+    x = torch.eye(K, device=dev, dtype=BF)
+    W = (torch.arange(K * 192, device=dev).reshape(192, K) % 251).to(BF) / 64
+    y = ops.linear(x, W)
+    assert torch.equal(y.float(), W.float().t())
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_epilogues_and_segments(dev, tile):
+    from reflectionflow_amd import _lib, ops
+    from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, Group, Seg
+    _lib.load().rf_debug_force_gemm_tile(tile)
+    try:
+        M, N, K = 520, 384, 256
+        x, W, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.05), rnd(N, dev=dev)
+        acc = x.float() @ W.float().t() + b.float()
+        assert_close(ops.linear(x, W, b, epilogue=RF_EPI_GELU), F.gelu(acc, approximate="tanh"), "gelu")
+        res, gate = rnd(M, N, dev=dev), rnd(N, dev=dev)
+        assert_close(ops.linear(x, W, b, epilogue=RF_EPI_GATE_RES, residual=res, gate=gate),
+                     res.float() + gate.float() * acc, "gate_res")
+        # in place on the residual (how the engine uses it)
+        res2 = res.clone()
+        ops.linear(x, W, b, epilogue=RF_EPI_GATE_RES, residual=res2, gate=gate, out=res2)
+        assert_close(res2, res.float() + gate.float() * acc, "gate_res in place")
+        # residual == NULL means 0
+        assert_close(ops.linear(x, W, b, epilogue=RF_EPI_GATE_RES, gate=gate), gate.float() * acc, "gate no residual")
+        # three K segments: [x | x2 | t] . [W | W2 | B]^T   (concat input + LoRA)
+        x2, W2 = rnd(M, 128, dev=dev), rnd(N, 128, dev=dev, scale=0.05)
+        t, Bm = rnd(M, 64, dev=dev), rnd(N, 64, dev=dev, scale=0.05)
+        y = ops.linear(x, W, b, extra=[Seg(x2, W2), Seg(t, Bm)])
+        ref = acc + x2.float() @ W2.float().t() + t.float() @ Bm.float().t()
+        assert_close(y, ref, "3 segments")
+        # strided views: A and W as column slices of wider matrices (single-block proj_out)
+        big_a, big_w = rnd(M, 640, dev=dev), rnd(N, 640, dev=dev, scale=0.05)
+        y = ops.linear(big_a[:, 128:384], big_w[:, 128:384], b)
+        assert_close(y, big_a[:, 128:384].float() @ big_w[:, 128:384].float().t() + b.float(), "strided operands")
+        # grouped: three token groups with their own weights / outputs, one with an extra segment
+        Ms = [96, 700, 130]
+        xs = [rnd(m, K, dev=dev, seed=10 + i) for i, m in enumerate(Ms)]
+        Ws = [rnd(N, K, dev=dev, scale=0.05, seed=20 + i) for i in range(3)]
+        bs = [rnd(N, dev=dev, seed=30 + i) for i in range(3)]
+        outs = [torch.empty(m, N, device=dev, dtype=BF) for m in Ms]
+        tl, Bl = rnd(Ms[2], 64, dev=dev), rnd(N, 64, dev=dev, scale=0.05)
+        groups = [Group([Seg(xs[0], Ws[0])], bias=bs[0], out=outs[0]),
+                  Group([Seg(xs[1], Ws[1])], bias=bs[1], out=outs[1]),
+                  Group([Seg(xs[2], Ws[2]), Seg(tl, Bl)], bias=bs[2], out=outs[2])]
+        ops.gemm(groups, N)
+        for i in range(3):
+            ref = xs[i].float() @ Ws[i].float().t() + bs[i].float()
+            if i == 2:
+                ref = ref + tl.float() @ Bl.float().t()
+            assert_close(outs[i], ref, f"group {i}")
+    finally:
+        _lib.load().rf_debug_force_gemm_tile(0)
+
+
+def vt_unpermute(vt, S):
+    """[H, S_pad/64, 128, 64] key-permuted V^T tiles -> [H, S, 128]."""
+    H, nt = vt.shape[0], vt.shape[1]
+    kv = torch.arange(64, device=vt.device)
+    pos = (kv & 51) | ((kv & 4) << 1) | ((kv & 8) >> 1)
+    v = vt[:, :, :, pos]                      # [H, nt, 128, 64(kv)]
+    return v.permute(0, 1, 3, 2).reshape(H, nt * 64, 128)[:, :S]
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("St,Si,Sc", [(32, 64, 16), (30, 70, 13), (512, 256, 0)])
+def test_gemm_qkv_epilogues(dev, tile, St, Si, Sc):
+    from reflectionflow_amd import _lib, ops
+    from reflectionflow_amd.ops import RF_EPI_QKV, RF_EPI_QKV_GELU, Group, Seg
+    _lib.load().rf_debug_force_gemm_tile(tile)
+    try:
+        H, D, MLP = 2, 256, 512
+        S = St + Si + Sc
+        q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+        xt, xi = rnd(St, D, dev=dev, seed=1), rnd(Si, D, dev=dev, seed=2)
+        Wt, Wi = rnd(3 * D, D, dev=dev, scale=0.05, seed=3), rnd(3 * D, D, dev=dev, scale=0.05, seed=4)
+        bt, bi = rnd(3 * D, dev=dev, seed=5), rnd(3 * D, dev=dev, seed=6)
+        groups = [Group([Seg(xt, Wt)], bias=bt, tok_offset=0), Group([Seg(xi, Wi)], bias=bi, tok_offset=St)]
+        refs = [xt.float() @ Wt.float().t() + bt.float(), xi.float() @ Wi.float().t() + bi.float()]
+        if Sc:
+            xc = rnd(Sc, D, dev=dev, seed=7)
+            groups.append(Group([Seg(xc, Wi)], bias=bi, tok_offset=St + Si))
+            refs.append(xc.float() @ Wi.float().t() + bi.float())
+        ops.gemm(groups, 3 * D, RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad)
+        ref = torch.cat(refs, 0)                       # [S, 3D]
+        rq, rk, rv = (ref[:, i * D:(i + 1) * D].reshape(S, H, 128).permute(1, 0, 2) for i in range(3))
+        assert_close(q[:, :S], rq, "q head-major")
+        assert_close(k[:, :S], rk, "k head-major")
+        assert_close(vt_unpermute(vt, S), rv, "v^T tiles")
+        # fused single-block flavour: [q|k|v|mlp] with GELU on the mlp columns
+        q2, k2, vt2, _ = ops.alloc_attn_operands(H, S, dev)
+        xm = torch.cat([xt, xi], 0)
+        Wf, bf_ = rnd(3 * D + MLP, D, dev=dev, scale=0.05, seed=8), rnd(3 * D + MLP, dev=dev, seed=9)
+        hid = torch.empty(S, MLP, device=dev, dtype=BF)
+        groups = [Group([Seg(xm, Wf)], bias=bf_, out=hid[:St + Si], tok_offset=0)]
+        if Sc:
+            groups.append(Group([Seg(xc, Wf)], bias=bf_, out=hid[St + Si:], tok_offset=St + Si))
+        ops.gemm(groups, 3 * D + MLP, RF_EPI_QKV_GELU, n_split=3 * D, q=q2, k=k2, vt=vt2, heads=H, s_pad=s_pad)
+        xa = torch.cat([xm, xc], 0) if Sc else xm
+        ref = xa.float() @ Wf.float().t() + bf_.float()
+        rq, rk, rv = (ref[:, i * D:(i + 1) * D].reshape(S, H, 128).permute(1, 0, 2) for i in range(3))
+        assert_close(q2[:, :S], rq, "fused q")
+        assert_close(k2[:, :S], rk, "fused k")
+        assert_close(vt_unpermute(vt2, S), rv, "fused v^T")
+        assert_close(hid, F.gelu(ref[:, 3 * D:], approximate="tanh"), "fused mlp gelu")
+    finally:
+        _lib.load().rf_debug_force_gemm_tile(0)
+
+
+# ------------------------------------------------------------------------------------- row kernels
+@pytest.mark.parametrize("rows,D", [(5, 256), (130, 3072), (64, 1024), (7, 2560)])
+def test_layernorm_modulate(dev, rows, D):
+    from reflectionflow_amd import ops
+    x, sc, sh = rnd(rows, D, dev=dev, scale=2.0), rnd(D, dev=dev, scale=0.3), rnd(D, dev=dev, scale=0.3)
+    y = ops.layernorm_modulate(x, sc, sh)
+    ref = F.layer_norm(x.float(), (D,), eps=1e-6) * (1 + sc.float()) + sh.float()
+    assert_close(y, ref, f"ln_mod {rows}x{D}")
+
+
+@pytest.mark.parametrize("S,n_added", [(70, 30), (128, 0), (513, 512)])
+def test_qk_rmsnorm_rope(dev, S, n_added):
+    from oracle import flux_oracle as O
+    from reflectionflow_amd import ops
+    H = 3
+    q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+    q[:, :S] = rnd(H, S, 128, dev=dev, seed=1)
+    k[:, :S] = rnd(H, S, 128, dev=dev, seed=2)
+    q0, k0 = q.clone(), k.clone()
+    ws = [(1 + 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(i))).to(dev).to(BF) for i in range(4)]
+    ids = torch.cat([torch.zeros(n_added, 3), O.prepare_latent_image_ids(1, S - n_added) * 3], 0)
+    ids[:, 1] = torch.arange(S) % 17
+    cos, sin = O.FluxPosEmbed(10000, (16, 56, 56))(ids)
+    cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+    ops.qk_rmsnorm_rope(q, k, S, n_added, ws[0], ws[1], ws[2], ws[3], cos, sin)
+
+    def ref_one(x, w_main, w_added):
+        x = x[:, :S].float()[None]                      # [1,H,S,128]
+        var = x.pow(2).mean(-1, keepdim=True)
+        xn = x * torch.rsqrt(var + 1e-6)
+        wsel = torch.where((torch.arange(S, device=dev) < n_added)[:, None], w_added.float()[None], w_main.float()[None])
+        return O.apply_rotary_emb(xn * wsel[None, None], (cos, sin))[0]
+
+    assert_close(q[:, :S], ref_one(q0, ws[0], ws[2]), "q norm+rope")
+    assert_close(k[:, :S], ref_one(k0, ws[1], ws[3]), "k norm+rope")
+    if s_pad > S:
+        assert torch.equal(q[:, S:], q0[:, S:]), "padding rows must stay untouched"
+
+
+def test_elementwise(dev):
+    from reflectionflow_amd import ops
+    for n in (64 * 4096, 1000, 7):
+        x, v = rnd(n, dev=dev, seed=1), rnd(n, dev=dev, seed=2)
+        ref = (x.float() + (-0.02) * v.float())
+        ops.euler_step_(x, v, -0.02)
+        assert_close(x, ref, f"euler n={n}", atol=1e-2)
+        a, b = rnd(n, dev=dev, seed=3), rnd(n, dev=dev, seed=4)
+        ref = a.float() + b.float()
+        assert_close(ops.add_(a, b), ref, "add", atol=2e-2)
+        s = rnd(n, dev=dev, seed=5, scale=3)
+        assert_close(ops.silu(s), F.silu(s.float()), "silu", atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------- attention
+def make_qkv(H, S, dev, seed=0, qscale=1.0):
+    from reflectionflow_amd import ops
+    q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+    qf = rnd(H, S, 128, dev=dev, seed=seed + 1, scale=qscale)
+    kf = rnd(H, S, 128, dev=dev, seed=seed + 2)
+    vf = rnd(H, S, 128, dev=dev, seed=seed + 3)
+    q[:, :S], k[:, :S] = qf, kf
+    kv = torch.arange(s_pad, device=dev)
+    pos = (kv & ~63) | (kv & 51) | ((kv & 4) << 1) | ((kv & 8) >> 1)
+    vpad = torch.zeros(H, s_pad, 128, device=dev, dtype=BF)
+    vpad[:, :S] = vf
+    vperm = torch.empty_like(vpad)
+    vperm[:, pos] = vpad                               # permuted position <- key
+    vt.copy_(vperm.reshape(H, s_pad // 64, 64, 128).permute(0, 1, 3, 2))
+    return q, k, vt, qf, kf, vf
+
+
+def sdpa_ref(qf, kf, vf, mask=None):
+    o = F.scaled_dot_product_attention(qf.float()[None], kf.float()[None], vf.float()[None], attn_mask=mask)
+    return o[0].permute(1, 0, 2).reshape(qf.shape[1], -1)
+
+
+@pytest.mark.parametrize("S", [64, 100, 128, 333, 768, 1500])
+def test_attention_plain(dev, S):
+    from reflectionflow_amd import ops
+    H = 2
+    q, k, vt, qf, kf, vf = make_qkv(H, S, dev, seed=S)
+    o = ops.attention(q, k, vt, S)
+    assert_close(o, sdpa_ref(qf, kf, vf), f"attention S={S}", atol=4e-3)
+
+
+def test_attention_peaked_rows(dev):
+    """Large logits: exercises the online-softmax rescale (running max jumps between tiles)."""
+    from reflectionflow_amd import ops
+    H, S = 1, 512
+    q, k, vt, qf, kf, vf = make_qkv(H, S, dev, seed=5, qscale=6.0)
+    o = ops.attention(q, k, vt, S)
+    assert_close(o, sdpa_ref(qf, kf, vf), "attention peaked", atol=1.5e-2)
+
+
+@pytest.mark.parametrize("S,n_main", [(192, 128), (200, 150), (333, 300), (640, 512)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_attention_cond_modes(dev, S, n_main, mode):
+    """block.py:106-122: additive log(c_factor) bias / block mask between main and condition tokens."""
+    from reflectionflow_amd import ops
+    H = 2
+    q, k, vt, qf, kf, vf = make_qkv(H, S, dev, seed=S + mode)
+    bias = math.log(1.5)
+    o = ops.attention(q, k, vt, S, n_main=n_main, mode=mode, cross_bias=bias)
+    n = S - n_main
+    if mode == 1:
+        mask = torch.zeros(S, S, device=dev)
+        mask[-n:, :-n] = bias
+        mask[:-n, -n:] = bias
+    else:
+        mask = torch.ones(S, S, device=dev, dtype=torch.bool)
+        mask[-n:, :-n] = False
+        mask[:-n, -n:] = False
+    assert_close(o, sdpa_ref(qf, kf, vf, mask), f"attention mode{mode} S={S}", atol=4e-3)
+
+
+def test_errors_are_loud(dev):
+    from reflectionflow_amd import ops
+    with pytest.raises(ops.RFError):
+        ops.linear(torch.zeros(4, 64, dtype=BF), torch.zeros(8, 64, dtype=BF))       # CPU tensors
+    with pytest.raises(ops.RFError):
+        ops.linear(torch.zeros(4, 72, dtype=BF, device=dev), torch.zeros(8, 72, dtype=BF, device=dev))  # K % 64
+    with pytest.raises(ops.RFError):
+        ops.linear(torch.zeros(4, 64, device=dev), torch.zeros(8, 64, device=dev))    # fp32
