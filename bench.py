@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its cfg2 workload.
+
+    metric : 1024^2 latents/sec (50-step FLUX denoise) per node
+    step   : ONE complete 50-step denoise of one 1024x1024 candidate (output_type="latent") through
+             the reference-shaped `generate()` API: modulation tables for the 50 timesteps, then
+             50 x (57-block transformer forward + Euler step) on the GPU.  Nothing is skipped or cached
+             across steps/candidates inside the timed region.
+    inputs : synthetic -- random-init FLUX.1-dev-shaped weights (N(0,0.02^2), seed 0), random
+             T5/CLIP embeddings, seeded initial noise via the tts/utils.py protocol.  Inputs are resident in
+             HBM when the timed region starts.
+    N GPUs : one process per GPU (torchrun), candidates sharded rank-round-robin, weights replicated;
+             the only collective is the round-boundary all-gather of verifier scores (RCCL).
+
+Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+    roofline     -- the dominant kernel (the 256x256 bf16 MFMA GEMM): algorithmic FLOPs of all its
+                    launches in one forward / their summed hipEvent-timed durations, vs 2.5 PFLOP/s.
+    cpu_baseline -- the CPU oracle (a port of the reference path) timed on the host cores over a
+                    bounded sample of the same workload, extrapolated and labelled as such.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md:42)
+
+
+def flops_per_forward(S_txt, S_img, D=3072, mlp=12288, nd=19, ns=38, in_ch=64, joint=4096):
+    """2MNK per GEMM, 4 S^2 D per attention block; element-wise excluded."""
+    S = S_txt + S_img
+    gemm = nd * S * (2 * D * 3 * D + 2 * D * D + 2 * 2 * D * mlp) + ns * S * (2 * D * (3 * D + mlp) + 2 * (D + mlp) * D)
+    attn = (nd + ns) * 4 * S * S * D
+    emb = 2 * S_img * in_ch * D * 2 + 2 * S_txt * joint * D
+    return gemm + attn + emb, gemm, attn
+
+
+def build_model(dev, cfg=None, seed=0):
+    """Random-init FLUX.1-dev-shaped transformer created directly in HBM (no checkpoint offline)."""
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.flux.pipeline import FluxPipeline
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            tr = M.FluxTransformer2DModel(**(cfg or {}))
+    finally:
+        torch.set_default_dtype(old)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in tr.named_parameters():
+            if name.endswith("weight") and p.ndim == 1:
+                p.copy_(1.0 + 0.02 * torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32))
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32))
+    return FluxPipeline(tr)
+
+
+def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
+    """Time every distinct launch shape of the dominant kernel (256^2 MFMA GEMM) with hipEvents."""
+    from reflectionflow_amd import ops
+    from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, Group, Seg
+    bf = torch.bfloat16
+    S = S_txt + S_img
+    r = lambda *s, sc=1.0: (torch.randn(*s, device=dev) * sc).to(bf)  # noqa: E731
+    xn, att, hid = r(S, D), r(S, D), r(S, mlp)
+    x = r(S, D)
+    q, k, vt, s_pad = ops.alloc_attn_operands(heads, S, dev)
+    gate, b3, b1, bm, bf_ = r(D), r(3 * D), r(D), r(mlp), r(3 * D + mlp)
+    Wq, Wq2 = r(3 * D, D, sc=.02), r(3 * D, D, sc=.02)
+    Wo, Wo2 = r(D, D, sc=.02), r(D, D, sc=.02)
+    W1, W1b = r(mlp, D, sc=.02), r(mlp, D, sc=.02)
+    W2, W2b = r(D, mlp, sc=.02), r(D, mlp, sc=.02)
+    Wf, Ws = r(3 * D + mlp, D, sc=.02), r(D, D + mlp, sc=.02)
+    t, i = slice(0, S_txt), slice(S_txt, S)
+    shapes = []
+
+    def two(A, Wt, Wi, **kw):
+        return [Group([Seg(A[t], Wt)], **{k_: (v[0] if isinstance(v, tuple) else v) for k_, v in kw.items()}),
+                Group([Seg(A[i], Wi)], **{k_: (v[1] if isinstance(v, tuple) else v) for k_, v in kw.items()})]
+
+    shapes.append(("dbl_qkv", nd, 2.0 * S * 3 * D * D,
+                   lambda: ops.time_gemm(two(xn, Wq2, Wq, bias=b3, tok_offset=(0, S_txt)), 3 * D, RF_EPI_QKV,
+                                         q=q, k=k, vt=vt, heads=heads, s_pad=s_pad)))
+    shapes.append(("dbl_out", nd, 2.0 * S * D * D,
+                   lambda: ops.time_gemm(two(att, Wo2, Wo, bias=b1, gate=gate, out=(x[t], x[i]), residual=(x[t], x[i])),
+                                         D, RF_EPI_GATE_RES)))
+    shapes.append(("dbl_ff1", nd, 2.0 * S * mlp * D,
+                   lambda: ops.time_gemm(two(xn, W1b, W1, bias=bm, out=(hid[t], hid[i])), mlp, RF_EPI_GELU)))
+    shapes.append(("dbl_ff2", nd, 2.0 * S * D * mlp,
+                   lambda: ops.time_gemm(two(hid, W2b, W2, bias=b1, gate=gate, out=(x[t], x[i]), residual=(x[t], x[i])),
+                                         D, RF_EPI_GATE_RES)))
+    shapes.append(("sgl_in", ns, 2.0 * S * (3 * D + mlp) * D,
+                   lambda: ops.time_gemm([Group([Seg(xn, Wf)], bias=bf_, out=hid, tok_offset=0)], 3 * D + mlp,
+                                         RF_EPI_QKV_GELU, n_split=3 * D, q=q, k=k, vt=vt, heads=heads, s_pad=s_pad)))
+    shapes.append(("sgl_out", ns, 2.0 * S * D * (D + mlp),
+                   lambda: ops.time_gemm([Group([Seg(att, Ws[:, :D]), Seg(hid, Ws[:, D:])], bias=b1, gate=gate, out=x,
+                                                residual=x)], D, RF_EPI_GATE_RES)))
+    tot_f = tot_t = 0.0
+    n_launch = 0
+    per = {}
+    for name, count, fl, fn in shapes:
+        sec = fn()
+        per[name] = {"launches_per_forward": count, "us": round(sec * 1e6, 1), "tflops": round(fl / sec / 1e12, 1)}
+        tot_f += count * fl
+        tot_t += count * sec
+        n_launch += count
+    ach = tot_f / tot_t / 1e12
+    return {"bound": "mfma", "kernel": "rf::gemm_bf16_kernel<256,256,2,4>", "achieved": round(ach, 1),
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_forward": n_launch, "avg_launch_us": round(tot_t / n_launch * 1e6, 1),
+            "flops_per_launch_avg": tot_f / n_launch, "shapes": per}
+
+
+def cpu_baseline(S_txt, S_img, T, D=3072, heads=24, nd=19, ns=38):
+    """The oracle (CPU restatement of the reference path), fp32, on the host cores: time one
+    DoubleStream + one SingleStream block at full width and sequence length and extrapolate to the
+    57-block x T-step latent.  A reported baseline, not an optimisation target."""
+    from oracle import flux_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        dbl = O.FluxTransformerBlock(D, heads, 128).float().eval()
+        sgl = O.FluxSingleTransformerBlock(D, heads, 128).float().eval()
+        g = torch.Generator().manual_seed(0)
+        x, e = torch.randn(1, S_img, D, generator=g), torch.randn(1, S_txt, D, generator=g)
+        temb = torch.randn(1, D, generator=g)
+        side = int(round(S_img ** 0.5))
+        ids = torch.cat([torch.zeros(S_txt, 3), O.prepare_latent_image_ids(side, side)])
+        rope = O.FluxPosEmbed(10000, (16, 56, 56))(ids)
+        t0 = time.time()
+        O.block_forward(dbl, x, e, None, temb, None, image_rotary_emb=rope)
+        td = time.time() - t0
+        t0 = time.time()
+        O.single_block_forward(sgl, torch.cat([e, x], 1), temb, image_rotary_emb=rope)
+        ts = time.time() - t0
+    per_latent = T * (nd * td + ns * ts)
+    return {"value": 1.0 / per_latent, "unit": "latents/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32, 1 DoubleStream ({td:.2f}s) + 1 SingleStream ({ts:.2f}s) block at S={S_txt + S_img}, "
+                      f"D={D}; extrapolated x({nd},{ns}) blocks x {T} steps = {per_latent:.0f} s/latent",
+            "extrapolated": True}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="timed latents (each a full 50-step denoise) per GPU")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="debug: 2+2-block model (NOT a valid bench result)")
+    args = ap.parse_args()
+
+    from reflectionflow_amd import _lib
+    from reflectionflow_amd.tts import search
+    from reflectionflow_amd.tts.utils import get_noises
+    from reflectionflow_amd.flux.generate import generate
+
+    _lib.load()
+    shard = search.init_distributed()
+    if shard.world_size != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world_size}: launch with torch.distributed.run")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg = dict(num_layers=2, num_single_layers=2) if args.small else {}
+    pipe = build_model(dev, cfg, seed=0)
+    tr = pipe.transformer
+    D, heads = tr.inner_dim, tr.config.num_attention_heads
+    nd, ns = len(tr.transformer_blocks), len(tr.single_transformer_blocks)
+    S_txt, S_img, T = 512, (args.res // 16) ** 2, args.denoise_steps
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(1, S_txt, tr.config.joint_attention_dim, generator=g).to(dev).to(torch.bfloat16)
+    pooled = torch.randn(1, tr.config.pooled_projection_dim, generator=g).to(dev).to(torch.bfloat16)
+    n_total = (args.warmup + args.steps)
+    seeds = [1000 * shard.rank + i for i in range(n_total)]
+    noises = get_noises(2 ** 31 - 1, n_total, args.res, args.res, device=dev, dtype=torch.bfloat16, seeds=seeds)
+
+    def one_latent(seed):
+        return generate(pipe, model_config={}, height=args.res, width=args.res, num_inference_steps=T,
+                        guidance_scale=3.5, latents=noises[seed], prompt_embeds=pe, pooled_prompt_embeds=pooled,
+                        output_type="latent").images
+
+    def barrier():
+        if shard.world_size > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        out = one_latent(seeds[i])
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    local_scores = {}
+    outs = []
+    for i in range(args.steps):
+        outs.append(one_latent(seeds[args.warmup + i]))
+    # round boundary: score this rank's candidates, exchange {score,label} (RCCL all-gather), top-k everywhere
+    n_round = args.steps * shard.world_size
+    for j, o in enumerate(outs):
+        local_scores[j * shard.world_size + shard.rank] = search.stub_verifier(o, seeds[args.warmup + j])
+    scores = search.allgather_scores(shard, n_round, local_scores)
+    best = search.select_topk(scores, 1)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if shard.world_size > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert all(torch.isfinite(o.float()).all() for o in outs), "non-finite latents"
+
+    if shard.rank == 0:
+        total_latents = args.steps * shard.world_size
+        value = total_latents / dt
+        f_fwd, f_gemm, f_attn = flops_per_forward(S_txt, S_img, D, tr.transformer_blocks[0].ff.net[0].proj.out_features
+                                                  if nd else 4 * D, nd, ns, tr.config.in_channels,
+                                                  tr.config.joint_attention_dim)
+        step_tflops = f_fwd * T * total_latents / dt / 1e12
+        res = {
+            "metric": "1024^2 latents/sec (50-step FLUX denoise) per node", "value": round(value, 5), "unit": "latents/s",
+            "n_gpus": shard.world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"FLUX.1-dev {args.res}x{args.res}, {T} Euler steps, 1 candidate per GPU per step "
+                                   f"(BASELINE cfg2{'; candidates sharded, cfg3-style' if shard.world_size > 1 else ''})",
+                       "tokens": S_txt + S_img, "blocks": f"{nd} double + {ns} single", "guidance": 3.5,
+                       "parallelism": f"candidate-parallel x{shard.world_size}, weights replicated"},
+            "whole_path": {"tflop_per_forward": round(f_fwd / 1e12, 2), "achieved_tflops_per_gpu": round(step_tflops / shard.world_size, 1),
+                           "frac_of_bf16_mfma_peak": round(step_tflops / shard.world_size / PEAK_BF16_TFLOPS, 4)},
+            "selected_candidate": best[0],
+        }
+        if args.small:
+            res["INVALID"] = "debug model (--small), not the BASELINE workload"
+        if shard.world_size == 1:
+            if not args.no_roofline:
+                res["roofline"] = gemm_roofline(dev, S_txt, S_img, D, 4 * D, heads, nd, ns)
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(S_txt, S_img, T, D, heads, nd, ns)
+        print(json.dumps(res), flush=True)
+    if shard.world_size > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -290,7 +290,11 @@ class CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
 
 
 class _Config(dict):
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 FLUX_DEV_CONFIG = dict(

@@ -115,6 +115,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RFError(f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; "
                       "run `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch-ROCm bundles its own libamdhip64 (same soname): import torch FIRST so that librf_flux
+    # binds to the HIP runtime torch's streams and allocations live in (two runtimes in one process
+    # cannot see each other's devices).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in {**_SIGS, **_EXTRA_SIGS}.items():
         try:

@@ -1,0 +1,323 @@
+"""FluxEngine: packs a FluxTransformer2DModel's weights into the C-ABI structs once, owns the
+device workspace, and runs whole forwards / whole T-step denoises through librf_flux.
+
+MI355X-first choices made here:
+  * weights of sibling projections are concatenated ONCE (to_q|to_k|to_v, and for single blocks
+    |proj_mlp) so each block runs 4 (double) / 2 (single) large grouped GEMMs;
+  * all 57 blocks' AdaLN modulation vectors depend only on (t, guidance, pooled text), not on the
+    latents, and the T timesteps are known before the loop starts: the modulation table for ALL
+    steps is produced up front by ~58 skinny GEMM launches (each streams one AdaLN weight once for
+    all T rows) instead of 2.3 k GEMV launches x 6.5 GB of weight traffic per step;
+  * LoRA (FLUX-Corrector) is never merged: it rides as an extra K-segment on the token groups it
+    is active for (condition rows; image rows too iff model_config["latent_lora"]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .flux import modules as M
+
+
+def _pad_lora(A: torch.Tensor, B: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    r = A.shape[0]
+    r_pad = (r + 63) // 64 * 64
+    if r_pad > 256:
+        raise ops.RFError(f"stacked LoRA rank {r} exceeds the 256-column low-rank buffer")
+    Ap = torch.zeros(r_pad, A.shape[1], dtype=A.dtype, device=A.device)
+    Ap[:r] = A
+    Bp = torch.zeros(B.shape[0], r_pad, dtype=B.dtype, device=B.device)
+    Bp[:, :r] = B
+    return Ap.contiguous(), Bp.contiguous(), r_pad
+
+
+def _base(lin):
+    return lin.base_layer if isinstance(lin, M.LoraLinear) else lin
+
+
+def _fused_lora(linears) -> Optional[Tuple[torch.Tensor, torch.Tensor, int]]:
+    """Stack the LoRA factors of sibling linears that were concatenated along N:
+    A = rows stacked, B = block diagonal (scaling folded in)."""
+    if not any(isinstance(l, M.LoraLinear) for l in linears):
+        return None
+    As, blocks = [], []
+    for l in linears:
+        if isinstance(l, M.LoraLinear):
+            A, B = l.lora_factors()
+        else:
+            A = torch.zeros(0, l.in_features, dtype=l.weight.dtype, device=l.weight.device)
+            B = torch.zeros(l.out_features, 0, dtype=l.weight.dtype, device=l.weight.device)
+        As.append(A)
+        blocks.append(B)
+    A = torch.cat(As, 0)
+    B = torch.block_diag(*[b.float() for b in blocks]).to(A.dtype)
+    return _pad_lora(A, B)
+
+
+class _Packed:
+    """A C weights struct plus the tensors its pointers refer to (kept alive together)."""
+
+    def __init__(self, struct):
+        self.struct = struct
+        self.keep: List[torch.Tensor] = []
+
+    def k(self, t: torch.Tensor) -> int:
+        t = t.detach().contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def lora(self, seg: L.rf_lora_seg, linears):
+        f = _fused_lora(linears)
+        if f is not None:
+            A, B, r_pad = f
+            seg.A, seg.B, seg.r_pad = self.k(A), self.k(B), r_pad
+
+
+def _require_device_bf16(p: torch.Tensor, what: str):
+    if not p.is_cuda or p.dtype != torch.bfloat16:
+        raise ops.RFError(f"{what}: weights must be bf16 on a HIP device (got {p.dtype} on {p.device}); "
+                          "the HIP path has no CPU fallback")
+
+
+def pack_double_block(b, refresh: bool = False) -> _Packed:
+    """rf_double_block_weights for a FluxTransformerBlock (cached on the module)."""
+    pk = getattr(b, "_rf_packed", None)
+    if pk is not None and not refresh:
+        return pk
+    a = b.attn
+    _require_device_bf16(_base(a.to_q).weight, "pack_double_block")
+    pk = _Packed(L.rf_double_block_weights())
+    w, cat = pk.struct, torch.cat
+    qkv = [a.to_q, a.to_k, a.to_v]
+    w.w_qkv = pk.k(cat([_base(l).weight for l in qkv], 0))
+    w.b_qkv = pk.k(cat([_base(l).bias for l in qkv], 0))
+    add = [a.add_q_proj, a.add_k_proj, a.add_v_proj]
+    w.w_add_qkv = pk.k(cat([l.weight for l in add], 0))
+    w.b_add_qkv = pk.k(cat([l.bias for l in add], 0))
+    w.norm_q, w.norm_k = pk.k(a.norm_q.weight), pk.k(a.norm_k.weight)
+    w.norm_added_q, w.norm_added_k = pk.k(a.norm_added_q.weight), pk.k(a.norm_added_k.weight)
+    w.w_out, w.b_out = pk.k(_base(a.to_out[0]).weight), pk.k(_base(a.to_out[0]).bias)
+    w.w_add_out, w.b_add_out = pk.k(a.to_add_out.weight), pk.k(a.to_add_out.bias)
+    w.w_ff1, w.b_ff1 = pk.k(b.ff.net[0].proj.weight), pk.k(b.ff.net[0].proj.bias)
+    w.w_ff2, w.b_ff2 = pk.k(_base(b.ff.net[2]).weight), pk.k(_base(b.ff.net[2]).bias)
+    w.w_ffc1, w.b_ffc1 = pk.k(b.ff_context.net[0].proj.weight), pk.k(b.ff_context.net[0].proj.bias)
+    w.w_ffc2, w.b_ffc2 = pk.k(b.ff_context.net[2].weight), pk.k(b.ff_context.net[2].bias)
+    pk.lora(w.lora_qkv, qkv)
+    pk.lora(w.lora_out, [a.to_out[0]])
+    pk.lora(w.lora_ff2, [b.ff.net[2]])
+    pk.D, pk.heads, pk.mlp = a.to_q.in_features, a.heads, b.ff.net[0].proj.out_features
+    object.__setattr__(b, "_rf_packed", pk)
+    return pk
+
+
+def pack_single_block(b, refresh: bool = False) -> _Packed:
+    """rf_single_block_weights for a FluxSingleTransformerBlock (cached on the module)."""
+    pk = getattr(b, "_rf_packed", None)
+    if pk is not None and not refresh:
+        return pk
+    a = b.attn
+    _require_device_bf16(_base(a.to_q).weight, "pack_single_block")
+    pk = _Packed(L.rf_single_block_weights())
+    w, cat = pk.struct, torch.cat
+    fused = [a.to_q, a.to_k, a.to_v, b.proj_mlp]
+    w.w_qkv_mlp = pk.k(cat([_base(l).weight for l in fused], 0))
+    w.b_qkv_mlp = pk.k(cat([_base(l).bias for l in fused], 0))
+    w.norm_q, w.norm_k = pk.k(a.norm_q.weight), pk.k(a.norm_k.weight)
+    w.w_out, w.b_out = pk.k(_base(b.proj_out).weight), pk.k(_base(b.proj_out).bias)
+    pk.lora(w.lora_qkv_mlp, fused)
+    pk.lora(w.lora_out, [b.proj_out])
+    pk.D, pk.heads, pk.mlp = a.to_q.in_features, a.heads, b.proj_mlp.out_features
+    object.__setattr__(b, "_rf_packed", pk)
+    return pk
+
+
+def make_dims(D: int, heads: int, mlp: int, S_txt: int, S_img: int, S_cond: int = 0,
+              model_config: Optional[dict] = None, c_factor: Optional[float] = None) -> L.rf_flux_dims:
+    mc = model_config or {}
+    d = L.rf_flux_dims()
+    d.D, d.heads, d.mlp = D, heads, mlp
+    d.S_txt, d.S_img, d.S_cond = S_txt, S_img, S_cond
+    d.attn_mode, d.cross_bias = 0, 0.0
+    if S_cond > 0:
+        if c_factor is not None:                    # block.py:115-122 (overrides the boolean mask)
+            d.attn_mode, d.cross_bias = 1, math.log(c_factor)
+        elif not mc.get("union_cond_attn", True):   # block.py:106-114
+            d.attn_mode = 2
+    d.lora_on_main = 1 if mc.get("latent_lora", False) else 0
+    d.add_cond_attn = 1 if mc.get("add_cond_attn", False) else 0
+    return d
+
+
+_WS_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
+    """Caller-owned scratch for one (D, heads, mlp, S_txt, S_img, S_cond) geometry, allocated once."""
+    key = (str(device), d.D, d.heads, d.mlp, d.S_txt, d.S_img, d.S_cond)
+    buf = _WS_CACHE.get(key)
+    if buf is None:
+        n = int(L.load().rf_workspace_bytes(C.byref(d)))
+        # zero-filled: padded key rows of V^T must be finite (they are multiplied by p = 0)
+        buf = torch.zeros(n, dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = buf
+    ws = L.rf_workspace()
+    ws.base, ws.bytes = buf.data_ptr(), buf.numel()
+    return ws
+
+
+class FluxEngine:
+    def __init__(self, transformer: M.FluxTransformer2DModel):
+        self.lib = L.load()
+        self.tr = transformer
+        p = _base(transformer.x_embedder).weight
+        _require_device_bf16(p, "FluxEngine")
+        self.device = p.device
+        cfg = transformer.config
+        self.D = cfg.num_attention_heads * cfg.attention_head_dim
+        self.heads = cfg.num_attention_heads
+        self.mlp = transformer.transformer_blocks[0].ff.net[0].proj.out_features if len(transformer.transformer_blocks) \
+            else transformer.single_transformer_blocks[0].mlp_hidden_dim
+        self.in_ch = cfg.in_channels
+        self._rope_cache: Dict[tuple, tuple] = {}
+        self._pack()
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self):
+        tr = self.tr
+        nd, ns = len(tr.transformer_blocks), len(tr.single_transformer_blocks)
+        self._dbl = (L.rf_double_block_weights * max(nd, 1))()
+        self._sgl = (L.rf_single_block_weights * max(ns, 1))()
+        self._packs = []
+        for i, b in enumerate(tr.transformer_blocks):
+            pk = pack_double_block(b, refresh=True)
+            self._packs.append(pk)
+            self._dbl[i] = pk.struct
+        for i, b in enumerate(tr.single_transformer_blocks):
+            pk = pack_single_block(b, refresh=True)
+            self._packs.append(pk)
+            self._sgl[i] = pk.struct
+        top = _Packed(L.rf_flux_model())
+        self._packs.append(top)
+        m = top.struct
+        m.num_double, m.num_single = nd, ns
+        m.dbl = C.cast(self._dbl, C.POINTER(L.rf_double_block_weights))
+        m.sgl = C.cast(self._sgl, C.POINTER(L.rf_single_block_weights))
+        m.w_x_embed, m.b_x_embed = top.k(_base(tr.x_embedder).weight), top.k(_base(tr.x_embedder).bias)
+        top.lora(m.lora_x_embed, [tr.x_embedder])
+        m.w_ctx_embed, m.b_ctx_embed = top.k(tr.context_embedder.weight), top.k(tr.context_embedder.bias)
+        m.w_proj_out, m.b_proj_out = top.k(tr.proj_out.weight), top.k(tr.proj_out.bias)
+        m.in_ch, m.joint_dim = self.in_ch, tr.context_embedder.in_features
+        self.model = m
+        self.mod_cols = int(self.lib.rf_mod_table_cols(C.byref(m), self.D))
+        # AdaLN linears in table order: per double block [norm1 (img) | norm1_context (txt)], singles, norm_out
+        self._mod_linears = []
+        for b in tr.transformer_blocks:
+            self._mod_linears += [b.norm1.linear, b.norm1_context.linear]
+        for b in tr.single_transformer_blocks:
+            self._mod_linears.append(b.norm.linear)
+        self._mod_linears.append(tr.norm_out.linear)
+        self._mod_lora = [(_pad_lora(*l.lora_factors()) if isinstance(l, M.LoraLinear) else None)
+                          for l in self._mod_linears]
+
+    # ------------------------------------------------------------------ small helpers
+    def dims(self, S_txt: int, S_img: int, S_cond: int = 0, model_config: Optional[dict] = None,
+             c_factor: Optional[float] = None) -> L.rf_flux_dims:
+        return make_dims(self.D, self.heads, self.mlp, S_txt, S_img, S_cond, model_config, c_factor)
+
+    def workspace(self, d: L.rf_flux_dims) -> L.rf_workspace:
+        return get_workspace(self.device, d)
+
+    def rope_tables(self, txt_ids, img_ids, cond_ids=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """FluxPosEmbed over [txt | img | cond] ids (transformer.py:129-134) -> fp32 [S,128] x2."""
+        ids = [txt_ids, img_ids] + ([cond_ids] if cond_ids is not None else [])
+        ids = torch.cat([i.to(self.device).float() for i in ids], 0)
+        key = (ids.shape[0], float(ids.sum()), float((ids * ids).sum()), float(ids[-1].sum()))
+        hit = self._rope_cache.get(key)
+        if hit is not None and torch.equal(hit[2], ids):
+            return hit[0], hit[1]
+        cos, sin = self.tr.pos_embed(ids)
+        cos, sin = cos.contiguous(), sin.contiguous()
+        self._rope_cache[key] = (cos, sin, ids)
+        return cos, sin
+
+    def temb(self, timestep, guidance, pooled) -> torch.Tensor:
+        """time_text_embed (stays in PyTorch-ROCm).  timestep/guidance arrive already x1000 in model dtype."""
+        te = self.tr.time_text_embed
+        return te(timestep, guidance, pooled) if guidance is not None else te(timestep, pooled)
+
+    def mod_table(self, temb: torch.Tensor, lora: bool = False) -> torch.Tensor:
+        """[M, D] conditioning rows -> [M, mod_cols] modulation table (all AdaLN linears)."""
+        if temb.dim() != 2 or temb.shape[1] != self.D:
+            raise ops.RFError("mod_table: temb must be [M, D]")
+        s = ops.silu(temb.to(torch.bfloat16).contiguous())
+        table = torch.empty(s.shape[0], self.mod_cols, dtype=torch.bfloat16, device=self.device)
+        col = 0
+        for lin, lo in zip(self._mod_linears, self._mod_lora):
+            base = _base(lin)
+            n = base.out_features
+            extra = []
+            if lora and lo is not None:
+                A, B, _ = lo
+                extra = [ops.Seg(ops.linear(s, A), B)]
+            ops.linear(s, base.weight, base.bias, extra=extra, out=table[:, col:col + n])
+            col += n
+        assert col == self.mod_cols
+        return table
+
+    # ------------------------------------------------------------------ forward / denoise
+    def forward(self, latents, ctx, mod_main, cos, sin, cond_latents=None, mod_cond=None, model_config=None,
+                c_factor=None, out=None) -> torch.Tensor:
+        """One sample: latents [S_img, in_ch], ctx [S_txt, joint], mod rows [mod_cols] -> velocity [S_img, in_ch]."""
+        Sc = 0 if cond_latents is None else cond_latents.shape[0]
+        d = self.dims(ctx.shape[0], latents.shape[0], Sc, model_config, c_factor)
+        ws = self.workspace(d)
+        if out is None:
+            out = torch.empty_like(latents)
+        for t in (latents, ctx, mod_main, out):
+            if not (t.is_contiguous() and t.dtype == torch.bfloat16 and t.is_cuda):
+                raise ops.RFError("FluxEngine.forward: inputs must be contiguous bf16 device tensors")
+        if cos.shape[0] != d.S_txt + d.S_img + d.S_cond:
+            raise ops.RFError("FluxEngine.forward: rope tables do not cover [txt|img|cond]")
+        L.check(self.lib.rf_flux_forward(
+            C.byref(d), C.byref(self.model), latents.data_ptr(), ops.ptr(cond_latents), ctx.data_ptr(),
+            mod_main.data_ptr(), ops.ptr(mod_cond), cos.data_ptr(), sin.data_ptr(), out.data_ptr(),
+            C.byref(ws), ops.stream_ptr()), "rf_flux_forward")
+        return out
+
+    def denoise(self, latents, ctx, mod_steps, dts, cos, sin, cond_latents=None, mod_cond=None, model_config=None,
+                c_factor=None) -> torch.Tensor:
+        """T-step loop in ONE C call, latents [S_img, in_ch] updated in place.
+        mod_steps [T, mod_cols] (row i = modulation table of timestep i), dts = sigma_{i+1}-sigma_i."""
+        Sc = 0 if cond_latents is None else cond_latents.shape[0]
+        d = self.dims(ctx.shape[0], latents.shape[0], Sc, model_config, c_factor)
+        ws = self.workspace(d)
+        T = len(dts)
+        if mod_steps.shape != (T, self.mod_cols) or not mod_steps.is_contiguous():
+            raise ops.RFError("FluxEngine.denoise: mod_steps must be contiguous [T, mod_cols]")
+        vel = torch.empty_like(latents)
+        arr = (C.c_float * T)(*[float(x) for x in dts])
+        L.check(self.lib.rf_flux_denoise(
+            C.byref(d), C.byref(self.model), latents.data_ptr(), ops.ptr(cond_latents), ctx.data_ptr(),
+            mod_steps.data_ptr(), mod_steps.stride(0), ops.ptr(mod_cond), cos.data_ptr(), sin.data_ptr(),
+            arr, T, vel.data_ptr(), C.byref(ws), ops.stream_ptr()), "rf_flux_denoise")
+        return latents
+
+
+def engine_for(transformer) -> FluxEngine:
+    """The engine is cached on the transformer; call `invalidate(transformer)` after changing weights
+    or loading LoRA."""
+    eng = getattr(transformer, "_rf_engine", None)
+    if eng is None:
+        eng = FluxEngine(transformer)
+        object.__setattr__(transformer, "_rf_engine", eng)
+    return eng
+
+
+def invalidate(transformer):
+    if hasattr(transformer, "_rf_engine"):
+        object.__delattr__(transformer, "_rf_engine")

@@ -15,7 +15,7 @@ import torch
 from . import _lib as L
 from ._lib import (RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, RF_EPI_STORE, RFError)
 
-__all__ = ["linear", "gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
+__all__ = ["linear", "gemm", "build_gemm_desc", "time_gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
            "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError"]
 
 
@@ -61,13 +61,11 @@ class Group:
             list(segs), bias, out, residual, gate, tok_offset)
 
 
-def gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
-         q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0):
-    lib = L.load()
+def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
+                    q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0) -> "L.rf_gemm_desc":
     d = L.rf_gemm_desc()
     d.N, d.epilogue, d.num_groups, d.n_split = N, epilogue, len(groups), n_split
     d.q, d.k, d.vt, d.heads, d.s_pad = ptr(q), ptr(k), ptr(vt), heads, s_pad
-    keep = []
     for gi, g in enumerate(groups):
         G = d.g[gi]
         G.M = g.segs[0].A.shape[0]
@@ -89,8 +87,20 @@ def gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split:
             G.residual, G.ldr = r.data_ptr(), r.stride(0)
         if g.gate is not None:
             G.gate = _chk(g.gate, "gate").data_ptr()
-        keep.append(g)
-    L.check(lib.rf_gemm_bf16(C.byref(d), stream_ptr()), "rf_gemm_bf16")
+    return d
+
+
+def gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, **kw):
+    d = build_gemm_desc(groups, N, epilogue, **kw)
+    L.check(L.load().rf_gemm_bf16(C.byref(d), stream_ptr()), "rf_gemm_bf16")
+
+
+def time_gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, iters: int = 10, **kw) -> float:
+    """Average duration (seconds) of one launch, measured with hipEvents on the launch stream."""
+    d = build_gemm_desc(groups, N, epilogue, **kw)
+    us = C.c_float(0.0)
+    L.check(L.load().rf_time_gemm(C.byref(d), iters, C.byref(us), stream_ptr()), "rf_time_gemm")
+    return us.value * 1e-6
 
 
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = RF_EPI_STORE,
