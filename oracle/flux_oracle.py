@@ -623,8 +623,14 @@ def single_block_forward(self, hidden_states, temb, image_rotary_emb=None, condi
 def tranformer_forward(transformer, condition_latents, condition_ids, condition_type_ids=None,
                        model_config=None, c_t=0, *, hidden_states, encoder_hidden_states,
                        pooled_projections, timestep, img_ids, txt_ids, guidance=None,
-                       joint_attention_kwargs=None, return_dict=False, **_):
-    """transformer.py:47-252 (inference branch; ControlNet hooks unused by the tts scripts)."""
+                       joint_attention_kwargs=None, return_dict=False, conditioning_dtype=None, **_):
+    """transformer.py:47-252 (inference branch; ControlNet hooks unused by the tts scripts).
+
+    `conditioning_dtype` (NOT in the reference; default None = exact restatement): when the model
+    runs in fp32 but must be compared with a bf16 pipeline, the scalars t*1000 and guidance*1000 are
+    formed in that dtype first, exactly as transformer.py:95-98 forms them when hidden_states is
+    bf16 (3.5*1000 -> 3504).  The sinusoidal embedding is very sensitive to that rounding, and the
+    north star says to inherit it, so a fair fp32 yardstick has to share it."""
     self = transformer
     model_config = model_config or {}
     use_condition = condition_latents is not None
@@ -632,8 +638,9 @@ def tranformer_forward(transformer, condition_latents, condition_ids, condition_
         hidden_states = self.x_embedder(hidden_states)
     condition_latents = self.x_embedder(condition_latents) if use_condition else None
 
-    timestep = timestep.to(hidden_states.dtype) * 1000                      # :95-100
-    guidance = guidance.to(hidden_states.dtype) * 1000 if guidance is not None else None
+    cdt = conditioning_dtype or hidden_states.dtype
+    timestep = (timestep.to(cdt) * 1000).to(hidden_states.dtype)            # :95-100
+    guidance = (guidance.to(cdt) * 1000).to(hidden_states.dtype) if guidance is not None else None
     if guidance is None:                                                    # :102-114
         temb = self.time_text_embed(timestep, pooled_projections)
         cond_temb = self.time_text_embed(torch.ones_like(timestep) * c_t * 1000, pooled_projections)
@@ -772,8 +779,9 @@ def condition_ids_for(cond_size: int, position_delta=None, dtype=torch.float32):
 @torch.no_grad()
 def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_inference_steps,
             guidance_scale=3.5, condition_latents=None, condition_ids=None, model_config=None,
-            image_hw=None, scheduler=None, callback=None):
-    """generate.py:193-299 with output_type='latent' (the T-step hot loop + Euler step)."""
+            image_hw=None, scheduler=None, callback=None, conditioning_dtype=None):
+    """generate.py:193-299 with output_type='latent' (the T-step hot loop + Euler step).
+    `conditioning_dtype`: see tranformer_forward (default None = exact restatement)."""
     scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
     B, S_i, _ = latents.shape
     dtype, device = prompt_embeds.dtype, latents.device
@@ -788,7 +796,7 @@ def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_infer
     timesteps, _ = retrieve_timesteps(scheduler, num_inference_steps, device, None, sigmas, mu=mu)
     use_condition = condition_latents is not None
     for i, t in enumerate(timesteps):                                        # :217
-        timestep = t.expand(latents.shape[0]).to(latents.dtype)              # :222
+        timestep = t.expand(latents.shape[0]).to(conditioning_dtype or latents.dtype)   # :222
         if transformer.config.guidance_embeds:                               # :225-229
             guidance = torch.tensor([guidance_scale], device=device).expand(latents.shape[0])
         else:
@@ -800,7 +808,8 @@ def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_infer
             condition_type_ids=None, hidden_states=latents, timestep=timestep / 1000,
             guidance=guidance, pooled_projections=pooled_prompt_embeds,
             encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
-            joint_attention_kwargs=None, return_dict=False)[0]               # :230-248
+            joint_attention_kwargs=None, return_dict=False,
+            conditioning_dtype=conditioning_dtype)[0]                        # :230-248
         latents = scheduler.step(noise_pred, t, latents, return_dict=False)[0]   # :276
         if callback is not None:
             callback(i, t, latents)

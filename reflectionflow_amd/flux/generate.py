@@ -149,7 +149,8 @@ def generate(pipeline, conditions: List[Condition] = None, config_path: str = No
                     noise_pred = unc_pred + image_guidance_scale * (noise_pred - unc_pred)
                 latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
                 if callback_on_step_end is not None:
-                    callback_kwargs = {k: locals()[k] for k in callback_on_step_end_tensor_inputs}
+                    avail = {"latents": latents, "prompt_embeds": prompt_embeds, "noise_pred": noise_pred}
+                    callback_kwargs = {k: avail[k] for k in callback_on_step_end_tensor_inputs}
                     callback_outputs = callback_on_step_end(self, i, t, callback_kwargs) or {}
                     latents = callback_outputs.pop("latents", latents)
                     prompt_embeds = callback_outputs.pop("prompt_embeds", prompt_embeds)

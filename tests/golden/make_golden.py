@@ -239,8 +239,11 @@ def gen_transformer(geom):
     img_ids = O.prepare_latent_image_ids(s["gh"], s["gw"])
     cond_ids = O.prepare_latent_image_ids(s["gc"], s["gc"])
     cond_ids[:, 2] -= s["gc"]
-    t = torch.tensor([0.7])
-    g = torch.tensor([3.5])
+    # (t, g) chosen so that t*1000 and g*1000 are exact in bf16 as well: the reference's bf16 path
+    # quantises them before the sinusoidal embedding (transformer.py:95-98), and this fixture is also
+    # the target of the bf16 GPU parity test
+    t = torch.tensor([0.5])
+    g = torch.tensor([4.0])
     out = dict(lat=lat, cond=cond, pe=pe, pooled=pooled, txt_ids=txt_ids, img_ids=img_ids,
                cond_ids=cond_ids, t=t, g=g)
     for lora in (False, True):

@@ -9,6 +9,13 @@ reference-shaped API (`attn_forward`, `block_forward`, `single_block_forward`, `
 Tolerance (stated): the HIP path computes in bf16 with fp32 accumulation, so it is
 compared with the fp32 result relative to what eager PyTorch bf16 itself achieves on the same
 inputs:  rel-L2(hip, fp32) <= 2.0 x rel-L2(torch_bf16, fp32) + 2e-3, and never above 3e-2.
+
+Conditioning scalars: a bf16 pipeline forms t*1000 and guidance*1000 in bf16 (reference
+transformer.py:95-98; 3.5*1000 -> 3504) and the sinusoidal embedding amplifies that rounding, so
+the north star says to INHERIT it.  The transformer fixture therefore uses (t, g) that are exact in
+bf16, and the multi-step loop is checked against the fp32 oracle run with
+`conditioning_dtype=bfloat16` (everything else fp32); the unmodified fp32 loop fixture is pinned by
+the CPU test.
 """
 import numpy as np
 import pytest
@@ -183,9 +190,12 @@ def test_generate_loop_vs_reference_fixture(dev):
         pipe = to_product(om, dev)
         cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
         key = "cond" if use_c else "nocond"
-        tb = O.denoise(ob, T(z["lat"]).to(BF), T(z["pe"]).to(BF), T(z["pooled"]).to(BF), 4, guidance_scale=3.5,
-                       condition_latents=T(z["cond"]).to(BF) if use_c else None,
-                       condition_ids=T(z["cond_ids"]) if use_c else None, model_config=cfg, image_hw=(s["gh"], s["gw"]))
+        okw = dict(guidance_scale=3.5, condition_ids=T(z["cond_ids"]) if use_c else None, model_config=cfg,
+                   image_hw=(s["gh"], s["gw"]))
+        tb = O.denoise(ob, T(z["lat"]).to(BF), T(z["pe"]).to(BF), T(z["pooled"]).to(BF), 4,
+                       condition_latents=T(z["cond"]).to(BF) if use_c else None, **okw)
+        ref = O.denoise(om, T(z["lat"]).clone(), T(z["pe"]), T(z["pooled"]), 4,
+                        condition_latents=T(z["cond"]) if use_c else None, conditioning_dtype=BF, **okw)
         conds = [Condition("cot", tokens=g(T(z["cond"]), dev), ids=T(z["cond_ids"]).to(dev))] if use_c else None
         common = dict(conditions=conds, model_config=cfg, default_lora=True, height=H, width=W, num_inference_steps=4,
                       guidance_scale=3.5, prompt_embeds=g(T(z["pe"]), dev), pooled_prompt_embeds=g(T(z["pooled"]), dev),
@@ -194,8 +204,8 @@ def test_generate_loop_vs_reference_fixture(dev):
         traj = []
         slow = generate(pipe, latents=g(T(z["lat"]), dev),
                         callback_on_step_end=lambda p, i, t, kw: traj.append(kw["latents"].clone()) or {}, **common).images
-        e = check(fast, T(z[f"final_{key}"]), tb, f"generate fast [{key}]")
-        check(slow, T(z[f"final_{key}"]), tb, f"generate per-step [{key}]")
+        e = check(fast, ref, tb, f"generate fast [{key}]")
+        check(slow, ref, tb, f"generate per-step [{key}]")
         assert len(traj) == 4
         # the single-C-call loop and the per-step loop run the same kernels on the same data
         assert torch.equal(fast, slow), f"fast vs per-step loop differ: {rel_l2(fast, slow):.3e}"
@@ -249,7 +259,7 @@ def test_cfg1_small_model_denoise_matches_oracle(dev):
     pe = torch.randn(B, St, cfgm["joint_attention_dim"], generator=gen)
     pooled = torch.randn(B, cfgm["pooled_projection_dim"], generator=gen)
     lat = torch.cat([O.get_noises([s], 256, 256, dtype=torch.float32)[s] for s in (11, 12)], 0)
-    ref = O.denoise(om, lat.clone(), pe, pooled, 4, image_hw=(16, 16))
+    ref = O.denoise(om, lat.clone(), pe, pooled, 4, image_hw=(16, 16), conditioning_dtype=BF)
     tb = O.denoise(bf16_oracle(om), lat.to(BF), pe.to(BF), pooled.to(BF), 4, image_hw=(16, 16))
     hp = generate(pipe, model_config={}, height=256, width=256, num_inference_steps=4, guidance_scale=3.5,
                   latents=g(lat, dev), prompt_embeds=g(pe, dev), pooled_prompt_embeds=g(pooled, dev),
