@@ -48,6 +48,100 @@ struct GemmParams {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// ---- shared epilogue ---------------------------------------------------------------------------
+// acc[i][j]: 32x32 MFMA accumulators of one wave; fragment (i,j) covers rows wrow0 + i*32 .. and
+// columns wcol0 + j*32 .. of the block tile at (m0, n0).
+// accumulator layout (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGroupDev& G, f32x16 (&acc)[FM][FN],
+                                              const int m0, const int n0, const int wrow0, const int wcol0,
+                                              const int l31, const int h) {
+  const int M = G.M, N = p.N;
+  int epi = p.epi;
+  int ncol_base = 0;  // column offset subtracted for the GELU half of QKV_GELU
+  if (epi == RF_EPI_QKV_GELU) {
+    if (n0 >= p.n_split) {
+      epi = RF_EPI_GELU;
+      ncol_base = p.n_split;
+    } else {
+      epi = RF_EPI_QKV;
+    }
+  }
+  const int DH = p.heads * 128;
+
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wcol0 + j * 32 + l31;
+    const bool nok = n < N;
+    const float bias_v = (G.bias != nullptr && nok) ? bf2f(G.bias[n]) : 0.f;
+    float gate_v = 0.f;
+    if (epi == RF_EPI_GATE_RES && nok) gate_v = bf2f(G.gate[n]);
+    // QKV destination decode for this column
+    int which = 0, head = 0, d = 0;
+    if (epi == RF_EPI_QKV && nok) {
+      which = n / DH;
+      const int rem = n - which * DH;
+      head = rem >> 7;
+      d = rem & 127;
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int mrow0 = m0 + wrow0 + i * 32 + 4 * h;
+      if (epi == RF_EPI_QKV) {
+        if (!nok) continue;
+        if (which < 2) {
+          bf16_t* dst = (which == 0 ? p.q : p.k) + ((int64_t)head * p.s_pad) * 128 + d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            if (m < M) dst[(int64_t)(G.tok_offset + m) * 128] = f2bf(acc[i][j][r] + bias_v);
+          }
+        } else {
+          // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped
+          bf16_t* dst = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64) + d * 64;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int m = mrow0 + 8 * rg;
+            const int tok = G.tok_offset + m;
+            if (((tok & 3) == 0) && (m + 3 < M)) {
+              const int pos = (tok & 51) | ((tok & 4) << 1) | ((tok & 8) >> 1);  // within tile
+              u32x2 v;
+              v[0] = pack2(acc[i][j][rg * 4 + 0] + bias_v, acc[i][j][rg * 4 + 1] + bias_v);
+              v[1] = pack2(acc[i][j][rg * 4 + 2] + bias_v, acc[i][j][rg * 4 + 3] + bias_v);
+              *(u32x2*)(dst + (int64_t)(tok >> 6) * (128 * 64) + pos) = v;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int t2 = tok + e;
+                if (m + e < M) {
+                  const int pos = (t2 & 51) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
+                  dst[(int64_t)(t2 >> 6) * (128 * 64) + pos] = f2bf(acc[i][j][rg * 4 + e] + bias_v);
+                }
+              }
+            }
+          }
+        }
+      } else {
+        if (!nok) continue;
+        bf16_t* orow = G.out + (n - ncol_base);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+          if (m < M) {
+            float v = acc[i][j][r] + bias_v;
+            if (epi == RF_EPI_GELU) {
+              v = gelu_tanh(v);
+            } else if (epi == RF_EPI_GATE_RES) {
+              v = (G.residual != nullptr ? bf2f(G.residual[(int64_t)m * G.ldr + n]) : 0.f) + gate_v * v;
+            }
+            orow[(int64_t)m * G.ldo] = f2bf(v);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
@@ -75,7 +169,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
   const GemmGroupDev& G = p.g[gi];
   const int lt = tile - G.tile_start;
-  const int tn = lt % p.tiles_n, tm = lt / p.tiles_n;
+  // grouped raster: column bands of GW tiles; consecutive ids (= one XCD's chunk after xcd_remap)
+  // walk tm inside a band, so the CUs of an XCD share a few A row-panels AND a few W column-panels
+  // in their private L2 (+5 % at 8192^3, neutral on the FLUX shapes; profiles/r01_gemm_variants.md)
+  constexpr int GW = 8;
+  const int band = lt / (GW * G.tiles_m);
+  const int first = band * GW;
+  const int gw = (p.tiles_n - first) < GW ? (p.tiles_n - first) : GW;
+  const int rr = lt - band * GW * G.tiles_m;
+  const int tm = rr / gw;
+  const int tn = first + rr % gw;
   const int m0 = tm * BM, n0 = tn * BN;
   const int M = G.M, N = p.N;
 
@@ -174,91 +277,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     }
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------
-  // accumulator layout (32x32 MFMA): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  int epi = p.epi;
-  int ncol_base = 0;  // column offset subtracted for the GELU half of QKV_GELU
-  if (epi == RF_EPI_QKV_GELU) {
-    if (n0 >= p.n_split) {
-      epi = RF_EPI_GELU;
-      ncol_base = p.n_split;
-    } else {
-      epi = RF_EPI_QKV;
-    }
-  }
-  const int DH = p.heads * 128;
-
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int n = n0 + wn * TN + j * 32 + l31;
-    const bool nok = n < N;
-    const float bias_v = (G.bias != nullptr && nok) ? bf2f(G.bias[n]) : 0.f;
-    float gate_v = 0.f;
-    if (epi == RF_EPI_GATE_RES && nok) gate_v = bf2f(G.gate[n]);
-    // QKV destination decode for this column
-    int which = 0, head = 0, d = 0;
-    if (epi == RF_EPI_QKV && nok) {
-      which = n / DH;
-      const int rem = n - which * DH;
-      head = rem >> 7;
-      d = rem & 127;
-    }
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int mrow0 = m0 + wm * TM + i * 32 + 4 * h;
-      if (epi == RF_EPI_QKV) {
-        if (!nok) continue;
-        if (which < 2) {
-          bf16_t* dst = (which == 0 ? p.q : p.k) + ((int64_t)head * p.s_pad) * 128 + d;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            if (m < M) dst[(int64_t)(G.tok_offset + m) * 128] = f2bf(acc[i][j][r] + bias_v);
-          }
-        } else {
-          // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped
-          bf16_t* dst = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64) + d * 64;
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int m = mrow0 + 8 * rg;
-            const int tok = G.tok_offset + m;
-            if (((tok & 3) == 0) && (m + 3 < M)) {
-              const int pos = (tok & 51) | ((tok & 4) << 1) | ((tok & 8) >> 1);  // within tile
-              u32x2 v;
-              v[0] = pack2(acc[i][j][rg * 4 + 0] + bias_v, acc[i][j][rg * 4 + 1] + bias_v);
-              v[1] = pack2(acc[i][j][rg * 4 + 2] + bias_v, acc[i][j][rg * 4 + 3] + bias_v);
-              *(u32x2*)(dst + (int64_t)(tok >> 6) * (128 * 64) + pos) = v;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int t2 = tok + e;
-                if (m + e < M) {
-                  const int pos = (t2 & 51) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
-                  dst[(int64_t)(t2 >> 6) * (128 * 64) + pos] = f2bf(acc[i][j][rg * 4 + e] + bias_v);
-                }
-              }
-            }
-          }
-        }
-      } else {
-        if (!nok) continue;
-        bf16_t* orow = G.out + (n - ncol_base);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-          if (m < M) {
-            float v = acc[i][j][r] + bias_v;
-            if (epi == RF_EPI_GELU) {
-              v = gelu_tanh(v);
-            } else if (epi == RF_EPI_GATE_RES) {
-              v = (G.residual != nullptr ? bf2f(G.residual[(int64_t)m * G.ldr + n]) : 0.f) + gate_v * v;
-            }
-            orow[(int64_t)m * G.ldo] = f2bf(v);
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<FM, FN>(p, G, acc, m0, n0, wm * TM, wn * TN, l31, h);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -12,6 +12,8 @@ from reflectionflow_amd import _lib, ops  # noqa: E402
 from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV_GELU, RF_EPI_STORE, Group, Seg  # noqa: E402
 
 dev = torch.device("cuda:0")
+TILES = tuple(int(x) for x in os.environ.get("RF_TILES", "128,256").split(","))
+ONLY_GEMM = os.environ.get("RF_ONLY_GEMM", "0") == "1"
 BF = torch.bfloat16
 
 
@@ -51,10 +53,12 @@ def main():
               ("sgl_in", S, 21504, 3072, RF_EPI_STORE), ("sgl_out", S, 3072, 15360, RF_EPI_GATE_RES),
               ("sq4096", 4096, 4096, 4096, RF_EPI_STORE), ("sq8192", 8192, 8192, 8192, RF_EPI_STORE)]
     for name, M, N, K, epi in shapes:
-        for tile in (128, 256):
+        for tile in TILES:
             t, tf = bench_gemm(M, N, K, tile, epi)
             res[f"gemm_{name}_t{tile}"] = dict(ms=t * 1e3, tflops=tf)
             print(f"gemm {name:9s} {M}x{N}x{K} tile{tile}: {t*1e3:8.3f} ms  {tf:7.1f} TF/s", flush=True)
+    if ONLY_GEMM:
+        return
     # attention, FLUX joint sequence
     for S in (4608, 5632):
         H = 24
