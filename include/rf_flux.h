@@ -3,7 +3,7 @@
  *
  * The reference (/root/reference, 100 % Python) has no FFI: its "plugin interface" for
  * this path is four duck-typed Python functions.  Each entry point below names the
- * reference call it replaces; the Python host side (reflectionflow_amd/flux/*.py) keeps
+ * reference call it replaces; the Python host side (the reflectionflow_amd/flux package) keeps
  * the reference's function names/signatures and binds these symbols with ctypes
  * (see INTEGRATION.md for the stub a reference maintainer would add).
  *

@@ -1,0 +1,96 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/rf_flux.h declares, its
+structs have the layout the ctypes binding assumes, and argument validation fails loudly
+(no kernel is launched: there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "rf_flux.h")
+
+
+def header_functions():
+    txt = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from reflectionflow_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from reflectionflow_amd import _lib
+    raw = C.CDLL(_lib.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(raw, n), f"librf_flux.so does not export {n} (declared in include/rf_flux.h)"
+    assert set(names) == set(_lib.declared_symbols()), "ctypes binding and header disagree"
+    assert lib.rf_abi_version() == _lib.ABI_VERSION and lib.rf_target_arch() == 950
+
+
+def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
+    from reflectionflow_amd import _lib
+    structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_lora_seg", "rf_double_block_weights",
+               "rf_single_block_weights", "rf_flux_dims", "rf_workspace", "rf_flux_model"]
+    src = '#include "rf_flux.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){\n' + "".join(
+        f'printf("{s} %zu\\n", sizeof({s}));\n' for s in structs) + \
+        'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\nreturn 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    for s in structs:
+        assert int(out[s]) == C.sizeof(getattr(_lib, s)), f"sizeof({s}): C {out[s]} vs ctypes {C.sizeof(getattr(_lib, s))}"
+    assert int(out["off_g"]) == _lib.rf_gemm_desc.g.offset
+    assert int(out["off_out"]) == _lib.rf_gemm_group.out.offset
+
+
+def test_argument_validation_is_loud(lib):
+    from reflectionflow_amd import _lib
+    d = _lib.rf_gemm_desc()
+    d.N, d.num_groups = 0, 1
+    assert lib.rf_gemm_bf16(C.byref(d), None) == -1 and b"N=0" in lib.rf_last_error()
+    d.N, d.num_groups, d.epilogue = 64, 1, 9
+    assert lib.rf_gemm_bf16(C.byref(d), None) == -1
+    d.epilogue = 0
+    d.g[0].M, d.g[0].seg[0].K = 4, 72                         # K not a multiple of 64
+    assert lib.rf_gemm_bf16(C.byref(d), None) == -1 and b"multiple of 64" in lib.rf_last_error()
+    d.g[0].seg[0].K = 64                                        # NULL operands
+    assert lib.rf_gemm_bf16(C.byref(d), None) == -3
+    assert lib.rf_attention_fwd(None, None, None, None, 2, 64, 64, 256, 64, 0, 0.0, 1.0, None) == -3
+    assert lib.rf_layernorm_modulate(1 << 4, 64, 1 << 4, 64, 2, 60, 1 << 4, 1 << 4, 1e-6, None) == -1   # D % 8
+    dims = _lib.rf_flux_dims()
+    dims.D, dims.heads, dims.mlp, dims.S_txt, dims.S_img = 256, 2, 1024, 32, 64
+    assert lib.rf_workspace_bytes(C.byref(dims)) > 0
+    dims.heads = 3                                              # D != heads*128
+    ws = _lib.rf_workspace()
+    ws.base, ws.bytes = 256, 1 << 30
+    w = _lib.rf_single_block_weights()
+    assert lib.rf_single_block_fwd(C.byref(dims), C.byref(w), 256, None, 256, 256, None, 256, 256, C.byref(ws), None) == -1
+
+
+def test_product_ops_refuse_cpu_tensors(lib):
+    import torch
+    from reflectionflow_amd import ops
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.flux.block import block_forward
+    x = torch.zeros(4, 64, dtype=torch.bfloat16)
+    with pytest.raises(ops.RFError, match="no CPU fallback"):
+        ops.linear(x, torch.zeros(8, 64, dtype=torch.bfloat16))
+    blk = M.FluxTransformerBlock(256, 2, 128).to(torch.bfloat16)
+    with pytest.raises(ops.RFError):
+        block_forward(blk, torch.zeros(1, 16, 256, dtype=torch.bfloat16), torch.zeros(1, 8, 256, dtype=torch.bfloat16),
+                      None, torch.zeros(1, 256, dtype=torch.bfloat16), None,
+                      image_rotary_emb=(torch.zeros(24, 128), torch.zeros(24, 128)))
