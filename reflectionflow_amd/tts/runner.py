@@ -1,0 +1,139 @@
+"""Candidate-parallel search runner shared by the two driver scripts.
+
+Mirrors the control flow of the reference drivers for the denoise path only:
+  * noise scaling  (tts/tts_t2i_noise_scaling.py:126-159, sample :16-77): per prompt x round draw
+    `search_branch` seeded noises and generate one candidate per noise -- no dependency between rounds;
+  * reflection loop (tts/tts_reflectionflow.py:591-629, sample :94-463): score the previous round,
+    keep the top-k, build a "cot" Condition from each kept candidate, generate the next round with
+    the FLUX-Corrector LoRA active on the condition tokens, re-score.
+What is NOT here (outside the hot path): the GPT-4o / NVILA verifiers and
+the reflection / prompt-refinement LLM calls.  `search.stub_verifier` stands in for their output
+contract; prompts are therefore not rewritten between rounds.
+
+Sharding: candidate i of a round runs on rank i % world_size; the only collective is the all-gather
+of {score, label} at the round boundary (search.allgather_scores).  Seeds are a pure function of
+(prompt index, round, candidate), so results do not depend on the world size.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from ..flux.condition import Condition
+from ..flux.generate import generate
+from ..flux.pipeline import FluxPipeline
+from . import search
+from .utils import TORCH_DTYPE_MAP, get_noises
+
+MAX_SEED = 2 ** 31 - 1
+
+
+def candidate_seeds(prompt_index: int, search_round: int, n: int, base: int = 0) -> List[int]:
+    g = torch.Generator().manual_seed((base * 1000003 + prompt_index * 9176 + search_round * 131) % MAX_SEED)
+    return torch.randint(0, MAX_SEED, (n,), generator=g).tolist()
+
+
+def build_pipeline(config: dict, device, synthetic: bool = False, small: bool = False) -> FluxPipeline:
+    pa = config["pipeline_args"]
+    dtype = TORCH_DTYPE_MAP[pa.get("torch_dtype", "bf16")]
+    if synthetic:
+        cfg = dict(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=256,
+                   pooled_projection_dim=64) if small else None
+        pipe = FluxPipeline.synthetic(cfg, seed=0, torch_dtype=dtype, device=device)
+    else:
+        pipe = FluxPipeline.from_pretrained(pa["pretrained_model_name_or_path"], torch_dtype=dtype,
+                                            cache_dir=pa.get("cache_dir") or None).to(device)
+    pipe.set_progress_bar_config(disable=True)
+    if pa.get("lora_path"):
+        pipe.load_lora_weights(pa["lora_path"], adapter_name="reflection")
+    return pipe
+
+
+def latent_to_condition(latents: torch.Tensor, height: int, width: int, condition_size: int) -> Condition:
+    """Stand-in for `resize(decoded image, condition_size) -> VAE encode` (tts_reflectionflow.py:273-279 +
+    condition.py:96-132) when no VAE is loaded: area-downsample the candidate's latent grid to the
+    condition resolution in latent space.  Position ids follow the reference: delta = [0, -size//16]."""
+    from ..flux.pipeline import FluxPipeline as P
+    z = P._unpack_latents(latents, height, width, 8).float()                   # [1,16,h,w]
+    hc = 2 * (condition_size // 16)
+    z = torch.nn.functional.interpolate(z, size=(hc, hc), mode="area")
+    tokens = P._pack_latents(z, 1, 16, hc, hc).to(latents.dtype)
+    ids = P._prepare_latent_image_ids(1, hc // 2, hc // 2, latents.device, latents.dtype)
+    return Condition("cot", tokens=tokens, ids=ids, position_delta=[0, -(condition_size // 16)])
+
+
+def _save(path: str, latents: torch.Tensor, pipe: FluxPipeline, height: int, width: int):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    if pipe.vae is not None and pipe.image_processor is not None:              # full pipeline available: PNG like the reference
+        z = pipe._unpack_latents(latents, height, width, pipe.vae_scale_factor)
+        z = z / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor
+        img = pipe.image_processor.postprocess(pipe.vae.decode(z, return_dict=False)[0], output_type="pil")[0]
+        img.save(path + ".png")
+    else:
+        torch.save(latents.cpu(), path + ".pt")
+
+
+def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
+                      start_index: int = 0) -> List[dict]:
+    pa, sa = config["pipeline_args"], config["search_args"]
+    dev, dtype = pipe.device, pipe.dtype
+    out = []
+    for index, prompt in enumerate(prompts):
+        sample_dir = os.path.join(output_dir, f"{index + start_index:0>5}", "samples")
+        for rnd in range(1, sa["search_rounds"] + 1):
+            seeds = candidate_seeds(index + start_index, rnd, sa["search_branch"])
+            for i in shard.mine(len(seeds)):
+                noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seeds[i]])[seeds[i]]
+                lat = pipe(prompt=[prompt], latents=noise, guidance_scale=pa["guidance_scale"],
+                           num_inference_steps=pa["num_inference_steps"], height=pa["height"], width=pa["width"],
+                           output_type="latent").images
+                _save(os.path.join(sample_dir, f"{rnd}_round@{seeds[i]}"), lat, pipe, pa["height"], pa["width"])
+            out.append({"prompt": prompt, "search_round": rnd, "num_noises": len(seeds)})
+    if shard.world_size > 1:
+        torch.distributed.barrier()
+    return out
+
+
+def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
+                          start_index: int = 0, verifier=search.stub_verifier) -> List[dict]:
+    pa, sa, model_cfg = config["pipeline_args"], config["search_args"], config.get("model", {})
+    dev, dtype = pipe.device, pipe.dtype
+    N, topk = sa["search_branch"], max(1, sa.get("topk", 1))
+    log = []
+    for index, prompt in enumerate(prompts):
+        pdir = os.path.join(output_dir, f"{index + start_index:0>5}")
+        kept: List[torch.Tensor] = []                                           # selected latents, identical on every rank
+        for rnd in range(0, sa["search_rounds"] + 1):
+            seeds = candidate_seeds(index + start_index, rnd, N)
+
+            def gen(i, seed):
+                noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seed])[seed]
+                conds = None
+                if rnd > 0:                                                     # round 0 = plain t2i (noise scaling)
+                    conds = [latent_to_condition(kept[i % len(kept)], pa["height"], pa["width"], pa["condition_size"])]
+                lat = generate(pipe, prompt=[prompt], conditions=conds, height=pa["height"], width=pa["width"],
+                               num_inference_steps=pa["num_inference_steps"], guidance_scale=pa["guidance_scale"],
+                               latents=noise, model_config=model_cfg, default_lora=True, output_type="latent").images
+                _save(os.path.join(pdir, "samples", f"{rnd}_round@{seed}"), lat, pipe, pa["height"], pa["width"])
+                return lat
+
+            sel, scores, local = search.run_round(shard, seeds, gen, verifier, topk=topk)
+            # hand the selected latents to every rank (N x 512 KiB at 1024^2; the reference hands PNG paths over)
+            kept = []
+            for i in sel:
+                lat = local.get(i)
+                if shard.world_size > 1:
+                    buf = lat if lat is not None else torch.empty(1, (pa["height"] // 16) * (pa["width"] // 16), 64,
+                                                                  device=dev, dtype=dtype)
+                    torch.distributed.broadcast(buf, src=shard.owner(i))
+                    lat = buf
+                kept.append(lat)
+            log.append({"prompt": prompt, "round": rnd, "seeds": seeds, "scores": scores, "selected": sel})
+        if shard.rank == 0:
+            with open(os.path.join(pdir, "search_log.jsonl"), "w") as f:
+                for r in log:
+                    f.write(json.dumps(r) + "\n")
+    return log

@@ -267,3 +267,28 @@ def test_cfg1_small_model_denoise_matches_oracle(dev):
     assert hp.shape == (B, 256, 64)
     e = check(hp, ref, tb, "cfg1-shaped denoise")
     print(f"  cfg1-shaped denoise: hip {e[0]:.3e} torch-bf16 {e[1]:.3e}")
+
+
+@torch.no_grad()
+def test_reflection_search_runner_small(dev, tmp_path):
+    """tts_reflectionflow-style search (round 0 plain, then rounds conditioned on the selected candidate with the
+    corrector LoRA on the condition tokens) on a 2+2-block model: runs, is deterministic, writes the artefacts."""
+    import json
+    import os
+    from reflectionflow_amd.flux.pipeline import synthetic_lora_state_dict
+    from reflectionflow_amd.tts import runner, search
+    cfg = json.load(open(os.path.join(os.path.dirname(runner.__file__), "configs", "flux1_dev_mi355x.json")))
+    cfg["pipeline_args"].update(height=256, width=256, condition_size=128, num_inference_steps=3)
+    cfg["search_args"].update(search_branch=3, search_rounds=2)
+    logs = []
+    for rep in range(2):
+        pipe = runner.build_pipeline(cfg, dev, synthetic=True, small=True)
+        pipe.load_lora_weights(synthetic_lora_state_dict(pipe.transformer, r=8, seed=3), adapter_name="reflection")
+        out = str(tmp_path / f"run{rep}")
+        logs.append(runner.run_reflection_search(cfg, ["a red cube left of a blue ball"], out, pipe, search.Shard(0, 1)))
+        files = sorted(os.listdir(os.path.join(out, "00000", "samples")))
+        assert len(files) == 3 * 3 and all(f.endswith(".pt") and "_round@" in f for f in files)
+        lat = torch.load(os.path.join(out, "00000", "samples", files[-1]))
+        assert lat.shape == (1, 256, 64) and torch.isfinite(lat.float()).all()
+    assert logs[0] == logs[1], "search must be deterministic for fixed seeds"
+    assert [r["round"] for r in logs[0]] == [0, 1, 2] and all(len(r["selected"]) == 1 for r in logs[0])
