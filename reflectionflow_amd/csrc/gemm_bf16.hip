@@ -41,6 +41,7 @@ struct GemmGroupDev {
 
 struct GemmParams {
   int N, epi, ngroups, n_split, heads, s_pad, tiles_n, total_tiles;
+  int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
   bf16_t* q; bf16_t* k; bf16_t* vt;
   GemmGroupDev g[4];
 };
@@ -142,7 +143,150 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGro
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+// ---- LDS-staged epilogue (the fast path) ------------------------------------------------------------
+// The MFMA accumulator layout gives a lane ONE column and 16 scattered rows: stored directly that is
+// 2-byte accesses, and the gated-residual epilogue becomes a chain of dependent 2-byte loads
+// (measured: 670 vs 975 TF/s on 4608x3072x3072).  After the K loop the LDS is idle, so every wave
+// transposes its accumulators through a private 16.5 KiB region, one 32-row fragment block at a time
+// ([32 rows][128 cols] fp32, rows padded to 528 B -> conflict-free ds_write_b32 and ds_read_b128 with
+// every offset an immediate off one base register), and then owns 8 CONSECUTIVE columns of a row: bias/gate are loaded once per lane as
+// 16 bytes, residual rows are prefetched as 16-byte loads, results leave as 16-byte stores (q/k:
+// 16 bytes of one head row).  V^T is written straight from registers (its natural layout already
+// gives 8-byte runs along the key axis).
+constexpr int EPI_ROW = 528;                 // padded fp32 row: 128 cols * 4 B + 16 B
+constexpr int EPI_REGION = 32 * EPI_ROW;     // one wave's staging region
+
+template <int FM>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const GemmGroupDev& G, f32x16 (&acc)[FM][4],
+                                                  const int m0, const int n0, const int wrow0, const int wcol0,
+                                                  const int lane, char* region) {
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M, N = p.N;
+  int epi = p.epi;
+  int ncol_base = 0;
+  if (epi == RF_EPI_QKV_GELU) {
+    if (n0 >= p.n_split) {
+      epi = RF_EPI_GELU;
+      ncol_base = p.n_split;
+    } else {
+      epi = RF_EPI_QKV;
+    }
+  }
+  const int ncol0 = n0 + wcol0;  // first column of this wave's 128-column strip
+  if (ncol0 >= N) return;
+  int which = 0, head = 0;
+  if (epi == RF_EPI_QKV) {
+    const int DH = p.heads * 128;
+    which = ncol0 / DH;
+    head = (ncol0 - which * DH) >> 7;
+  }
+
+  if (epi == RF_EPI_QKV && which == 2) {
+    // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped; lane = one d, 4-key runs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = ncol0 + j * 32 + l31;
+      const float bias_v = G.bias != nullptr ? bf2f(G.bias[n]) : 0.f;
+      bf16_t* dst = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64) + (j * 32 + l31) * 64;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int mrow0 = m0 + wrow0 + i * 32 + 4 * h;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int m = mrow0 + 8 * rg;
+          const int tok = G.tok_offset + m;
+          if (((tok & 3) == 0) && (m + 3 < M)) {
+            const int pos = (tok & 51) | ((tok & 4) << 1) | ((tok & 8) >> 1);
+            u32x2 v;
+            v[0] = pack2(acc[i][j][rg * 4 + 0] + bias_v, acc[i][j][rg * 4 + 1] + bias_v);
+            v[1] = pack2(acc[i][j][rg * 4 + 2] + bias_v, acc[i][j][rg * 4 + 3] + bias_v);
+            *(u32x2*)(dst + (int64_t)(tok >> 6) * (128 * 64) + pos) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int t2 = tok + e;
+              if (m + e < M) {
+                const int pos = (t2 & 51) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
+                dst[(int64_t)(t2 >> 6) * (128 * 64) + pos] = f2bf(acc[i][j][rg * 4 + e] + bias_v);
+              }
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // this lane's 8 consecutive columns
+  const int q8 = (lane & 15) * 8;
+  const int n = ncol0 + q8;
+  const bool nok = n < N;  // N % 8 == 0 on this path
+  float bias8[8], gate8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f, gate8[e] = 0.f;
+  if (nok && G.bias != nullptr) unpack8(*(const u32x4*)(G.bias + n), bias8);
+  if (nok && epi == RF_EPI_GATE_RES) unpack8(*(const u32x4*)(G.gate + n), gate8);
+  const int rsub = lane >> 4;            // row within a 4-row read group
+  const int c0 = (lane & 15) * 2;        // first of this lane's two 16-byte chunks
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    // registers -> LDS (row-major fp32 with swizzled chunks)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = j * 32 + l31;
+        *(float*)(region + row * EPI_ROW + col * 4) = acc[i][j][r];
+      }
+    const int mbase = m0 + wrow0 + i * 32;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {  // two batches of 4 row groups: bounds the prefetch registers
+      u32x4 resv[4];
+      if (epi == RF_EPI_GATE_RES && G.residual != nullptr) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = mbase + (ib * 4 + it) * 4 + rsub;
+          if (m < M && nok) resv[it] = *(const u32x4*)(G.residual + (int64_t)m * G.ldr + n);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = (ib * 4 + it) * 4 + rsub;
+        const int m = mbase + row;
+        const f32x4 lo = *(const f32x4*)(region + row * EPI_ROW + c0 * 16);
+        const f32x4 hi = *(const f32x4*)(region + row * EPI_ROW + c0 * 16 + 16);
+        if (m < M && nok) {
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+          if (epi == RF_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+          } else if (epi == RF_EPI_GATE_RES) {
+            float rr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rr[e] = 0.f;
+            if (G.residual != nullptr) unpack8(resv[it], rr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rr[e] + gate8[e] * v[e];
+          }
+          bf16_t* dst;
+          if (epi == RF_EPI_QKV) {
+            dst = (which == 0 ? p.q : p.k) + ((int64_t)head * p.s_pad + G.tok_offset + m) * 128 + q8;
+          } else {
+            dst = G.out + (int64_t)m * G.ldo + (n - ncol_base);
+          }
+          *(u32x4*)dst = pack8(v);
+        }
+      }
+    }
+  }
+}
+
+// VEC: LDS-staged 16-byte epilogue (all pointers 16-byte aligned, N % 8 == 0) vs the per-element fallback
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
@@ -277,15 +421,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     }
   }
 
-  gemm_epilogue<FM, FN>(p, G, acc, m0, n0, wm * TM, wn * TN, l31, h);
+  if constexpr (VEC) {
+    static_assert(FN == 4, "LDS-staged epilogue expects 128-column wave strips");
+    __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+    gemm_epilogue_lds<FM>(p, G, acc, m0, n0, wm * TM, wn * TN, lane, smem + w * EPI_REGION);
+  } else {
+    gemm_epilogue<FM, FN>(p, G, acc, m0, n0, wm * TM, wn * TN, l31, h);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
+  constexpr int LDS = (VEC && LDS_EPI > LDS_MAIN) ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WM, WN>;
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, VEC>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -351,6 +502,15 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
     if (qkv) RF_REQUIRE(s.tok_offset >= 0 && s.tok_offset + s.M <= d->s_pad, RF_ERR_SHAPE, "rf_gemm_bf16: tokens exceed s_pad");
   }
   p.ngroups = ng;
+  bool vec = (d->N % 8 == 0) && (!qkv || (aligned16(d->q) && aligned16(d->k) && aligned16(d->vt)));
+  if (d->epilogue == RF_EPI_QKV_GELU) vec = vec && ((d->N - d->n_split) % 8 == 0);
+  for (int g = 0; g < ng; ++g) {
+    const GemmGroupDev& t = p.g[g];
+    vec = vec && (t.bias == nullptr || aligned16(t.bias)) && (t.gate == nullptr || aligned16(t.gate)) &&
+          (t.out == nullptr || (aligned16(t.out) && t.ldo % 8 == 0)) &&
+          (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
+  }
+  p.vec_ok = vec ? 1 : 0;
   return RF_OK;
 }
 
@@ -364,8 +524,9 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
     const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
     tile = (t256 >= 200) ? 256 : 128;
   }
-  if (tile == 256) return launch_gemm<256, 256, 2, 4>(p, stream);
-  return launch_gemm<128, 128, 2, 2>(p, stream);
+  // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
+  if (tile == 256) return p.vec_ok ? launch_gemm<256, 256, 4, 2, true>(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
+  return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }
 
 }  // namespace rf

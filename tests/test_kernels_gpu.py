@@ -50,7 +50,7 @@ def assert_close(got, ref, what, rtol=1.2e-2, atol=None):
 # ------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 768, 512), (512, 64, 256), (1, 512, 256),
-                                   (1024, 1536, 1024)])
+                                   (1024, 1536, 1024), (130, 100, 64), (513, 3076, 128)])
 def test_gemm_store(dev, tile, M, N, K):
     from reflectionflow_amd import _lib, ops
     _lib.load().rf_debug_force_gemm_tile(tile)
