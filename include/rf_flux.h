@@ -72,6 +72,8 @@ typedef struct rf_gemm_group {
   void* out; int64_t ldo;             /* STORE/GELU/GATE_RES: [M x N];  QKV_GELU: [M x (N-n_split)] */
   const void* residual; int64_t ldr;  /* GATE_RES: [M x N] (may alias out); NULL = 0 */
   const void* gate;                   /* GATE_RES: [N] */
+  const void* norm_q;                 /* QKV + rope_cos: per-head RMSNorm weights [128] for this group's q rows */
+  const void* norm_k;                 /*                 ... and k rows (text group: norm_added_q/k)             */
 } rf_gemm_group;
 
 typedef struct rf_gemm_desc {
@@ -83,6 +85,11 @@ typedef struct rf_gemm_desc {
   void* q;  void* k;                  /* [heads][S_pad][128] */
   void* vt;                           /* [heads][S_pad/64][128][64] key-permuted, see rf_attention_fwd */
   int32_t heads; int32_t s_pad;
+  /* optional fusion of rf_qk_rmsnorm_rope into the QKV epilogue (block.py:38-41,60-67,74-78,92-99):
+   * when rope_cos != NULL, q and k rows are RMS-normalised with the group's norm_q/norm_k and rotated
+   * with the fp32 tables [S][128] (indexed by joint token row) before they are stored. */
+  const float* rope_cos; const float* rope_sin;
+  float norm_eps; int32_t _pad;
   rf_gemm_group g[4];
 } rf_gemm_desc;
 
@@ -92,6 +99,8 @@ int rf_gemm_bf16(const rf_gemm_desc* d, void* stream);
  * Fused per-head RMSNorm(q,k) + interleaved-pair RoPE, in place on head-major q,k
  * (replaces attn.norm_q/k, norm_added_q/k and apply_rotary_emb: block.py:38-41,60-67,74-78,92-99)
  *   rows [0, n_added) use w_added_* (text stream), rows [n_added, S) use w_* .
+ *   (The engine fuses this into the QKV GEMM epilogue -- rf_gemm_desc.rope_cos; the standalone kernel
+ *   remains for callers that produce q,k themselves.)
  *   cos,sin: fp32 [S][128] (FluxPosEmbed tables for [txt|img|cond] rows, transformer.py:130-134)
  * ---------------------------------------------------------------------------------- */
 int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 
@@ -28,12 +28,13 @@ class rf_kseg(C.Structure):
 class rf_gemm_group(C.Structure):
     _fields_ = [("seg", rf_kseg * 3), ("bias", C.c_void_p), ("M", C.c_int32), ("tok_offset", C.c_int32),
                 ("out", C.c_void_p), ("ldo", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
-                ("gate", C.c_void_p)]
+                ("gate", C.c_void_p), ("norm_q", C.c_void_p), ("norm_k", C.c_void_p)]
 
 
 class rf_gemm_desc(C.Structure):
     _fields_ = [("N", C.c_int32), ("epilogue", C.c_int32), ("num_groups", C.c_int32), ("n_split", C.c_int32),
                 ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("heads", C.c_int32), ("s_pad", C.c_int32),
+                ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("norm_eps", C.c_float), ("_pad", C.c_int32),
                 ("g", rf_gemm_group * 4)]
 
 

@@ -122,7 +122,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
   stage(0, 0);
   for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // tile t landed (vmcnt(0) inside); all waves finished tile t-1
+    // Tile t's LDS-DMA must have landed for EVERY wave before anyone reads it.  The wait is explicit:
+    // hipcc does not reliably track LDS-DMA across a loop back edge (it hoisted its own vmcnt(0)
+    // out of this loop, leaving tiles >= 1 unguarded -- a cold-cache race).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // ... and all waves have finished reading tile t-1's buffer
     if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
     const char* kb = smem + (t & 1) * ATT_STAGE;
     const char* vb = kb + ATT_K_BYTES;

@@ -1,8 +1,8 @@
 // Block / forward / denoise sequencing for the FLUX MM-DiT hot path on one MI355X.
 //
 // A transformer forward is a FIXED sequence of ~350 kernel launches on one HIP stream, with no
-// allocation and no host synchronisation inside (hipGraph-capturable): 8 launches per
-// DoubleStream block, 5 per SingleStream block (DESIGN.md "step anatomy").  All activations
+// allocation and no host synchronisation inside (hipGraph-capturable): 7 launches per
+// DoubleStream block, 4 per SingleStream block (DESIGN.md "step anatomy").  All activations
 // live in a caller-owned workspace laid out once per (S_txt, S_img, S_cond):
 //
 //   XN  [S][D]        LayerNorm+modulate output (GEMM A operand)
@@ -132,12 +132,15 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
     d.N = 3 * D; d.epilogue = RF_EPI_QKV; d.num_groups = 3; d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
+    d.rope_cos = cos_tab; d.rope_sin = sin_tab; d.norm_eps = 1e-6f;   // per-head RMSNorm + RoPE fused into the epilogue
     for (int i = 0; i < 3; ++i) {
       const Stream& s = sx[i];
       rf_gemm_group& g = d.g[i];
       g.M = s.rows; g.tok_offset = s.off;
       if (s.rows <= 0) continue;
       const bool txt = (i == 0);
+      g.norm_q = txt ? w->norm_added_q : w->norm_q;
+      g.norm_k = txt ? w->norm_added_k : w->norm_k;
       set_seg(g.seg[0], XN + (int64_t)s.off * D, D, txt ? w->w_add_qkv : w->w_qkv, D, D);
       g.bias = txt ? w->b_add_qkv : w->b_qkv;
       if (!txt && s.lora && w->lora_qkv.B) {
@@ -148,9 +151,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
     }
     RF_TRY(rf_gemm_bf16(&d, st));
   }
-  // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE
-  RF_TRY(rf_qk_rmsnorm_rope(Q, K, H, S, L.s_pad, St, w->norm_q, w->norm_k, w->norm_added_q, w->norm_added_k, cos_tab,
-                            sin_tab, 1e-6f, st));
+  // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE: fused into the QKV epilogue above
   // 4. joint attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, St + Si, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
                           0.08838834764831845f /* 1/sqrt(128) */, st));
@@ -268,11 +269,13 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
     memset(&d, 0, sizeof(d));
     d.N = 3 * D + MLP; d.epilogue = RF_EPI_QKV_GELU; d.n_split = 3 * D; d.num_groups = 2;
     d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
+    d.rope_cos = cos_tab; d.rope_sin = sin_tab; d.norm_eps = 1e-6f;
     for (int i = 0; i < 2; ++i) {
       const Stream& s = sx[i];
       rf_gemm_group& g = d.g[i];
       g.M = s.rows; g.tok_offset = s.off;
       if (s.rows <= 0) continue;
+      g.norm_q = w->norm_q; g.norm_k = w->norm_k;
       set_seg(g.seg[0], XN + (int64_t)s.off * D, D, w->w_qkv_mlp, D, D);
       g.bias = w->b_qkv_mlp;
       g.out = HID + (int64_t)s.off * MLP; g.ldo = MLP;
@@ -284,8 +287,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
     }
     RF_TRY(rf_gemm_bf16(&d, st));
   }
-  // 3. RMSNorm(q,k) + RoPE (no added-norm rows in single blocks)
-  RF_TRY(rf_qk_rmsnorm_rope(Q, K, H, S, L.s_pad, 0, w->norm_q, w->norm_k, nullptr, nullptr, cos_tab, sin_tab, 1e-6f, st));
+  // 3. RMSNorm(q,k) + RoPE: fused into the epilogue above (no added-norm rows in single blocks)
   // 4. attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, Sm, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
                           0.08838834764831845f, st));

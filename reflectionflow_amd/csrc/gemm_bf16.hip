@@ -36,6 +36,7 @@ struct GemmGroupDev {
   bf16_t* out; int64_t ldo;
   const bf16_t* residual; int64_t ldr;
   const bf16_t* gate;
+  const bf16_t* norm_q; const bf16_t* norm_k;
   int M, tok_offset, tile_start, tiles_m;
 };
 
@@ -43,6 +44,7 @@ struct GemmParams {
   int N, epi, ngroups, n_split, heads, s_pad, tiles_n, total_tiles;
   int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
   bf16_t* q; bf16_t* k; bf16_t* vt;
+  const float* rope_cos; const float* rope_sin; float norm_eps;
   GemmGroupDev g[4];
 };
 
@@ -228,6 +230,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
   if (nok && epi == RF_EPI_GATE_RES) unpack8(*(const u32x4*)(G.gate + n), gate8);
   const int rsub = lane >> 4;            // row within a 4-row read group
   const int c0 = (lane & 15) * 2;        // first of this lane's two 16-byte chunks
+  // fused per-head RMSNorm + RoPE (block.py:38-41,60-67,74-78,92-99): the 16 lanes lane&~15 .. +15 hold
+  // one complete 128-wide head row, 8 consecutive d each (rotation pairs stay inside a lane)
+  const bool fuse_rope = (epi == RF_EPI_QKV) && (p.rope_cos != nullptr);
+  float nw8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) nw8[e] = 1.f;
+  if (fuse_rope) unpack8(*(const u32x4*)((which == 0 ? G.norm_q : G.norm_k) + q8), nw8);
 
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -274,6 +283,25 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
           }
           bf16_t* dst;
           if (epi == RF_EPI_QKV) {
+            if (fuse_rope) {
+              const int64_t trow = (int64_t)(G.tok_offset + m) * 128 + q8;
+              const f32x4 ca = *(const f32x4*)(p.rope_cos + trow), cb = *(const f32x4*)(p.rope_cos + trow + 4);
+              const f32x4 sa = *(const f32x4*)(p.rope_sin + trow), sb = *(const f32x4*)(p.rope_sin + trow + 4);
+              const float cs[8] = {ca[0], ca[1], ca[2], ca[3], cb[0], cb[1], cb[2], cb[3]};
+              const float sn[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+              float ss = 0.f;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+#pragma unroll
+              for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+              const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.norm_eps);
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                const float a = v[e] * rs * nw8[e], b = v[e + 1] * rs * nw8[e + 1];
+                v[e] = a * cs[e] - b * sn[e];
+                v[e + 1] = b * cs[e + 1] + a * sn[e + 1];
+              }
+            }
             dst = (which == 0 ? p.q : p.k) + ((int64_t)head * p.s_pad + G.tok_offset + m) * 128 + q8;
           } else {
             dst = G.out + (int64_t)m * G.ldo + (n - ncol_base);
@@ -399,7 +427,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   advance();
 
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();  // tile kt has landed (vmcnt(0) inside); every wave is done with tile kt-1
+    // explicit drain of this wave's LDS-DMA before the barrier: never rely on the compiler's own
+    // vmcnt placement for LDS-DMA in a loop (see attention.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt has landed for every wave; every wave is done with tile kt-1
     if (kt + 1 < nk) {
       stage(kk, (kt + 1) & 1);
       advance();
@@ -467,6 +498,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
   p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
+  p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin; p.norm_eps = d->norm_eps;
   const bool qkv = d->epilogue == RF_EPI_QKV || d->epilogue == RF_EPI_QKV_GELU;
   if (qkv) {
     RF_REQUIRE(d->q && d->k && d->vt, RF_ERR_NULL, "rf_gemm_bf16: QKV epilogue needs q,k,vt");
@@ -497,6 +529,10 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
     t.M = s.M; t.tok_offset = s.tok_offset;
     t.out = (bf16_t*)s.out; t.ldo = s.ldo;
     t.residual = (const bf16_t*)s.residual; t.ldr = s.ldr; t.gate = (const bf16_t*)s.gate;
+    t.norm_q = (const bf16_t*)s.norm_q; t.norm_k = (const bf16_t*)s.norm_k;
+    if (qkv && d->rope_cos != nullptr)
+      RF_REQUIRE(s.norm_q && s.norm_k && aligned16(s.norm_q) && aligned16(s.norm_k), RF_ERR_NULL,
+                 "rf_gemm_bf16: fused rope needs 16-byte aligned norm_q/norm_k in group %d", g);
     if (d->epilogue != RF_EPI_QKV) RF_REQUIRE(s.out != nullptr, RF_ERR_NULL, "rf_gemm_bf16: group %d out NULL", g);
     if (d->epilogue == RF_EPI_GATE_RES) RF_REQUIRE(s.gate != nullptr, RF_ERR_NULL, "rf_gemm_bf16: GATE_RES needs gate");
     if (qkv) RF_REQUIRE(s.tok_offset >= 0 && s.tok_offset + s.M <= d->s_pad, RF_ERR_SHAPE, "rf_gemm_bf16: tokens exceed s_pad");
@@ -511,6 +547,11 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
           (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
   }
   p.vec_ok = vec ? 1 : 0;
+  if (d->rope_cos != nullptr) {
+    RF_REQUIRE(qkv && d->rope_sin != nullptr && aligned16(d->rope_cos) && aligned16(d->rope_sin), RF_ERR_ALIGN,
+               "rf_gemm_bf16: rope tables need a QKV epilogue and 16-byte alignment");
+    RF_REQUIRE(vec, RF_ERR_ALIGN, "rf_gemm_bf16: fused RMSNorm+RoPE needs the 16-byte aligned epilogue path");
+  }
   return RF_OK;
 }
 

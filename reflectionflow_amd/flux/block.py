@@ -100,21 +100,20 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
         q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
         groups = []
         if has_txt:
-            groups.append(ops.Group([ops.Seg(encoder_hidden_states[b], w_add)], bias=b_add, tok_offset=0))
+            groups.append(ops.Group([ops.Seg(encoder_hidden_states[b], w_add)], bias=b_add, tok_offset=0,
+                                    norm_q=attn.norm_added_q.weight, norm_k=attn.norm_added_k.weight))
 
         def proj_group(x, off, use_lora):
             segs = [ops.Seg(x, w_qkv)]
             if use_lora and lora is not None:
                 segs.append(ops.Seg(ops.linear(x, lora[0]), lora[1]))
-            return ops.Group(segs, bias=b_qkv, tok_offset=off)
+            return ops.Group(segs, bias=b_qkv, tok_offset=off, norm_q=attn.norm_q.weight, norm_k=attn.norm_k.weight)
 
         groups.append(proj_group(hidden_states[b], St, latent_lora))
         if has_cond:
             groups.append(proj_group(condition_latents[b], St + Si, True))
-        ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad)
-        ops.qk_rmsnorm_rope(q, k, S, St, attn.norm_q.weight, attn.norm_k.weight,
-                            attn.norm_added_q.weight if has_txt else None,
-                            attn.norm_added_k.weight if has_txt else None, cos, sin)
+        # QKV projections with per-head RMSNorm + RoPE fused into the epilogue
+        ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin))
         outs.append(ops.attention(q, k, vt, S, n_main=St + Si, mode=mode, cross_bias=bias))
     hs = torch.stack(outs, 0)                                           # [B, S, D]
 

@@ -56,16 +56,27 @@ class Seg:
 class Group:
     """One token group of a grouped GEMM."""
 
-    def __init__(self, segs: Sequence[Seg], bias=None, out=None, residual=None, gate=None, tok_offset=0):
+    def __init__(self, segs: Sequence[Seg], bias=None, out=None, residual=None, gate=None, tok_offset=0,
+                 norm_q=None, norm_k=None):
         self.segs, self.bias, self.out, self.residual, self.gate, self.tok_offset = (
             list(segs), bias, out, residual, gate, tok_offset)
+        self.norm_q, self.norm_k = norm_q, norm_k
 
 
 def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
-                    q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0) -> "L.rf_gemm_desc":
+                    q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0, rope=None, norm_eps: float = 1e-6
+                    ) -> "L.rf_gemm_desc":
+    """rope=(cos, sin) fp32 [S,128]: fuse per-head RMSNorm (each group's norm_q/norm_k) + RoPE into the
+    QKV epilogue."""
     d = L.rf_gemm_desc()
     d.N, d.epilogue, d.num_groups, d.n_split = N, epilogue, len(groups), n_split
     d.q, d.k, d.vt, d.heads, d.s_pad = ptr(q), ptr(k), ptr(vt), heads, s_pad
+    if rope is not None:
+        cos, sin = rope
+        _chk(cos, "cos", torch.float32), _chk(sin, "sin", torch.float32)
+        if not (cos.is_contiguous() and sin.is_contiguous() and cos.shape[1] == 128 and cos.shape == sin.shape):
+            raise RFError("rope tables must be contiguous fp32 [S,128]")
+        d.rope_cos, d.rope_sin, d.norm_eps = cos.data_ptr(), sin.data_ptr(), norm_eps
     for gi, g in enumerate(groups):
         G = d.g[gi]
         G.M = g.segs[0].A.shape[0]
@@ -87,6 +98,8 @@ def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STOR
             G.residual, G.ldr = r.data_ptr(), r.stride(0)
         if g.gate is not None:
             G.gate = _chk(g.gate, "gate").data_ptr()
+        if g.norm_q is not None:
+            G.norm_q, G.norm_k = _chk(g.norm_q, "norm_q").data_ptr(), _chk(g.norm_k, "norm_k").data_ptr()
     return d
 
 

@@ -301,3 +301,49 @@ def test_errors_are_loud(dev):
         ops.linear(torch.zeros(4, 72, dtype=BF, device=dev), torch.zeros(8, 72, dtype=BF, device=dev))  # K % 64
     with pytest.raises(ops.RFError):
         ops.linear(torch.zeros(4, 64, device=dev), torch.zeros(8, 64, device=dev))    # fp32
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("St,Si,Sc", [(32, 64, 16), (30, 70, 13), (512, 320, 0)])
+def test_gemm_qkv_fused_norm_rope(dev, tile, St, Si, Sc):
+    """QKV GEMM with per-head RMSNorm (text rows: added-norm weights) + RoPE fused into the epilogue
+    == plain QKV GEMM followed by the oracle's RMSNorm / apply_rotary_emb (block.py:38-41,60-67,74-78)."""
+    from oracle import flux_oracle as O
+    from reflectionflow_amd import _lib, ops
+    from reflectionflow_amd.ops import RF_EPI_QKV, Group, Seg
+    _lib.load().rf_debug_force_gemm_tile(tile)
+    try:
+        H, D = 2, 256
+        S = St + Si + Sc
+        q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+        xs = [rnd(m, D, dev=dev, seed=40 + i) for i, m in enumerate((St, Si, Sc)) if m]
+        Wt, Wi = rnd(3 * D, D, dev=dev, scale=0.05, seed=3), rnd(3 * D, D, dev=dev, scale=0.05, seed=4)
+        bt, bi = rnd(3 * D, dev=dev, seed=5), rnd(3 * D, dev=dev, seed=6)
+        nw = [(1 + 0.1 * torch.randn(128, generator=torch.Generator().manual_seed(70 + i))).to(dev).to(BF) for i in range(4)]
+        ids = torch.zeros(S, 3)
+        ids[:, 1] = torch.arange(S) % 23
+        ids[:, 2] = torch.arange(S) // 7
+        cos, sin = O.FluxPosEmbed(10000, (16, 56, 56))(ids)
+        cos, sin = cos.to(dev).contiguous(), sin.to(dev).contiguous()
+        offs = [0, St, St + Si]
+        groups, refs = [], []
+        for gi, x in enumerate(xs):
+            txt = gi == 0
+            groups.append(Group([Seg(x, Wt if txt else Wi)], bias=bt if txt else bi, tok_offset=offs[gi],
+                                norm_q=nw[2] if txt else nw[0], norm_k=nw[3] if txt else nw[1]))
+            refs.append(x.float() @ (Wt if txt else Wi).float().t() + (bt if txt else bi).float())
+        ops.gemm(groups, 3 * D, RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin))
+        ref = torch.cat(refs, 0)
+        is_txt = (torch.arange(S, device=dev) < St)[:, None]
+
+        def nr(x, w_main, w_added):
+            x = x.reshape(S, H, 128).permute(1, 0, 2)[None]                  # [1,H,S,128]
+            xn = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6)
+            w = torch.where(is_txt, w_added.float()[None], w_main.float()[None])
+            return O.apply_rotary_emb(xn * w[None, None], (cos, sin))[0]
+
+        assert_close(q[:, :S], nr(ref[:, :D], nw[0], nw[2]), "fused q")
+        assert_close(k[:, :S], nr(ref[:, D:2 * D], nw[1], nw[3]), "fused k")
+        assert_close(vt_unpermute(vt, S), ref[:, 2 * D:].reshape(S, H, 128).permute(1, 0, 2), "v^T (untouched by rope)")
+    finally:
+        _lib.load().rf_debug_force_gemm_tile(0)

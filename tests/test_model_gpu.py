@@ -292,3 +292,98 @@ def test_reflection_search_runner_small(dev, tmp_path):
         assert lat.shape == (1, 256, 64) and torch.isfinite(lat.float()).all()
     assert logs[0] == logs[1], "search must be deterministic for fixed seeds"
     assert [r["round"] for r in logs[0]] == [0, 1, 2] and all(len(r["selected"]) == 1 for r in logs[0])
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("St,Si,Sc", [(512, 4096, 0), (512, 4096, 1024)])
+def test_full_size_blocks_vs_oracle_on_gpu(dev, St, Si, Sc):
+    """BASELINE cfg2 / cfg4 token counts at FLUX.1-dev width (D=3072, 24 heads): one DoubleStream and one
+    SingleStream block through the HIP path vs the fp32 oracle evaluated on the same GPU."""
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.flux.block import block_forward, single_block_forward
+    D, H = 3072, 24
+    torch.manual_seed(0)
+    with torch.device(dev):
+        od = O.FluxTransformerBlock(D, H, 128).float().eval()
+        os_ = O.FluxSingleTransformerBlock(D, H, 128).float().eval()
+    g = torch.Generator(device=dev).manual_seed(1)
+    for m in (od, os_):
+        for name, p in m.named_parameters():
+            p.copy_((1.0 if (name.endswith("weight") and p.ndim == 1) else 0.0) + 0.02 * torch.randn(p.shape, generator=g, device=dev))
+    pd, ps = M.FluxTransformerBlock(D, H, 128), M.FluxSingleTransformerBlock(D, H, 128)
+    pd.load_state_dict({k: v.cpu() for k, v in od.state_dict().items()})
+    ps.load_state_dict({k: v.cpu() for k, v in os_.state_dict().items()})
+    pd, ps = pd.to(dev).to(BF), ps.to(dev).to(BF)
+    r = lambda *s: torch.randn(*s, generator=g, device=dev)  # noqa: E731
+    x, e, temb, ctemb = r(1, Si, D), r(1, St, D), r(1, D), r(1, D)
+    c = r(1, Sc, D) if Sc else None
+    side = int(Si ** 0.5)
+    ids = torch.cat([torch.zeros(St, 3), O.prepare_latent_image_ids(side, side)])
+    pe = O.FluxPosEmbed(10000, (16, 56, 56))
+    rope = tuple(t.to(dev) for t in pe(ids))
+    crope = tuple(t.to(dev) for t in pe(O.condition_ids_for(int(Sc ** 0.5) * 16))) if Sc else None
+    cfg = {"union_cond_attn": True}
+    # round the inputs to bf16 once so both paths see identical values
+    xb, eb, tb, cb_, ctb = (t.to(BF) if t is not None else None for t in (x, e, temb, c, ctemb))
+    f = lambda t: t.float() if t is not None else None  # noqa: E731
+    ref = O.block_forward(od, f(xb), f(eb), f(cb_), f(tb), f(ctb) if Sc else None, cond_rotary_emb=crope,
+                          image_rotary_emb=rope, model_config=cfg)
+    hp = block_forward(pd, xb, eb, cb_, tb, ctb if Sc else None, cond_rotary_emb=crope, image_rotary_emb=rope,
+                       model_config=cfg)
+    for name, a, b in zip(("txt", "img", "cond"), hp, ref):
+        if a is None:
+            continue
+        assert torch.isfinite(a.float()).all(), f"double/{name}: non-finite"
+        e_ = rel_l2(a, b)
+        print(f"  double/{name} S={St}+{Si}+{Sc}: rel-L2 {e_:.3e}")
+        assert e_ < 8e-3, f"double/{name}: rel-L2 {e_:.3e}"
+    xs = torch.cat([eb, xb], 1)
+    kw32 = dict(condition_latents=f(cb_), cond_temb=f(ctb), cond_rotary_emb=crope) if Sc else {}
+    kwbf = dict(condition_latents=cb_, cond_temb=ctb, cond_rotary_emb=crope) if Sc else {}
+    ref = O.single_block_forward(os_, f(xs), f(tb), image_rotary_emb=rope, model_config=cfg, **kw32)
+    hp = single_block_forward(ps, xs, tb, image_rotary_emb=rope, model_config=cfg, **kwbf)
+    ref = ref if isinstance(ref, tuple) else (ref,)
+    hp = hp if isinstance(hp, tuple) else (hp,)
+    for name, a, b in zip(("main", "cond"), hp, ref):
+        assert torch.isfinite(a.float()).all(), f"single/{name}: non-finite"
+        e_ = rel_l2(a, b)
+        print(f"  single/{name}: rel-L2 {e_:.3e}")
+        assert e_ < 8e-3, f"single/{name}: rel-L2 {e_:.3e}"
+
+
+@torch.no_grad()
+def test_full_flux_dev_forward_deterministic_and_matches_oracle(dev):
+    """The whole FLUX.1-dev-shaped transformer (19 double + 38 single blocks, 11.9 B random-init params) at
+    the BASELINE cfg2 size (512 text + 4096 image tokens): HIP forward vs the fp32 oracle evaluated on the same
+    GPU, and bitwise run-to-run determinism of the kernel sequence (this is the test that exposes a missing
+    LDS-DMA wait: such races only show with cold caches inside the real sequence, not in isolated kernels)."""
+    import bench
+    from reflectionflow_amd import engine as E
+    pipe = bench.build_model(dev, {}, seed=0)
+    tr = pipe.transformer
+    eng = E.engine_for(tr)
+    gen = torch.Generator().manual_seed(1)
+    St, Si = 512, 4096
+    pe = torch.randn(St, 4096, generator=gen).to(dev).to(BF)
+    pooled = torch.randn(1, 768, generator=gen).to(dev).to(BF)
+    lat = torch.randn(Si, 64, generator=gen).to(dev).to(BF)
+    img_ids, txt_ids = O.prepare_latent_image_ids(64, 64), torch.zeros(St, 3)
+    t, gd = torch.tensor([0.5], device=dev), torch.tensor([4.0], device=dev)      # exact in bf16 after x1000
+    temb = eng.temb(t.to(BF) * 1000, gd.to(BF) * 1000, pooled)
+    mod = eng.mod_table(temb)[0].contiguous()
+    cos, sin = eng.rope_tables(txt_ids, img_ids)
+    outs = [eng.forward(lat, pe, mod, cos, sin).clone() for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(o.float()).all() for o in outs)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:]), "kernel sequence is not deterministic run-to-run"
+    with torch.device(dev):
+        om = O.FluxTransformer2DModel().float().eval()
+    om.load_state_dict({k: v.float() for k, v in tr.state_dict().items()})
+    ref = O.tranformer_forward(om, None, None, None, model_config={}, hidden_states=lat.float()[None],
+                               encoder_hidden_states=pe.float()[None], pooled_projections=pooled.float(), timestep=t,
+                               guidance=gd, img_ids=img_ids, txt_ids=txt_ids, return_dict=False)[0][0]
+    e = rel_l2(outs[0], ref)
+    print(f"  full FLUX-dev forward: rel-L2 vs fp32 oracle {e:.3e} (57 blocks deep)")
+    assert e < 4e-2, f"full forward rel-L2 {e:.3e}"
+    del om
+    torch.cuda.empty_cache()
