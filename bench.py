@@ -13,7 +13,7 @@
              the only collective is the round-boundary all-gather of verifier scores (RCCL).
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-    roofline     -- the dominant kernel (the 256x256 bf16 MFMA GEMM): algorithmic FLOPs of all its
+    roofline     -- the dominant kernel (the 256x256 bf16 MFMA GEMM, rf::gemm_bf16_kernel<256,256,4,2,true>): algorithmic FLOPs of all its
                     launches in one forward / their summed hipEvent-timed durations, vs 2.5 PFLOP/s.
     cpu_baseline -- the CPU oracle (a port of the reference path) timed on the host cores over a
                     bounded sample of the same workload, extrapolated and labelled as such.
@@ -114,7 +114,7 @@ def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
         tot_t += count * sec
         n_launch += count
     ach = tot_f / tot_t / 1e12
-    return {"bound": "mfma", "kernel": "rf::gemm_bf16_kernel<256,256,2,4>", "achieved": round(ach, 1),
+    return {"bound": "mfma", "kernel": "rf::gemm_bf16_kernel<256,256,4,2,true>", "achieved": round(ach, 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "launches_per_forward": n_launch, "avg_launch_us": round(tot_t / n_launch * 1e6, 1),
             "flops_per_launch_avg": tot_f / n_launch, "shapes": per}

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
           tmax = fmaxf(tmax, x);
         }
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    {  // the other 32 keys of this query live in lane ^ 32: v_permlane32_swap (VALU, no LDS round trip)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+      tmax = fmaxf(tmax, __uint_as_float(h ? sw[0] : sw[1]));
+    }
     const float m_new = fmaxf(m_run, tmax);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
@@ -190,10 +193,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         pf[kvb * 2 + s2] = t8;
       }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {  // wave-uniform: after the first tiles the running max rarely moves
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
 
     // ---- O^T += V^T P^T : 4 d-blocks x 4 key steps ---------------------------------------
 #pragma unroll
@@ -240,8 +245,7 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
   RF_REQUIRE(n_main >= 0 && n_main <= S, RF_ERR_SHAPE, "rf_attention_fwd: n_main=%d", n_main);
   static bool attr_set = false;
   if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     2 * ATT_STAGE));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
     attr_set = true;
   }
   AttnParams p;
