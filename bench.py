@@ -81,6 +81,8 @@ def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
     W2, W2b = r(D, mlp, sc=.02), r(D, mlp, sc=.02)
     Wf, Ws = r(3 * D + mlp, D, sc=.02), r(D, D + mlp, sc=.02)
     t, i = slice(0, S_txt), slice(S_txt, S)
+    nw = [r(128) for _ in range(4)]
+    rope = (torch.rand(S, 128, device=dev), torch.rand(S, 128, device=dev))
     shapes = []
 
     def two(A, Wt, Wi, **kw):
@@ -88,8 +90,9 @@ def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
                 Group([Seg(A[i], Wi)], **{k_: (v[1] if isinstance(v, tuple) else v) for k_, v in kw.items()})]
 
     shapes.append(("dbl_qkv", nd, 2.0 * S * 3 * D * D,
-                   lambda: ops.time_gemm(two(xn, Wq2, Wq, bias=b3, tok_offset=(0, S_txt)), 3 * D, RF_EPI_QKV,
-                                         q=q, k=k, vt=vt, heads=heads, s_pad=s_pad)))
+                   lambda: ops.time_gemm(two(xn, Wq2, Wq, bias=b3, tok_offset=(0, S_txt), norm_q=(nw[2], nw[0]),
+                                             norm_k=(nw[3], nw[1])), 3 * D, RF_EPI_QKV,
+                                         q=q, k=k, vt=vt, heads=heads, s_pad=s_pad, rope=rope)))
     shapes.append(("dbl_out", nd, 2.0 * S * D * D,
                    lambda: ops.time_gemm(two(att, Wo2, Wo, bias=b1, gate=gate, out=(x[t], x[i]), residual=(x[t], x[i])),
                                          D, RF_EPI_GATE_RES)))
@@ -99,8 +102,9 @@ def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
                    lambda: ops.time_gemm(two(hid, W2b, W2, bias=b1, gate=gate, out=(x[t], x[i]), residual=(x[t], x[i])),
                                          D, RF_EPI_GATE_RES)))
     shapes.append(("sgl_in", ns, 2.0 * S * (3 * D + mlp) * D,
-                   lambda: ops.time_gemm([Group([Seg(xn, Wf)], bias=bf_, out=hid, tok_offset=0)], 3 * D + mlp,
-                                         RF_EPI_QKV_GELU, n_split=3 * D, q=q, k=k, vt=vt, heads=heads, s_pad=s_pad)))
+                   lambda: ops.time_gemm([Group([Seg(xn, Wf)], bias=bf_, out=hid, tok_offset=0, norm_q=nw[0],
+                                                norm_k=nw[1])], 3 * D + mlp, RF_EPI_QKV_GELU, n_split=3 * D, q=q, k=k,
+                                         vt=vt, heads=heads, s_pad=s_pad, rope=rope)))
     shapes.append(("sgl_out", ns, 2.0 * S * D * (D + mlp),
                    lambda: ops.time_gemm([Group([Seg(att, Ws[:, :D]), Seg(hid, Ws[:, D:])], bias=b1, gate=gate, out=x,
                                                 residual=x)], D, RF_EPI_GATE_RES)))

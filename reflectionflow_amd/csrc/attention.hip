@@ -228,7 +228,235 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+// =================================================================================================
+// v2: 8 waves x 32 queries per workgroup (one K/V tile feeds 256 queries: half the DMA traffic per
+// flop), K in a 4-stage and V^T in a 3-stage LDS ring filled two tiles ahead under a COUNTED vmcnt
+// (the queue is never drained in the main loop), and the score MFMAs of tile t+1 are issued next to the
+// softmax VALU of tile t inside each wave, so the matrix pipe has work while a wave exponentiates.
+//   per iteration t:   wait{K(t+1), V(t)} -> barrier -> DMA{K(t+3), V(t+2)} -> S_next = K(t+1) Q^T
+//                      -> softmax(S_cur) -> O^T += V(t)^T P^T -> S_cur = S_next
+// Hazards: a ring slot is re-filled >= 1 barrier after every wave finished reading it (K slot of tile
+// t-1 is re-filled in iteration t, V slot of tile t-1 in iteration t, both after barrier B_t); a tile is
+// read only after every wave's counted vmcnt for it and a barrier.
+constexpr int ATT2_NK = 4, ATT2_NV = 3;
+constexpr int ATT2_LDS = (ATT2_NK + ATT2_NV) * 16384;
+
+#define RF_ATT_WAIT_BARRIER(allowed)                                             \
+  do {                                                                           \
+    if ((allowed) >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         \
+    else if ((allowed) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    \
+    else if ((allowed) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
+    else if ((allowed) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");    \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    __syncthreads();                                                             \
+  } while (0)
+
+// GENERIC = false: no condition bias/mask and S % 64 == 0 (every BASELINE config with union attention): the loop
+// body is ONE basic block, so the scheduler can interleave the next tile's score MFMAs with the softmax VALU.
+// GENERIC = true: per-element key masks/biases (ragged tail, attn.c_factor, union_cond_attn=False).
+template <bool GENERIC>
+__global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x % p.heads;
+  const int qb = blockIdx.x / p.heads;
+  const int S = p.S;
+  const int q_row = qb * 256 + w * 32 + l31;
+  const int q_ld = q_row < S ? q_row : S - 1;
+  const int nt = (S + ATT_KV - 1) / ATT_KV;
+  const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
+  const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
+  char* const kring = smem;
+  char* const vring = smem + ATT2_NK * 16384;
+
+  bf16x8 qf[8];
+  {
+    const bf16_t* qp = p.q + ((int64_t)head * p.s_pad + q_ld) * 128 + h * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+  // DMA pieces: 2 of the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each) per wave
+  int k_row[2], k_chunk[2], v_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + w) * 4 + (lane >> 4);
+    k_row[i] = row;
+    k_chunk[i] = ((lane & 15) ^ (row & 15)) * 8;
+    const int vrow = (i * 8 + w) * 8 + (lane >> 3);
+    v_off[i] = vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8);
+  }
+  auto issue_k = [&](int t) {
+    char* base = kring + (t % ATT2_NK) * 16384;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int kv = t * ATT_KV + k_row[i];
+      kv = kv < S ? kv : S - 1;
+      __builtin_amdgcn_global_load_lds((glb_void*)(Kh + (int64_t)kv * 128 + k_chunk[i]),
+                                       (lds_void*)(base + (i * 8 + w) * 1024), 16, 0, 0);
+    }
+  };
+  auto issue_v = [&](int t) {
+    char* base = vring + (t % ATT2_NV) * 16384;
+    const bf16_t* vt = Vh + (int64_t)t * (128 * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void*)(vt + v_off[i]), (lds_void*)(base + (i * 8 + w) * 1024), 16, 0, 0);
+  };
+
+  const float NEG_INF = -__builtin_huge_valf();
+  const bool q_is_cond = q_row >= p.n_main;
+  float badd_main = 0.f, badd_cond = 0.f;
+  if (p.mode == 1) {
+    badd_main = q_is_cond ? p.cross_bias_l2 : 0.f;
+    badd_cond = q_is_cond ? 0.f : p.cross_bias_l2;
+  } else if (p.mode == 2) {
+    badd_main = q_is_cond ? NEG_INF : 0.f;
+    badd_cond = q_is_cond ? 0.f : NEG_INF;
+  }
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int k_swz = l31 & 15;
+  const int v_swz = (l31 >> 1) & 7;
+
+  auto qk = [&](int t, f32x16 (&sacc)[2]) {
+    const char* kb = kring + (t % ATT2_NK) * 16384;
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kvb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(kb + (kvb * 32 + l31) * 256 + (((ks * 2 + h) ^ k_swz) << 4));
+        sacc[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kvb], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: queue order  K0 | K1 V0 | K2 V1 -----------------------------------------------
+  issue_k(0);
+  if (nt > 1) issue_k(1);
+  issue_v(0);
+  if (nt > 2) issue_k(2);
+  if (nt > 1) issue_v(1);
+  {
+    const int allowed = 2 * ((nt > 1) + 1 + (nt > 2) + (nt > 1));  // everything younger than K0
+    RF_ATT_WAIT_BARRIER(allowed);
+  }
+  f32x16 s_cur[2], s_nxt[2];
+  qk(0, s_cur);
+
+  for (int t = 0; t < nt; ++t) {
+    // K(t+1), V(t) must have landed; K(t+2), V(t+1) (issued last iteration) may stay in flight
+    {
+      const int allowed = 2 * ((t + 2 < nt) + (t + 1 < nt));
+      RF_ATT_WAIT_BARRIER(allowed);
+    }
+    if (t + 3 < nt) issue_k(t + 3);
+    if (t + 2 < nt) issue_v(t + 2);
+    // scores of the NEXT tile (clamped on the last iteration: that K slot is still resident, the result is
+    // unused) -- unconditional so that these MFMAs share a basic block with the softmax VALU below
+    qk(t + 1 < nt ? t + 1 : nt - 1, s_nxt);
+
+    const int kv0 = t * ATT_KV;
+    float tmax = NEG_INF;
+    if (!GENERIC) {
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = s_cur[kvb][r] * p.sl2;
+          s_cur[kvb][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    } else {
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + kvb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float badd = kv >= S ? NEG_INF : (kv >= p.n_main ? badd_cond : badd_main);
+          const float x = s_cur[kvb][r] * p.sl2 + badd;
+          s_cur[kvb][r] = x;
+          tmax = fmaxf(tmax, x);
+        }
+    }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+      tmax = fmaxf(tmax, __uint_as_float(h ? sw[0] : sw[1]));
+    }
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 t8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(s_cur[kvb][s2 * 8 + j] - m_new);
+          psum += pv;
+          t8[j] = f2bf(pv);
+        }
+        pf[kvb * 2 + s2] = t8;
+      }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    const char* vb = vring + (t % ATT2_NV) * 16384;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 vf = *(const bf16x8*)(vb + (db * 32 + l31) * 128 + (((s * 2 + h) ^ v_swz) << 4));
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s], oacc[db], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int kvb = 0; kvb < 2; ++kvb) s_cur[kvb] = s_nxt[kvb];
+  }
+
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = l_run + __uint_as_float(h ? sw[0] : sw[1]);
+  }
+  const float inv = 1.0f / l_tot;
+  if (q_row < S) {
+    bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        u32x2 v;
+        v[0] = pack2(oacc[db][rg * 4 + 0] * inv, oacc[db][rg * 4 + 1] * inv);
+        v[1] = pack2(oacc[db][rg * 4 + 2] * inv, oacc[db][rg * 4 + 3] * inv);
+        *(u32x2*)(orow + db * 32 + rg * 8) = v;
+      }
+  }
+}
+
+static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)
+
 }  // namespace rf
+
+extern "C" int rf_debug_attn_v2(int on) {  // tuning hook (-1 = cost model), not part of the drop-in surface
+  rf::g_attn_v2 = on < 0 ? -1 : (on ? 1 : 0);
+  return RF_OK;
+}
 
 extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                                 int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
@@ -254,7 +482,31 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
   p.nqb = cdiv(S, ATT_QBLK); p.ldo = ldo;
   p.cross_bias_l2 = cross_bias * 1.4426950408889634f;
   p.sl2 = scale * 1.4426950408889634f;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads * p.nqb), dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, p);
+  // v2 (256-query workgroups, 1 per CU) is ~8 % more efficient per row but has a coarser tail than v1
+  // (128-query workgroups, 2 per CU); estimate both in units of "one CU doing 256 rows x S keys"
+  bool use_v2 = g_attn_v2 == 1;
+  if (g_attn_v2 < 0) {
+    const int nb1 = heads * cdiv(S, 128), nb2 = heads * cdiv(S, 256);
+    const int rem1 = nb1 % 512;
+    const float t1 = (float)(nb1 / 512) + (rem1 == 0 ? 0.f : (rem1 <= 256 ? 0.55f : 1.f));
+    const float t2 = (float)cdiv(nb2, 256) / 1.08f;
+    use_v2 = t2 < t1;
+  }
+  if (use_v2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+      RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+      attr2 = true;
+    }
+    const dim3 grid2(heads * cdiv(S, 256));
+    if (mode == 0 && S % 64 == 0)
+      hipLaunchKernelGGL(attn_fwd_kernel_v2<false>, grid2, dim3(512), ATT2_LDS, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL(attn_fwd_kernel_v2<true>, grid2, dim3(512), ATT2_LDS, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads * p.nqb), dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, p);
+  }
   RF_LAUNCH_CHECK();
   return RF_OK;
 }

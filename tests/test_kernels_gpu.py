@@ -254,8 +254,16 @@ def sdpa_ref(qf, kf, vf, mask=None):
     return o[0].permute(1, 0, 2).reshape(qf.shape[1], -1)
 
 
+@pytest.fixture(params=[0, 1], ids=["attn_v1", "attn_v2"])
+def attn_impl(request, dev):
+    from reflectionflow_amd import _lib
+    _lib.load().rf_debug_attn_v2(request.param)
+    yield request.param
+    _lib.load().rf_debug_attn_v2(-1)
+
+
 @pytest.mark.parametrize("S", [64, 100, 128, 333, 768, 1500])
-def test_attention_plain(dev, S):
+def test_attention_plain(dev, attn_impl, S):
     from reflectionflow_amd import ops
     H = 2
     q, k, vt, qf, kf, vf = make_qkv(H, S, dev, seed=S)
@@ -263,7 +271,7 @@ def test_attention_plain(dev, S):
     assert_close(o, sdpa_ref(qf, kf, vf), f"attention S={S}", atol=4e-3)
 
 
-def test_attention_peaked_rows(dev):
+def test_attention_peaked_rows(dev, attn_impl):
     """Large logits: exercises the online-softmax rescale (running max jumps between tiles)."""
     from reflectionflow_amd import ops
     H, S = 1, 512
@@ -274,7 +282,7 @@ def test_attention_peaked_rows(dev):
 
 @pytest.mark.parametrize("S,n_main", [(192, 128), (200, 150), (333, 300), (640, 512)])
 @pytest.mark.parametrize("mode", [1, 2])
-def test_attention_cond_modes(dev, S, n_main, mode):
+def test_attention_cond_modes(dev, attn_impl, S, n_main, mode):
     """block.py:106-122: additive log(c_factor) bias / block mask between main and condition tokens."""
     from reflectionflow_amd import ops
     H = 2

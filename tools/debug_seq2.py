@@ -13,7 +13,7 @@ blocks = list(pipe.transformer.single_transformer_blocks)
 pks = [E.pack_single_block(b) for b in blocks]
 d = E.make_dims(D, H, MLP, 0, Sm, 0)
 ws = E.get_workspace(dev, d)
-wsbuf = E._WS_CACHE[(str(dev), D, H, MLP, 0, Sm, 0)]
+wsbuf = E._WS_CACHE[(str(dev), torch.cuda.current_stream(dev).cuda_stream, D, H, MLP, 0, Sm, 0)]
 def r256(n): return (n + 255) // 256 * 256
 SD, HS = Sm * D * 2, H * Sm * 128 * 2
 names = ["xn", "q", "k", "vt", "att", "hid", "lt", "x"]
