@@ -118,8 +118,20 @@ def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
         tot_t += count * sec
         n_launch += count
     ach = tot_f / tot_t / 1e12
+    # HBM/fabric bytes per launch cannot be measured from inside this process: they come from the committed
+    # rocprofv3 --pmc passes over the same six launches (tools/pmc_collect.sh -> profiles/r01_pmc_kernels.json,
+    # FETCH_SIZE doubled per the gfx950 correction), forward-weighted like `achieved`.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
+    if os.path.exists(pmc) and (S_txt, S_img, D, mlp) == (512, 4096, 3072, 12288):
+        pj = json.load(open(pmc))
+        traffic = round(pj["_summary"]["gemm_traffic_bytes_per_launch_avg"])
+        traffic_src = ("profiles/r01_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; algorithmic "
+                       f"{round(pj['_summary']['gemm_algorithmic_bytes_per_launch_avg'])} B/launch; MFMA busy "
+                       f"{pj['_summary']['gemm_mfma_busy_pct_weighted']:.1f} % of SIMD-cycles at the sustained clock)")
     return {"bound": "mfma", "kernel": "rf::gemm_bf16_kernel<256,256,4,2,true>", "achieved": round(ach, 1),
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "launches_per_forward": n_launch, "avg_launch_us": round(tot_t / n_launch * 1e6, 1),
             "flops_per_launch_avg": tot_f / n_launch, "shapes": per}
 
