@@ -378,18 +378,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     }
   };
 
-  auto stage = [&](int kt_in_seg, int buf) {
+  // piece q of a stage: q < IA -> A piece q, else W piece q - IA
+  auto stage_piece = [&](int q, int kt_in_seg, int buf) {
     char* base = smem + buf * STAGE;
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[i] + (int64_t)kt_in_seg * 64),
-                                       (lds_void*)(base + (i * NW + w) * 1024), 16, 0, 0);
+    if (q < IA) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[q] + (int64_t)kt_in_seg * 64),
+                                       (lds_void*)(base + (q * NW + w) * 1024), 16, 0, 0);
+    } else {
+      __builtin_amdgcn_global_load_lds((glb_void*)(srcB[q - IA] + (int64_t)kt_in_seg * 64),
+                                       (lds_void*)(base + A_BYTES + ((q - IA) * NW + w) * 1024), 16, 0, 0);
     }
+  };
+  auto stage = [&](int kt_in_seg, int buf) {
 #pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(srcB[i] + (int64_t)kt_in_seg * 64),
-                                       (lds_void*)(base + A_BYTES + (i * NW + w) * 1024), 16, 0, 0);
-    }
+    for (int q = 0; q < IA + IB; ++q) stage_piece(q, kt_in_seg, buf);
   };
 
   f32x16 acc[FM][FN];
@@ -431,11 +433,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     // vmcnt placement for LDS-DMA in a loop (see attention.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed for every wave; every wave is done with tile kt-1
-    if (kt + 1 < nk) {
-      stage(kk, (kt + 1) & 1);
-      advance();
-    }
+    // The next tile's 8 LDS-DMA pieces are issued two per k-step BEHIND that k-step's fragment reads rather than
+    // all at once after the barrier: the matrix pipe restarts ~300 cycles earlier per K-tile (+5-10 %, measured;
+    // the kernel is not DMA-latency bound -- profiles/r01_gemm_variants.md)
+    const bool more = kt + 1 < nk;
     const char* base = smem + (kt & 1) * STAGE;
+    constexpr int PPS = (IA + IB + 3) / 4;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int coff = ((ks * 2 + h) ^ swz) << 4;
@@ -444,12 +447,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
       for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(base + a_row_off + i * 32 * 128 + coff);
 #pragma unroll
       for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(base + b_row_off + j * 32 * 128 + coff);
+      if (more) {
+#pragma unroll
+        for (int q = ks * PPS; q < (ks + 1) * PPS && q < IA + IB; ++q) stage_piece(q, kk, (kt + 1) & 1);
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (more) advance();
   }
 
   if constexpr (VEC) {
