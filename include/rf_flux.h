@@ -89,7 +89,10 @@ typedef struct rf_gemm_desc {
    * when rope_cos != NULL, q and k rows are RMS-normalised with the group's norm_q/norm_k and rotated
    * with the fp32 tables [S][128] (indexed by joint token row) before they are stored. */
   const float* rope_cos; const float* rope_sin;
-  float norm_eps; int32_t _pad;
+  float norm_eps;
+  float q_scale;                      /* QKV: multiply the q rows by this (fp32, before the one bf16 rounding);
+                                         0 = 1.0.  The engine folds softmax_scale*log2(e) in here and tells
+                                         rf_attention_fwd via q_prescaled, saving a multiply per score. */
   rf_gemm_group g[4];
 } rf_gemm_desc;
 
@@ -117,10 +120,12 @@ int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad
  *   n_main: rows [0,n_main) are text+image tokens, [n_main,S) condition tokens.
  *   mode: 0 = plain; 1 = additive bias `cross_bias` on (main<->cond) blocks (attn.c_factor,
  *         block.py:115-122); 2 = mask (main<->cond) blocks (union_cond_attn=False, block.py:106-114)
+ *   q_prescaled: 0 = scores are scaled by `scale` here; 1 = q already carries scale*log2(e)
+ *         (rf_gemm_desc.q_scale), `scale` is ignored.
  * ---------------------------------------------------------------------------------- */
 int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                      int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
-                     float cross_bias, float scale, void* stream);
+                     float cross_bias, float scale, int32_t q_prescaled, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm(no affine, eps) + (1+scale)*x + shift, row-wise over D

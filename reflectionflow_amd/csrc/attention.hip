@@ -39,6 +39,8 @@ constexpr int ATT_K_BYTES = ATT_KV * 256;    // 16 KiB
 constexpr int ATT_V_BYTES = 128 * 128;       // 16 KiB
 constexpr int ATT_STAGE = ATT_K_BYTES + ATT_V_BYTES;
 
+// PRE: q already carries softmax_scale*log2(e) (folded in by the QKV GEMM epilogue): no multiply per score
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
       for (int kvb = 0; kvb < 2; ++kvb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float x = sacc[kvb][r] * p.sl2 + badd;
+          const float x = PRE ? sacc[kvb][r] + badd : sacc[kvb][r] * p.sl2 + badd;
           sacc[kvb][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + kvb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float badd = kv >= S ? NEG_INF : (kv >= p.n_main ? badd_cond : badd_main);
-          const float x = sacc[kvb][r] * p.sl2 + badd;
+          const float x = PRE ? sacc[kvb][r] + badd : sacc[kvb][r] * p.sl2 + badd;
           sacc[kvb][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -254,7 +256,7 @@ constexpr int ATT2_LDS = (ATT2_NK + ATT2_NV) * 16384;
 // GENERIC = false: no condition bias/mask and S % 64 == 0 (every BASELINE config with union attention): the loop
 // body is ONE basic block, so the scheduler can interleave the next tile's score MFMAs with the softmax VALU.
 // GENERIC = true: per-element key masks/biases (ragged tail, attn.c_factor, union_cond_attn=False).
-template <bool GENERIC>
+template <bool GENERIC, bool PRE>
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
       for (int kvb = 0; kvb < 2; ++kvb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float x = s_cur[kvb][r] * p.sl2;
+          const float x = PRE ? s_cur[kvb][r] : s_cur[kvb][r] * p.sl2;
           s_cur[kvb][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + kvb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float badd = kv >= S ? NEG_INF : (kv >= p.n_main ? badd_cond : badd_main);
-          const float x = s_cur[kvb][r] * p.sl2 + badd;
+          const float x = PRE ? s_cur[kvb][r] + badd : s_cur[kvb][r] * p.sl2 + badd;
           s_cur[kvb][r] = x;
           tmax = fmaxf(tmax, x);
         }
@@ -460,7 +462,7 @@ extern "C" int rf_debug_attn_v2(int on) {  // tuning hook (-1 = cost model), not
 
 extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                                 int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
-                                float cross_bias, float scale, void* stream) {
+                                float cross_bias, float scale, int32_t q_prescaled, void* stream) {
   using namespace rf;
   RF_REQUIRE(q && k && vt && out, RF_ERR_NULL, "rf_attention_fwd: NULL pointer");
   RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0, RF_ERR_SHAPE,
@@ -473,7 +475,12 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
   RF_REQUIRE(n_main >= 0 && n_main <= S, RF_ERR_SHAPE, "rf_attention_fwd: n_main=%d", n_main);
   static bool attr_set = false;
   if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
     attr_set = true;
   }
   AttnParams p;
@@ -492,20 +499,22 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
     const float t2 = (float)cdiv(nb2, 256) / 1.08f;
     use_v2 = t2 < t1;
   }
+  hipStream_t st = (hipStream_t)stream;
+  const bool pre = q_prescaled != 0;
   if (use_v2) {
-    static bool attr2 = false;
-    if (!attr2) {
-      RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
-      RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
-      attr2 = true;
+    const dim3 grid2(heads * cdiv(S, 256)), blk(512);
+    const bool generic = !(mode == 0 && S % 64 == 0);
+    if (generic) {
+      if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<true, true>), grid2, blk, ATT2_LDS, st, p);
+      else hipLaunchKernelGGL((attn_fwd_kernel_v2<true, false>), grid2, blk, ATT2_LDS, st, p);
+    } else {
+      if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<false, true>), grid2, blk, ATT2_LDS, st, p);
+      else hipLaunchKernelGGL((attn_fwd_kernel_v2<false, false>), grid2, blk, ATT2_LDS, st, p);
     }
-    const dim3 grid2(heads * cdiv(S, 256));
-    if (mode == 0 && S % 64 == 0)
-      hipLaunchKernelGGL(attn_fwd_kernel_v2<false>, grid2, dim3(512), ATT2_LDS, (hipStream_t)stream, p);
-    else
-      hipLaunchKernelGGL(attn_fwd_kernel_v2<true>, grid2, dim3(512), ATT2_LDS, (hipStream_t)stream, p);
   } else {
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads * p.nqb), dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, p);
+    const dim3 grid1(heads * p.nqb), blk(256);
+    if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid1, blk, 2 * ATT_STAGE, st, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid1, blk, 2 * ATT_STAGE, st, p);
   }
   RF_LAUNCH_CHECK();
   return RF_OK;

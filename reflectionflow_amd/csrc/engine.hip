@@ -67,6 +67,9 @@ static void set_seg(rf_kseg& s, const void* A, int64_t lda, const void* W, int64
   s.A = A; s.lda = lda; s.W = W; s.ldw = ldw; s.K = K; s._pad = 0;
 }
 
+// softmax scale 1/sqrt(128) times log2(e): the QKV epilogue folds it into q, attention then works in the exp2 domain
+static constexpr float QK_PRESCALE = 0.08838834764831845f * 1.4426950408889634f;
+
 #define RF_TRY(expr)            \
   do {                          \
     int _rc = (expr);           \
@@ -133,6 +136,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
     memset(&d, 0, sizeof(d));
     d.N = 3 * D; d.epilogue = RF_EPI_QKV; d.num_groups = 3; d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
     d.rope_cos = cos_tab; d.rope_sin = sin_tab; d.norm_eps = 1e-6f;   // per-head RMSNorm + RoPE fused into the epilogue
+    d.q_scale = QK_PRESCALE;                                          // ... and the softmax scale folded into q
     for (int i = 0; i < 3; ++i) {
       const Stream& s = sx[i];
       rf_gemm_group& g = d.g[i];
@@ -154,7 +158,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
   // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE: fused into the QKV epilogue above
   // 4. joint attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, St + Si, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
-                          0.08838834764831845f /* 1/sqrt(128) */, st));
+                          0.08838834764831845f /* 1/sqrt(128) */, /*q_prescaled=*/1, st));
   // 5. output projections + gated residual: x += gate_msa * proj(attn)
   {
     rf_gemm_desc d;
@@ -270,6 +274,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
     d.N = 3 * D + MLP; d.epilogue = RF_EPI_QKV_GELU; d.n_split = 3 * D; d.num_groups = 2;
     d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
     d.rope_cos = cos_tab; d.rope_sin = sin_tab; d.norm_eps = 1e-6f;
+    d.q_scale = QK_PRESCALE;
     for (int i = 0; i < 2; ++i) {
       const Stream& s = sx[i];
       rf_gemm_group& g = d.g[i];
@@ -290,7 +295,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
   // 3. RMSNorm(q,k) + RoPE: fused into the epilogue above (no added-norm rows in single blocks)
   // 4. attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, Sm, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
-                          0.08838834764831845f, st));
+                          0.08838834764831845f, /*q_prescaled=*/1, st));
   // 5. proj_out over cat([attn, mlp]) as two K segments + gated residual
   {
     rf_gemm_desc d;

@@ -44,7 +44,7 @@ struct GemmParams {
   int N, epi, ngroups, n_split, heads, s_pad, tiles_n, total_tiles;
   int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
   bf16_t* q; bf16_t* k; bf16_t* vt;
-  const float* rope_cos; const float* rope_sin; float norm_eps;
+  const float* rope_cos; const float* rope_sin; float norm_eps; float q_scale;
   GemmGroupDev g[4];
 };
 
@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGro
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            if (m < M) dst[(int64_t)(G.tok_offset + m) * 128] = f2bf(acc[i][j][r] + bias_v);
+            if (m < M) dst[(int64_t)(G.tok_offset + m) * 128] = f2bf((acc[i][j][r] + bias_v) * (which == 0 ? p.q_scale : 1.0f));
           }
         } else {
           // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped
@@ -301,6 +301,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
                 v[e] = a * cs[e] - b * sn[e];
                 v[e + 1] = b * cs[e + 1] + a * sn[e + 1];
               }
+            }
+            if (which == 0) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= p.q_scale;   // softmax scale * log2(e) folded into q (fp32, pre-rounding)
             }
             dst = (which == 0 ? p.q : p.k) + ((int64_t)head * p.s_pad + G.tok_offset + m) * 128 + q8;
           } else {
@@ -507,6 +511,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
   p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin; p.norm_eps = d->norm_eps;
+  p.q_scale = d->q_scale == 0.f ? 1.0f : d->q_scale;
   const bool qkv = d->epilogue == RF_EPI_QKV || d->epilogue == RF_EPI_QKV_GELU;
   if (qkv) {
     RF_REQUIRE(d->q && d->k && d->vt, RF_ERR_NULL, "rf_gemm_bf16: QKV epilogue needs q,k,vt");

@@ -113,8 +113,9 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
         if has_cond:
             groups.append(proj_group(condition_latents[b], St + Si, True))
         # QKV projections with per-head RMSNorm + RoPE fused into the epilogue
-        ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin))
-        outs.append(ops.attention(q, k, vt, S, n_main=St + Si, mode=mode, cross_bias=bias))
+        ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin),
+                 q_scale=ops.QK_PRESCALE)
+        outs.append(ops.attention(q, k, vt, S, n_main=St + Si, mode=mode, cross_bias=bias, q_prescaled=True))
     hs = torch.stack(outs, 0)                                           # [B, S, D]
 
     if has_txt:

@@ -16,7 +16,7 @@ from . import _lib as L
 from ._lib import (RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, RF_EPI_STORE, RFError)
 
 __all__ = ["linear", "gemm", "build_gemm_desc", "time_gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
-           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError"]
+           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError", "QK_PRESCALE"]
 
 
 def stream_ptr() -> int:
@@ -64,13 +64,14 @@ class Group:
 
 
 def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
-                    q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0, rope=None, norm_eps: float = 1e-6
-                    ) -> "L.rf_gemm_desc":
+                    q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0, rope=None, norm_eps: float = 1e-6,
+                    q_scale: float = 0.0) -> "L.rf_gemm_desc":
     """rope=(cos, sin) fp32 [S,128]: fuse per-head RMSNorm (each group's norm_q/norm_k) + RoPE into the
     QKV epilogue."""
     d = L.rf_gemm_desc()
     d.N, d.epilogue, d.num_groups, d.n_split = N, epilogue, len(groups), n_split
     d.q, d.k, d.vt, d.heads, d.s_pad = ptr(q), ptr(k), ptr(vt), heads, s_pad
+    d.q_scale = q_scale
     if rope is not None:
         cos, sin = rope
         _chk(cos, "cos", torch.float32), _chk(sin, "sin", torch.float32)
@@ -148,8 +149,11 @@ def qk_rmsnorm_rope(q, k, S: int, n_added: int, w_q, w_k, w_added_q, w_added_k, 
                                    stream_ptr()), "rf_qk_rmsnorm_rope")
 
 
+QK_PRESCALE = (1.0 / math.sqrt(128.0)) * 1.4426950408889634   # softmax scale * log2(e), folded into q by the QKV GEMM
+
+
 def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
-              cross_bias: float = 0.0, scale: Optional[float] = None) -> torch.Tensor:
+              cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False) -> torch.Tensor:
     lib = L.load()
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     heads, s_pad = q.shape[0], q.shape[1]
@@ -160,7 +164,7 @@ def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Opti
         scale = 1.0 / math.sqrt(128.0)
     L.check(lib.rf_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), heads, S, s_pad,
                                  out.stride(0), S if n_main is None else n_main, mode, cross_bias, scale,
-                                 stream_ptr()), "rf_attention_fwd")
+                                 1 if q_prescaled else 0, stream_ptr()), "rf_attention_fwd")
     return out
 
 

@@ -355,3 +355,17 @@ def test_gemm_qkv_fused_norm_rope(dev, tile, St, Si, Sc):
         assert_close(vt_unpermute(vt, S), ref[:, 2 * D:].reshape(S, H, 128).permute(1, 0, 2), "v^T (untouched by rope)")
     finally:
         _lib.load().rf_debug_force_gemm_tile(0)
+
+
+def test_attention_prescaled_q_matches_scaled_path(dev, attn_impl):
+    """q carrying softmax_scale*log2(e) (as the engine's QKV epilogue writes it) + q_prescaled=1 gives the same
+    attention as unscaled q with the scale applied inside the kernel (up to q's bf16 rounding)."""
+    from reflectionflow_amd import ops
+    H, S = 2, 640
+    q, k, vt, qf, kf, vf = make_qkv(H, S, dev, seed=77)
+    o_ref = ops.attention(q, k, vt, S)
+    q2 = q.clone()
+    q2[:, :S] = (qf.float() * ops.QK_PRESCALE).to(BF)
+    o_pre = ops.attention(q2, k, vt, S, q_prescaled=True)
+    assert_close(o_pre, sdpa_ref(qf, kf, vf), "attention with prescaled q", atol=6e-3)
+    assert_close(o_pre, o_ref.float(), "prescaled vs in-kernel scale", atol=6e-3)
