@@ -93,6 +93,11 @@ typedef struct rf_gemm_desc {
   float q_scale;                      /* QKV: multiply the q rows by this (fp32, before the one bf16 rounding);
                                          0 = 1.0.  The engine folds softmax_scale*log2(e) in here and tells
                                          rf_attention_fwd via q_prescaled, saving a multiply per score. */
+  /* optional deterministic split-K scratch (caller-owned fp32, 16-byte aligned).  When set, a STORE GEMM with
+   * one group, <= 64 output tiles and a long K (the LoRA down-projections x.lora_A^T: 8 tiles x up to 240
+   * K-tiles) is sliced over K across the grid; partial tiles are summed in slice order by a second kernel.
+   * NULL = never split. */
+  void* splitk_ws; int64_t splitk_ws_bytes;
   rf_gemm_group g[4];
 } rf_gemm_desc;
 

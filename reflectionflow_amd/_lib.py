@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 
@@ -35,7 +35,7 @@ class rf_gemm_desc(C.Structure):
     _fields_ = [("N", C.c_int32), ("epilogue", C.c_int32), ("num_groups", C.c_int32), ("n_split", C.c_int32),
                 ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("heads", C.c_int32), ("s_pad", C.c_int32),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("norm_eps", C.c_float), ("q_scale", C.c_float),
-                ("g", rf_gemm_group * 4)]
+                ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("g", rf_gemm_group * 4)]
 
 
 class rf_lora_seg(C.Structure):

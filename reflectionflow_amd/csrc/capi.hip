@@ -22,5 +22,5 @@ int hip_fail(hipError_t e, const char* what) {
 }  // namespace rf
 
 extern "C" const char* rf_last_error(void) { return rf::g_err; }
-extern "C" int rf_abi_version(void) { return 4; }
+extern "C" int rf_abi_version(void) { return 5; }
 extern "C" int rf_target_arch(void) { return 950; }

@@ -42,6 +42,7 @@ int hip_fail(hipError_t e, const char* what);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // ---- bf16 <-> f32 (round-to-nearest-even, the same rounding torch uses) ---------------

@@ -10,6 +10,7 @@
 //   ATT [S][D]        attention output, token-major
 //   HID [S][mlp]      FF hidden / single-block MLP branch
 //   LT  [S][256]      LoRA low-rank intermediates (x . lora_A^T)
+//   SK  fp32          split-K partial tiles of the LoRA down-projections (<= 32 MiB)
 //   X   [S][D]        residual stream (rf_flux_forward only; rows = txt | img | cond)
 //
 // Token order everywhere is [text | image | condition] -- the order the reference concatenates
@@ -20,7 +21,7 @@ namespace rf {
 
 struct WsLayout {
   int S, s_pad;
-  int64_t xn, q, k, vt, att, hid, lt, x, total;  // byte offsets
+  int64_t xn, q, k, vt, att, hid, lt, x, sk, sk_bytes, total;  // byte offsets
 };
 
 static WsLayout ws_layout(const rf_flux_dims& d) {
@@ -43,6 +44,10 @@ static WsLayout ws_layout(const rf_flux_dims& d) {
   L.hid = take((int64_t)L.S * d.mlp);
   L.lt = take((int64_t)L.S * 256);
   L.x = take(SD);
+  // split-K scratch: up to 32 K-slices of a [rows x 256] fp32 partial, capped at 32 MiB
+  const int64_t lora_rows = d.S_cond + (d.lora_on_main ? d.S_img + d.S_txt : 0);
+  L.sk_bytes = lora_rows > 0 ? std::min<int64_t>(32ll << 20, round_up(lora_rows, 128) * 256 * 4 * 32) : 0;
+  L.sk = take(L.sk_bytes / 2);
   L.total = off;
   return L;
 }
@@ -78,10 +83,11 @@ static constexpr float QK_PRESCALE = 0.08838834764831845f * 1.4426950408889634f;
 
 // LoRA intermediate T = A_act . lora_A^T  ([M x r_pad]); two activation segments for proj_out.
 static int lora_down(const rf_lora_seg& l, const bf16_t* a0, int64_t lda0, int K0, const bf16_t* a1, int64_t lda1,
-                     int K1, int M, bf16_t* T, hipStream_t st) {
+                     int K1, int M, bf16_t* T, const rf_workspace* ws, const WsLayout& L, hipStream_t st) {
   rf_gemm_desc d;
   memset(&d, 0, sizeof(d));
   d.N = l.r_pad; d.epilogue = RF_EPI_STORE; d.num_groups = 1;
+  if (L.sk_bytes > 0) { d.splitk_ws = (char*)ws->base + L.sk; d.splitk_ws_bytes = L.sk_bytes; }
   rf_gemm_group& g = d.g[0];
   const int64_t ldA = (int64_t)K0 + K1;  // lora_A rows span the concatenated input
   set_seg(g.seg[0], a0, lda0, l.A, ldA, K0);
@@ -149,7 +155,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
       g.bias = txt ? w->b_add_qkv : w->b_qkv;
       if (!txt && s.lora && w->lora_qkv.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
-        RF_TRY(lora_down(w->lora_qkv, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, st));
+        RF_TRY(lora_down(w->lora_qkv, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_qkv.B, w->lora_qkv.r_pad, w->lora_qkv.r_pad);
       }
     }
@@ -180,7 +186,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
       }
       if (!txt && s.lora && w->lora_out.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
-        RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, st));
+        RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
       }
     }
@@ -235,7 +241,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
       g.out = s.x; g.ldo = ldx; g.residual = s.x; g.ldr = ldx;
       if (!txt && s.lora && w->lora_ff2.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
-        RF_TRY(lora_down(w->lora_ff2, HID + (int64_t)s.off * MLP, MLP, MLP, nullptr, 0, 0, s.rows, T, st));
+        RF_TRY(lora_down(w->lora_ff2, HID + (int64_t)s.off * MLP, MLP, MLP, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_ff2.B, w->lora_ff2.r_pad, w->lora_ff2.r_pad);
       }
     }
@@ -286,7 +292,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
       g.out = HID + (int64_t)s.off * MLP; g.ldo = MLP;
       if (s.lora && w->lora_qkv_mlp.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
-        RF_TRY(lora_down(w->lora_qkv_mlp, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, st));
+        RF_TRY(lora_down(w->lora_qkv_mlp, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_qkv_mlp.B, w->lora_qkv_mlp.r_pad, w->lora_qkv_mlp.r_pad);
       }
     }
@@ -314,7 +320,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
       g.out = s.x; g.ldo = ldx; g.residual = s.x; g.ldr = ldx;
       if (s.lora && w->lora_out.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
-        RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, HID + (int64_t)s.off * MLP, MLP, MLP, s.rows, T, st));
+        RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, HID + (int64_t)s.off * MLP, MLP, MLP, s.rows, T, ws, L, st));
         set_seg(g.seg[2], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
       }
     }
@@ -371,7 +377,7 @@ extern "C" int rf_flux_forward(const rf_flux_dims* dims, const rf_flux_model* m,
       g.bias = m->b_x_embed; g.out = dst[i]; g.ldo = D;
       if (lora[i] && m->lora_x_embed.B) {
         bf16_t* T = LT + (int64_t)(i == 0 ? St : St + Si) * 256;
-        RF_TRY(lora_down(m->lora_x_embed, (const bf16_t*)src[i], m->in_ch, m->in_ch, nullptr, 0, 0, rows[i], T, st));
+        RF_TRY(lora_down(m->lora_x_embed, (const bf16_t*)src[i], m->in_ch, m->in_ch, nullptr, 0, 0, rows[i], T, ws, L, st));
         set_seg(g.seg[1], T, 256, m->lora_x_embed.B, m->lora_x_embed.r_pad, m->lora_x_embed.r_pad);
       }
     }

@@ -45,8 +45,13 @@ struct GemmParams {
   int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
   bf16_t* q; bf16_t* k; bf16_t* vt;
   const float* rope_cos; const float* rope_sin; float norm_eps; float q_scale;
+  // deterministic split-K (few-tile GEMMs, e.g. the LoRA down-projections): blockIdx.y = K-slice of kchunk
+  // K-tiles, fp32 partial tiles go to ws[slice][m][n_pad], splitk_reduce_kernel sums them in slice order
+  int ksplit, kchunk; float* ws; int64_t ws_slice; int ws_ld;
   GemmGroupDev g[4];
 };
+
+constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -174,6 +179,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
       epi = RF_EPI_QKV;
     }
   }
+  if (p.ksplit > 1) epi = EPI_PARTIAL;
   const int ncol0 = n0 + wcol0;  // first column of this wave's 128-column strip
   if (ncol0 >= N) return;
   int which = 0, head = 0;
@@ -226,7 +232,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
   float bias8[8], gate8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f, gate8[e] = 0.f;
-  if (nok && G.bias != nullptr) unpack8(*(const u32x4*)(G.bias + n), bias8);
+  if (nok && G.bias != nullptr && epi != EPI_PARTIAL) unpack8(*(const u32x4*)(G.bias + n), bias8);
   if (nok && epi == RF_EPI_GATE_RES) unpack8(*(const u32x4*)(G.gate + n), gate8);
   const int rsub = lane >> 4;            // row within a 4-row read group
   const int c0 = (lane & 15) * 2;        // first of this lane's two 16-byte chunks
@@ -266,6 +272,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
         const int m = mbase + row;
         const f32x4 lo = *(const f32x4*)(region + row * EPI_ROW + c0 * 16);
         const f32x4 hi = *(const f32x4*)(region + row * EPI_ROW + c0 * 16 + 16);
+        if (epi == EPI_PARTIAL) {
+          if (m < M && nok) {
+            float* dstp = p.ws + (int64_t)blockIdx.y * p.ws_slice + (int64_t)m * p.ws_ld + n;
+            *(f32x4*)dstp = lo;
+            *(f32x4*)(dstp + 4) = hi;
+          }
+          continue;
+        }
         if (m < M && nok) {
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
@@ -411,11 +425,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   const int a_row_off = (wm * TM + l31) * 128;
   const int b_row_off = A_BYTES + (wn * TN + l31) * 128;
 
-  // K loop over the concatenation of this group's segments; (seg, kk) is the NEXT tile to stage
-  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  int seg = 0, kk = 0, cur_nk = G.seg[0].nk;
+  // K loop over the concatenation of this group's segments; (seg, kk) is the NEXT tile to stage.
+  // With split-K this block covers K-tiles [kt_begin, kt_begin + nk) of that concatenation.
+  const int nk_all = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  const int kt_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;
+  const int nk = p.ksplit > 1 ? ((nk_all - kt_begin) < p.kchunk ? (nk_all - kt_begin) : p.kchunk) : nk_all;
+  int seg = 0, kk = kt_begin, cur_nk = G.seg[0].nk;
+  while (kk >= cur_nk && seg < 2) {  // position at the slice's first tile (host compacts segments)
+    kk -= cur_nk;
+    ++seg;
+    cur_nk = G.seg[seg].nk;
+  }
   auto advance = [&]() {  // move (seg,kk) to the next tile; re-point the DMA sources at a boundary.
-    ++kk;                 // (host side compacts segments, so a used segment is never followed by an empty one)
+    ++kk;                 // (a used segment is never followed by an empty one)
     if (kk >= cur_nk) {
       kk = 0;
       ++seg;
@@ -428,8 +450,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
       }
     }
   };
-  setup_ptrs(G.seg[0].A, G.seg[0].lda, G.seg[0].W, G.seg[0].ldw);  // segment 0 is never empty
-  stage(0, 0);
+  if (seg == 0) setup_ptrs(G.seg[0].A, G.seg[0].lda, G.seg[0].W, G.seg[0].ldw);  // segment 0 is never empty
+  else if (seg == 1) setup_ptrs(G.seg[1].A, G.seg[1].lda, G.seg[1].W, G.seg[1].ldw);
+  else setup_ptrs(G.seg[2].A, G.seg[2].lda, G.seg[2].W, G.seg[2].ldw);
+  stage(kk, 0);
   advance();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -493,9 +517,34 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   }
   p.total_tiles = start;
   if (start == 0) return RF_OK;
-  hipLaunchKernelGGL(kern, dim3(start), dim3(WM * WN * 64), LDS, stream, p);
+  hipLaunchKernelGGL(kern, dim3(start, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * WN * 64), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
+}
+
+// out[m][n] = bf16( sum_s ws[s][m][n] + bias[n] ), slices summed in index order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int64_t slice, int ws_ld, int ksplit,
+                                                            const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                            int64_t ldo, int M, int N) {
+  const int n8 = N >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * n8) return;
+  const int m = (int)(idx / n8), n = (int)(idx % n8) * 8;
+  const float* src = ws + (int64_t)m * ws_ld + n;
+  f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+  for (int s2 = 1; s2 < ksplit; ++s2) {
+    src += slice;
+    lo += *(const f32x4*)src;
+    hi += *(const f32x4*)(src + 4);
+  }
+  float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  if (bias != nullptr) {
+    float b8[8];
+    unpack8(*(const u32x4*)(bias + n), b8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += b8[e];
+  }
+  *(u32x4*)(out + (int64_t)m * ldo + n) = pack8(v);
 }
 
 static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 = forced (used by tests and the tuner)
@@ -560,6 +609,12 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
           (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
   }
   p.vec_ok = vec ? 1 : 0;
+  p.ksplit = 1;
+  if (d->splitk_ws != nullptr) {
+    RF_REQUIRE(aligned16(d->splitk_ws) && d->splitk_ws_bytes >= 0, RF_ERR_ALIGN, "rf_gemm_bf16: splitk_ws must be 16-byte aligned");
+    p.ws = (float*)d->splitk_ws;
+    p.ws_slice = d->splitk_ws_bytes;  // bytes for now; dispatch() turns it into the slice stride
+  }
   if (d->rope_cos != nullptr) {
     RF_REQUIRE(qkv && d->rope_sin != nullptr && aligned16(d->rope_cos) && aligned16(d->rope_sin), RF_ERR_ALIGN,
                "rf_gemm_bf16: rope tables need a QKV epilogue and 16-byte alignment");
@@ -577,6 +632,32 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
     // 256^2 tiles only pay when they still fill the 256 CUs; small problems get 128^2.
     const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
     tile = (t256 >= 200) ? 256 : 128;
+  }
+  // split-K: a plain-store, single-group GEMM with a handful of tiles and a long K (LoRA down-projection:
+  // [S_cond x K] . [r_pad x K]^T = 8 tiles x up to 240 K-tiles) would run on 8 of 256 CUs.  Slice K over
+  // blockIdx.y, >= 4 K-tiles per slice, ~256 blocks in flight, fp32 partials in caller-owned scratch.
+  const int64_t ws_bytes = p.ws != nullptr ? p.ws_slice : 0;
+  p.ksplit = 1; p.ws_slice = 0;
+  if (ws_bytes > 0 && tile == 128 && p.ngroups == 1 && p.epi == RF_EPI_STORE && p.vec_ok) {
+    const GemmGroupDev& G = p.g[0];
+    const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+    const int tm = cdiv(G.M, 128), tn = cdiv(p.N, 128), tiles = tm * tn;
+    const int64_t slice = (int64_t)G.M * tn * 128;  // floats
+    int ks = nk / 4 < cdiv(256, tiles) ? nk / 4 : cdiv(256, tiles);
+    if (slice * 4 * ks > ws_bytes) ks = (int)(ws_bytes / (slice * 4));
+    if (tiles <= 64 && ks >= 2) {
+      p.kchunk = cdiv(nk, ks);
+      p.ksplit = cdiv(nk, p.kchunk);
+      p.ws_slice = slice;
+      p.ws_ld = tn * 128;
+      int rc = launch_gemm<128, 128, 4, 1, true>(p, stream);
+      if (rc != RF_OK) return rc;
+      const int64_t items = (int64_t)G.M * (p.N >> 3);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, stream, p.ws, slice, p.ws_ld,
+                         p.ksplit, G.bias, G.out, G.ldo, G.M, p.N);
+      RF_LAUNCH_CHECK();
+      return RF_OK;
+    }
   }
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
   if (tile == 256) return p.vec_ok ? launch_gemm<256, 256, 4, 2, true>(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);

@@ -159,7 +159,8 @@ _WS_CACHE: Dict[tuple, torch.Tensor] = {}
 def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
     """Caller-owned scratch for one (D, heads, mlp, S_txt, S_img, S_cond) geometry, allocated once per
     stream (calls on different streams may overlap on the device, so they must not share scratch)."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, d.D, d.heads, d.mlp, d.S_txt, d.S_img, d.S_cond)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, d.D, d.heads, d.mlp, d.S_txt, d.S_img, d.S_cond,
+           d.lora_on_main)
     buf = _WS_CACHE.get(key)
     if buf is None:
         n = int(L.load().rf_workspace_bytes(C.byref(d)))

@@ -106,7 +106,7 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
         def proj_group(x, off, use_lora):
             segs = [ops.Seg(x, w_qkv)]
             if use_lora and lora is not None:
-                segs.append(ops.Seg(ops.linear(x, lora[0]), lora[1]))
+                segs.append(ops.Seg(ops.lora_down(x, lora[0]), lora[1]))
             return ops.Group(segs, bias=b_qkv, tok_offset=off, norm_q=attn.norm_q.weight, norm_k=attn.norm_k.weight)
 
         groups.append(proj_group(hidden_states[b], St, latent_lora))
@@ -124,7 +124,7 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
             base = E._base(lin)
             fl = E._fused_lora([lin]) if use_lora else None
             for b in range(B):
-                extra = [ops.Seg(ops.linear(x[b], fl[0]), fl[1])] if fl is not None else []
+                extra = [ops.Seg(ops.lora_down(x[b], fl[0]), fl[1])] if fl is not None else []
                 ops.linear(x[b], base.weight, base.bias, extra=extra, out=y[b])
             return y
 

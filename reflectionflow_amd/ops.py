@@ -65,13 +65,16 @@ class Group:
 
 def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
                     q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0, rope=None, norm_eps: float = 1e-6,
-                    q_scale: float = 0.0) -> "L.rf_gemm_desc":
+                    q_scale: float = 0.0, splitk_ws: Optional[torch.Tensor] = None) -> "L.rf_gemm_desc":
     """rope=(cos, sin) fp32 [S,128]: fuse per-head RMSNorm (each group's norm_q/norm_k) + RoPE into the
     QKV epilogue."""
     d = L.rf_gemm_desc()
     d.N, d.epilogue, d.num_groups, d.n_split = N, epilogue, len(groups), n_split
     d.q, d.k, d.vt, d.heads, d.s_pad = ptr(q), ptr(k), ptr(vt), heads, s_pad
     d.q_scale = q_scale
+    if splitk_ws is not None:
+        _chk(splitk_ws, "splitk_ws", torch.float32)
+        d.splitk_ws, d.splitk_ws_bytes = ptr(splitk_ws), splitk_ws.numel() * 4
     if rope is not None:
         cos, sin = rope
         _chk(cos, "cos", torch.float32), _chk(sin, "sin", torch.float32)
@@ -119,14 +122,34 @@ def time_gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, ite
 
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = RF_EPI_STORE,
            residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None,
-           extra: Sequence[Seg] = (), out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = epi(x @ W^T (+ extra segments) + bias), x [M,K] bf16, W [N,K] bf16."""
+           extra: Sequence[Seg] = (), out: Optional[torch.Tensor] = None,
+           splitk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epi(x @ W^T (+ extra segments) + bias), x [M,K] bf16, W [N,K] bf16.
+    splitk_ws: optional fp32 scratch; lets few-tile / long-K STORE GEMMs (LoRA down) split K over the grid."""
     x = _rows2d(x, "x")
     N = W.shape[0]
     if out is None:
         out = torch.empty(x.shape[0], N, dtype=torch.bfloat16, device=x.device)
-    gemm([Group([Seg(x, W), *extra], bias=bias, out=out, residual=residual, gate=gate)], N, epilogue)
+    gemm([Group([Seg(x, W), *extra], bias=bias, out=out, residual=residual, gate=gate)], N, epilogue,
+         splitk_ws=splitk_ws)
     return out
+
+
+_SPLITK = {}
+
+
+def splitk_scratch(device) -> torch.Tensor:
+    """Per-(device, stream) 32 MiB fp32 scratch for the split-K LoRA down-projections of the per-block API
+    (the whole-forward engine carves its own out of the workspace)."""
+    key = (torch.device(device).index, stream_ptr())
+    if key not in _SPLITK:
+        _SPLITK[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+    return _SPLITK[key]
+
+
+def lora_down(x: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
+    """T = x . lora_A^T  ([M, r_pad]); few output tiles and a long K, so it runs split-K."""
+    return linear(x, A, splitk_ws=splitk_scratch(x.device))
 
 
 def alloc_attn_operands(heads: int, S: int, device) -> tuple:

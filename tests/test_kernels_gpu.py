@@ -369,3 +369,31 @@ def test_attention_prescaled_q_matches_scaled_path(dev, attn_impl):
     o_pre = ops.attention(q2, k, vt, S, q_prescaled=True)
     assert_close(o_pre, sdpa_ref(qf, kf, vf), "attention with prescaled q", atol=6e-3)
     assert_close(o_pre, o_ref.float(), "prescaled vs in-kernel scale", atol=6e-3)
+
+
+# ------------------------------------------------------------------------------------- split-K (LoRA down)
+@pytest.mark.parametrize("M,N,K,K2,ws_mib", [(1024, 128, 3072, 0, 32), (1024, 128, 3072, 12288, 32), (1000, 64, 2048, 0, 32),
+                                             (517, 256, 1024, 512, 32), (1024, 128, 12288, 0, 2), (4608, 128, 3072, 0, 32)])
+def test_gemm_splitk_lora_down(dev, M, N, K, K2, ws_mib):
+    """Few-tile / long-K STORE GEMM (x . lora_A^T, one or two activation segments as in the single-block
+    proj_out) sliced over K: same result as the unsplit launch up to one bf16 rounding of the fp32 sum, and
+    bit-identical from run to run (slices are summed in index order)."""
+    from reflectionflow_amd import ops
+    x, A, b = rnd(M, K, dev=dev), rnd(N, K + K2, dev=dev, scale=0.05), rnd(N, dev=dev)
+    segs = [ops.Seg(x, A[:, :K])]
+    ref = x.float() @ A[:, :K].float().t() + b.float()
+    if K2:
+        x2 = rnd(M, K2, dev=dev, seed=7)
+        segs.append(ops.Seg(x2, A[:, K:]))
+        ref = ref + x2.float() @ A[:, K:].float().t()
+    ws = torch.empty(ws_mib << 18, dtype=torch.float32, device=dev)
+    outs = []
+    for scratch in (ws, ws, None):
+        ws.fill_(float("nan"))  # partial tiles must be fully overwritten before they are summed
+        y = torch.full((M, 256), 7.0, dtype=BF, device=dev)  # ldo > N as in the engine's LT buffer
+        ops.gemm([ops.Group(segs, bias=b, out=y[:, :N])], N, ops.RF_EPI_STORE, splitk_ws=scratch)
+        outs.append(y)
+    assert_close(outs[0][:, :N], ref, "split-K vs fp32")
+    assert torch.equal(outs[0], outs[1]), "split-K is not deterministic"
+    assert (outs[0][:, N:] == 7.0).all(), "split-K reduce wrote outside its N columns"
+    assert_close(outs[0][:, :N], outs[2][:, :N].float(), "split-K vs unsplit", rtol=8e-3)
