@@ -93,10 +93,15 @@ typedef struct rf_gemm_desc {
   float q_scale;                      /* QKV: multiply the q rows by this (fp32, before the one bf16 rounding);
                                          0 = 1.0.  The engine folds softmax_scale*log2(e) in here and tells
                                          rf_attention_fwd via q_prescaled, saving a multiply per score. */
-  /* optional deterministic split-K scratch (caller-owned fp32, 16-byte aligned).  When set, a STORE GEMM with
-   * one group, <= 64 output tiles and a long K (the LoRA down-projections x.lora_A^T: 8 tiles x up to 240
-   * K-tiles) is sliced over K across the grid; partial tiles are summed in slice order by a second kernel.
-   * NULL = never split. */
+  /* optional GEMM scratch (caller-owned, 16-byte aligned; one per stream).  Layout: [0, 4096) flags, then fp32
+   * partial tiles.  The first 4 KiB must be ZERO before the first launch that uses the buffer; every launch
+   * leaves them zero again.  With it the library may
+   *   - stream-K the 256x256-tile kernel: the launch's K-tile iterations are cut into one equal contiguous range
+   *     per CU, so e.g. 216 or 264 tiles on 256 CUs cost 0.84 / 1.03 tile-times instead of 1 / 2.  Needs
+   *     4096 + num_CUs * 256 KiB (64 MiB + 4 KiB on MI355X); smaller buffers simply disable it;
+   *   - split-K a STORE GEMM with one group, <= 64 output tiles and a long K (the LoRA down-projections
+   *     x.lora_A^T: 8 tiles x up to 240 K-tiles) over the grid, reduced by a second kernel.
+   * Both sum partials in a fixed order: results are bit-reproducible run to run.  NULL = neither. */
   void* splitk_ws; int64_t splitk_ws_bytes;
   rf_gemm_group g[4];
 } rf_gemm_desc;

@@ -10,7 +10,7 @@
 //   ATT [S][D]        attention output, token-major
 //   HID [S][mlp]      FF hidden / single-block MLP branch
 //   LT  [S][256]      LoRA low-rank intermediates (x . lora_A^T)
-//   SK  fp32          split-K partial tiles of the LoRA down-projections (<= 32 MiB)
+//   SK  fp32          GEMM scratch: stream-K flags + per-CU partial tiles, LoRA split-K partials (64 MiB)
 //   X   [S][D]        residual stream (rf_flux_forward only; rows = txt | img | cond)
 //
 // Token order everywhere is [text | image | condition] -- the order the reference concatenates
@@ -44,9 +44,9 @@ static WsLayout ws_layout(const rf_flux_dims& d) {
   L.hid = take((int64_t)L.S * d.mlp);
   L.lt = take((int64_t)L.S * 256);
   L.x = take(SD);
-  // split-K scratch: up to 32 K-slices of a [rows x 256] fp32 partial, capped at 32 MiB
-  const int64_t lora_rows = d.S_cond + (d.lora_on_main ? d.S_img + d.S_txt : 0);
-  L.sk_bytes = lora_rows > 0 ? std::min<int64_t>(32ll << 20, round_up(lora_rows, 128) * 256 * 4 * 32) : 0;
+  // GEMM scratch: 4 KiB of stream-K flags (must be zero before the first launch; every launch restores them),
+  // then fp32 partial tiles: one 256x256 slot per CU for stream-K (64 MiB at 256 CUs), reused by the LoRA split-K
+  L.sk_bytes = 4096 + (64ll << 20);
   L.sk = take(L.sk_bytes / 2);
   L.total = off;
   return L;
@@ -81,13 +81,19 @@ static constexpr float QK_PRESCALE = 0.08838834764831845f * 1.4426950408889634f;
     if (_rc != RF_OK) return _rc; \
   } while (0)
 
+// split-K / stream-K scratch of the GEMMs (flags + fp32 partial tiles)
+static inline void attach_scratch(rf_gemm_desc& d, const rf_workspace* ws, const WsLayout& L) {
+  d.splitk_ws = (char*)ws->base + L.sk;
+  d.splitk_ws_bytes = L.sk_bytes;
+}
+
 // LoRA intermediate T = A_act . lora_A^T  ([M x r_pad]); two activation segments for proj_out.
 static int lora_down(const rf_lora_seg& l, const bf16_t* a0, int64_t lda0, int K0, const bf16_t* a1, int64_t lda1,
                      int K1, int M, bf16_t* T, const rf_workspace* ws, const WsLayout& L, hipStream_t st) {
   rf_gemm_desc d;
   memset(&d, 0, sizeof(d));
   d.N = l.r_pad; d.epilogue = RF_EPI_STORE; d.num_groups = 1;
-  if (L.sk_bytes > 0) { d.splitk_ws = (char*)ws->base + L.sk; d.splitk_ws_bytes = L.sk_bytes; }
+  attach_scratch(d, ws, L);
   rf_gemm_group& g = d.g[0];
   const int64_t ldA = (int64_t)K0 + K1;  // lora_A rows span the concatenated input
   set_seg(g.seg[0], a0, lda0, l.A, ldA, K0);
@@ -159,6 +165,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         set_seg(g.seg[1], T, 256, w->lora_qkv.B, w->lora_qkv.r_pad, w->lora_qkv.r_pad);
       }
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE: fused into the QKV epilogue above
@@ -190,6 +197,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         set_seg(g.seg[1], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
       }
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
     if (add_cond) {
       for (int r = 0; r < Sc; ++r) {  // rows may be strided (ldx != D): add row by row only then
@@ -222,6 +230,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
       g.bias = txt ? w->b_ffc1 : w->b_ff1;
       g.out = HID + (int64_t)s.off * MLP; g.ldo = MLP;
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   // 8. FF down + gated residual: x += gate_mlp * ff(x)
@@ -245,6 +254,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         set_seg(g.seg[1], T, 256, w->lora_ff2.B, w->lora_ff2.r_pad, w->lora_ff2.r_pad);
       }
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   return RF_OK;
@@ -296,6 +306,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
         set_seg(g.seg[1], T, 256, w->lora_qkv_mlp.B, w->lora_qkv_mlp.r_pad, w->lora_qkv_mlp.r_pad);
       }
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   // 3. RMSNorm(q,k) + RoPE: fused into the epilogue above (no added-norm rows in single blocks)
@@ -324,6 +335,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
         set_seg(g.seg[2], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
       }
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   return RF_OK;
@@ -381,6 +393,7 @@ extern "C" int rf_flux_forward(const rf_flux_dims* dims, const rf_flux_model* m,
         set_seg(g.seg[1], T, 256, m->lora_x_embed.B, m->lora_x_embed.r_pad, m->lora_x_embed.r_pad);
       }
     }
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   if (St > 0) {
@@ -389,6 +402,7 @@ extern "C" int rf_flux_forward(const rf_flux_dims* dims, const rf_flux_model* m,
     d.N = D; d.epilogue = RF_EPI_STORE; d.num_groups = 1;
     set_seg(d.g[0].seg[0], ctx, m->joint_dim, m->w_ctx_embed, m->joint_dim, m->joint_dim);
     d.g[0].bias = m->b_ctx_embed; d.g[0].M = St; d.g[0].out = x_txt; d.g[0].ldo = D;
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
 
@@ -415,6 +429,7 @@ extern "C" int rf_flux_forward(const rf_flux_dims* dims, const rf_flux_model* m,
     d.N = m->in_ch; d.epilogue = RF_EPI_STORE; d.num_groups = 1;
     set_seg(d.g[0].seg[0], XN, D, m->w_proj_out, D, D);
     d.g[0].bias = m->b_proj_out; d.g[0].M = Si; d.g[0].out = out; d.g[0].ldo = m->in_ch;
+    attach_scratch(d, ws, L);
     RF_TRY(rf_gemm_bf16(&d, st));
   }
   return RF_OK;

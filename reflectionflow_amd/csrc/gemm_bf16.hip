@@ -48,6 +48,7 @@ struct GemmParams {
   // deterministic split-K (few-tile GEMMs, e.g. the LoRA down-projections): blockIdx.y = K-slice of kchunk
   // K-tiles, fp32 partial tiles go to ws[slice][m][n_pad], splitk_reduce_kernel sums them in slice order
   int ksplit, kchunk; float* ws; int64_t ws_slice; int ws_ld;
+  float* scratch; int64_t scratch_bytes;  // host side: the caller's scratch as passed (flags + partials)
   GemmGroupDev g[4];
 };
 
@@ -331,9 +332,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
   }
 }
 
-// VEC: LDS-staged 16-byte epilogue (all pointers 16-byte aligned, N % 8 == 0) vs the per-element fallback
-template <int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+// ---- main loop ----------------------------------------------------------------------------------------
+// acc += A[m0.., K-tiles kt_begin .. kt_begin+nk) . W[n0.., same)^T over the concatenation of G's K segments.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                              const int nk, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem, const int w,
+                                              const int lane) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -342,35 +346,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   constexpr int IA = BM * 8 / NT, IB = BN * 8 / NT;  // LDS-DMA instructions per thread per stage
   static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / WN, wn = w % WN;
   const int l31 = lane & 31, h = lane >> 5;
-
-  // ---- tile decode (wave-uniform) -------------------------------------------------------
-  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
-  int gi = 0;
-#pragma unroll
-  for (int t = 1; t < 4; ++t)
-    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
-  const GemmGroupDev& G = p.g[gi];
-  const int lt = tile - G.tile_start;
-  // grouped raster: column bands of GW tiles; consecutive ids (= one XCD's chunk after xcd_remap)
-  // walk tm inside a band, so the CUs of an XCD share a few A row-panels AND a few W column-panels
-  // in their private L2 (+5 % at 8192^3, neutral on the FLUX shapes; profiles/r01_gemm_variants.md)
-  constexpr int GW = 8;
-  const int band = lt / (GW * G.tiles_m);
-  const int first = band * GW;
-  const int gw = (p.tiles_n - first) < GW ? (p.tiles_n - first) : GW;
-  const int rr = lt - band * GW * G.tiles_m;
-  const int tm = rr / gw;
-  const int tn = first + rr % gw;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int M = G.M, N = p.N;
+  const int M = G.M;
 
   // ---- per-lane DMA source pointers -----------------------------------------------------
   // DMA instruction i of wave w fills LDS bytes [(i*NW + w)*1024, +1024): 8 rows of 128 B.
@@ -412,7 +390,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     for (int q = 0; q < IA + IB; ++q) stage_piece(q, kt_in_seg, buf);
   };
 
-  f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -425,13 +402,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   const int a_row_off = (wm * TM + l31) * 128;
   const int b_row_off = A_BYTES + (wn * TN + l31) * 128;
 
-  // K loop over the concatenation of this group's segments; (seg, kk) is the NEXT tile to stage.
-  // With split-K this block covers K-tiles [kt_begin, kt_begin + nk) of that concatenation.
-  const int nk_all = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  const int kt_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;
-  const int nk = p.ksplit > 1 ? ((nk_all - kt_begin) < p.kchunk ? (nk_all - kt_begin) : p.kchunk) : nk_all;
+  // (seg, kk) is the NEXT tile to stage; position at the range's first tile (host compacts segments)
   int seg = 0, kk = kt_begin, cur_nk = G.seg[0].nk;
-  while (kk >= cur_nk && seg < 2) {  // position at the slice's first tile (host compacts segments)
+  while (kk >= cur_nk && seg < 2) {
     kk -= cur_nk;
     ++seg;
     cur_nk = G.seg[seg].nk;
@@ -487,17 +460,234 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
     }
     if (more) advance();
   }
+}
+
+// local tile id of a group -> (tm, tn).  Grouped raster: column bands of GW tiles; consecutive ids (= one XCD's
+// chunk) walk tm inside a band, so the CUs of an XCD share a few A row-panels AND a few W column-panels in their
+// private L2 (+5 % at 8192^3, neutral on the FLUX shapes; profiles/r01_gemm_variants.md)
+__device__ __forceinline__ void tile_coords(const int lt, const int tiles_m, const int tiles_n, int& tm, int& tn) {
+  constexpr int GW = 8;
+  const int band = lt / (GW * tiles_m);
+  const int first = band * GW;
+  const int gw = (tiles_n - first) < GW ? (tiles_n - first) : GW;
+  const int rr = lt - band * GW * tiles_m;
+  tm = rr / gw;
+  tn = first + rr % gw;
+}
+
+// VEC: LDS-staged 16-byte epilogue (all pointers 16-byte aligned, N % 8 == 0) vs the per-element fallback
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 32, FN = TN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / WN, wn = w % WN;
+
+  // ---- tile decode (wave-uniform) -------------------------------------------------------
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  int tm, tn;
+  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // with split-K this block covers K-tiles [kt_begin, kt_begin + nk) of the segment concatenation
+  const int nk_all = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  const int kt_begin = p.ksplit > 1 ? (int)blockIdx.y * p.kchunk : 0;
+  const int nk = p.ksplit > 1 ? ((nk_all - kt_begin) < p.kchunk ? (nk_all - kt_begin) : p.kchunk) : nk_all;
+
+  f32x16 acc[FM][FN];
+  gemm_mainloop<BM, BN, WM, WN>(G, p.N, m0, n0, kt_begin, nk, acc, smem, w, lane);
 
   if constexpr (VEC) {
     static_assert(FN == 4, "LDS-staged epilogue expects 128-column wave strips");
     __syncthreads();  // every wave is done reading the staged operands: the LDS is free
     gemm_epilogue_lds<FM>(p, G, acc, m0, n0, wm * TM, wn * TN, lane, smem + w * EPI_REGION);
   } else {
-    gemm_epilogue<FM, FN>(p, G, acc, m0, n0, wm * TM, wn * TN, l31, h);
+    gemm_epilogue<FM, FN>(p, G, acc, m0, n0, wm * TM, wn * TN, lane & 31, lane >> 5);
   }
 }
 
-// ---------------------------------------------------------------------------------------------
+// ---- stream-K variant ---------------------------------------------------------------------------------
+// One persistent block per CU.  The launch's MAC work is measured in K-tile iterations (tile-major) and cut into
+// gridDim.x equal contiguous ranges, so 216 or 264 tiles on 256 CUs cost 0.84 / 1.03 tile-times instead of 1 / 2
+// (tile quantisation was the largest single GEMM loss: profiles/r01_cfg4_kernel_stats.csv).  A range covers the
+// tail of one tile, whole tiles, and the head of another.  Pieces are processed LAST-FIRST:
+//   * a piece that does not reach its tile's last K-tile is stored as raw fp32 accumulators into the block's
+//     partial slot (register layout, coalesced 16-byte stores) and published with a release flag;
+//   * the block holding a tile's final piece adds the partials of the (1..2) blocks before it in index order
+//     and runs the normal fused epilogue -- fixed summation order, bit-reproducible.
+// Waits only ever target a block with a LOWER hardware index inside the same XCD chunk (ranges are cut per XCD
+// at tile boundaries), which was dispatched earlier and produced that partial as its FIRST piece: no deadlock
+// even without co-residency, and in practice no spinning.  Flags are reset by their single consumer, so the
+// kernel leaves the scratch as it found it (hipGraph-replayable).
+struct SkParams {
+  int iter_start[5];    // first global iteration of group g (iter_start[ngroups] = total)
+  int nk[4];            // K-tiles per tile of group g
+  // per-XCD chunk x (cut at tile boundaries): whole-tile rounds first -- worker cl takes tiles
+  // chunk_tile[x] + r*PL + cl, r < dp_rounds[x], i.e. the XCD's CUs sweep 32 consecutive tiles together exactly
+  // like the one-tile-per-block launch (shared A / W panels in the private L2) -- then the stream-K region, the
+  // iterations [sk_begin[x], chunk_end[x]) (one to two tiles per worker), cut evenly
+  int chunk_tile[8], dp_rounds[8], sk_begin[8], chunk_end[8];
+  float* partials;      // [gridDim.x] slots of BM*BN floats
+  int* flags;           // [gridDim.x], zero outside a launch
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmParams p, const SkParams sk) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 32, FN = TN / 32;
+  static_assert(FN == 4, "LDS-staged epilogue expects 128-column wave strips");
+  static_assert(NT * 16 == 0x2000, "partial-slot stride is hard-coded in the inline assembly");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w / WN, wn = w % WN;
+
+  // block b runs on XCD b % 8; it is worker b / 8 of that XCD's chunk
+  const int xcd = blockIdx.x & 7, cl = blockIdx.x >> 3, PL = gridDim.x >> 3;
+  const int cs = sk.sk_begin[xcd], clen = sk.chunk_end[xcd] - cs;
+  auto range_begin = [&](int worker) { return cs + (int)((int64_t)worker * clen / PL); };
+  const int it_begin = range_begin(cl);
+  int cur_end = range_begin(cl + 1);
+  const int dp_rounds = sk.dp_rounds[xcd];
+  int round = 0;
+  float* const my_slot = sk.partials + (int64_t)blockIdx.x * (BM * BN);
+  bool first = true;
+
+  while (true) {
+    int gi = 0, lt, ts, ub, nk_u;
+    bool is_tail;
+    if (round < dp_rounds) {
+      // whole tile of a full round
+      const int tile = sk.chunk_tile[xcd] + round * PL + cl;
+      ++round;
+#pragma unroll
+      for (int t = 1; t < 4; ++t)
+        if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+      lt = tile - p.g[gi].tile_start;
+      nk_u = sk.nk[gi];
+      ts = 0; ub = 0;
+      is_tail = true;
+    } else if (cur_end > it_begin) {
+      const int last = cur_end - 1;
+#pragma unroll
+      for (int t = 1; t < 4; ++t)
+        if (t < p.ngroups && last >= sk.iter_start[t]) gi = t;
+      const int nk_g = sk.nk[gi];
+      lt = (last - sk.iter_start[gi]) / nk_g;
+      ts = sk.iter_start[gi] + lt * nk_g;  // the tile's iterations are [ts, ts + nk_g)
+      ub = it_begin > ts ? it_begin : ts;
+      is_tail = cur_end == ts + nk_g;
+      nk_u = cur_end - ub;                 // K-tiles of this piece
+      cur_end = ub;
+    } else {
+      break;
+    }
+    const GemmGroupDev& G = p.g[gi];
+    int tm, tn;
+    tile_coords(lt, G.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    if (!first) __syncthreads();  // the previous piece's epilogue staging is done with the LDS
+    first = false;
+    // launder the lane id once per piece: keeps the per-lane address math of the main loop and the epilogue INSIDE the
+    // loop (LICM would hoist ~100 VGPRs of it across the whole kernel and spill)
+    int lane_i = lane, tid_i = tid;
+    asm volatile("" : "+v"(lane_i), "+v"(tid_i));
+    f32x16 acc[FM][FN];
+    gemm_mainloop<BM, BN, WM, WN>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+
+    if (!is_tail) {
+      // head or middle piece: raw accumulators -> this block's slot, [quad k][thread] x 16 B, as agent-coherent
+      // write-through stores (sc1: what a relaxed agent-scope atomic store compiles to), so publishing them needs
+      // no cache-wide writeback; then the flag
+      {
+        uint32_t voff = (uint32_t)tid_i * 16u;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              const f32x4 v = {acc[i][j][rq * 4], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+              asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\tv_add_u32 %0, 0x2000, %0" : "+v"(voff) : "v"(v), "s"(my_slot) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();  // every thread's stores have been issued and acknowledged
+      if (tid == 0) __hip_atomic_store(sk.flags + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (ub > ts) {
+        // final piece of a split tile: add the earlier pieces (workers cl-1, cl-2, .. down to the one holding ts)
+        for (int c2 = cl - 1;; --c2) {
+          const int b2 = xcd + 8 * c2;
+          const int rb2 = range_begin(c2);
+          if (rb2 == range_begin(c2 + 1)) continue;  // empty range (the host never creates one): nothing to add
+          if (tid == 0) {
+            while (__hip_atomic_load(sk.flags + b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(sk.flags + b2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // single consumer: reset
+          }
+          __syncthreads();
+          // agent-coherent loads (sc1: they never hit a stale line of this XCD's L2) instead of an acquire fence,
+          // which would invalidate the whole L2 under the other 31 CUs' feet.  8 x 16 B in flight per lane.
+          const float* slot = sk.partials + (int64_t)b2 * (BM * BN);
+          uint32_t voff = (uint32_t)tid_i * 16u;
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; j += 2) {
+              f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+              asm volatile(
+                  "global_load_dwordx4 %0, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %1, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %2, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %3, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %4, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %5, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %6, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "global_load_dwordx4 %7, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
+                  "s_waitcnt vmcnt(0)"
+                  : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "+v"(voff)
+                  : "s"(slot)
+                  : "memory");
+              const f32x4 tt[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j + (q >> 2)][(q & 3) * 4 + e] += tt[q][e];
+            }
+          if (rb2 <= ts) break;
+        }
+      }
+      __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+      gemm_epilogue_lds<FM>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+    }
+  }
+}
+
+template <int BM, int BN>
+static void layout_tiles(GemmParams& p) {
+  p.tiles_n = cdiv(p.N, BN);
+  int start = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    p.g[g].tiles_m = cdiv(p.g[g].M, BM);
+    p.g[g].tile_start = start;
+    start += p.g[g].tiles_m * p.tiles_n;
+  }
+  p.total_tiles = start;
+}
+
 template <int BM, int BN, int WM, int WN, bool VEC>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
@@ -508,18 +698,91 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  p.tiles_n = cdiv(p.N, BN);
-  int start = 0;
-  for (int g = 0; g < p.ngroups; ++g) {
-    p.g[g].tiles_m = cdiv(p.g[g].M, BM);
-    p.g[g].tile_start = start;
-    start += p.g[g].tiles_m * p.tiles_n;
-  }
-  p.total_tiles = start;
-  if (start == 0) return RF_OK;
-  hipLaunchKernelGGL(kern, dim3(start, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * WN * 64), LDS, stream, p);
+  layout_tiles<BM, BN>(p);
+  if (p.total_tiles == 0) return RF_OK;
+  hipLaunchKernelGGL(kern, dim3(p.total_tiles, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * WN * 64), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
+}
+
+// scratch layout shared by split-K and stream-K: [0, 4096) stream-K flags (zero outside a launch), partials after
+constexpr int64_t WS_FLAG_BYTES = 4096;
+static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K (test introspection)
+static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = whenever feasible (tests)
+
+// stream-K launch of the 256x256 kernel; returns 1 if it launched, 0 if the shape does not qualify, < 0 on error
+template <int BM, int BN, int WM, int WN>
+static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStream_t stream) {
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    RF_CHECK_HIP(hipGetDevice(&dev));
+    RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int P = num_cus / 8 * 8;  // one persistent block per CU, 8 XCD chunks
+  if (P < 8 || (int64_t)P * 4 > WS_FLAG_BYTES) return 0;
+  if (ws == nullptr || ws_bytes < WS_FLAG_BYTES + (int64_t)P * BM * BN * 4) return 0;
+  layout_tiles<BM, BN>(p);
+  const int T = p.total_tiles;
+  if (T == 0) return 0;
+  const int rounds = cdiv(T, P);
+  // Measured on MI355X (tools/kb_sk.py, profiles/r01_stream_k.md): the chip is power-limited (~1.39 kW at 1.87 GHz
+  // under this kernel), so a last round that leaves CUs idle costs less than its tile count suggests, while the
+  // stream-K region loses the lock-step L2 sharing of A/W panels.  Stream-K wins below ~83 % round utilisation
+  // (S=5632: 264 tiles +40..58 %, 792 tiles +9 %, 1056 tiles +5 %) and loses above it (S=4608: 0.84 -> -2..-10 %).
+  if (g_force_sk < 0 && (double)T / ((double)rounds * P) >= 0.83) return 0;
+  SkParams sk;
+  memset(&sk, 0, sizeof(sk));
+  int64_t I = 0;
+  for (int g = 0; g < p.ngroups; ++g) {
+    sk.iter_start[g] = (int)I;
+    sk.nk[g] = p.g[g].seg[0].nk + p.g[g].seg[1].nk + p.g[g].seg[2].nk;
+    I += (int64_t)p.g[g].tiles_m * p.tiles_n * sk.nk[g];
+  }
+  if (I * 8 >= (1ll << 31)) return 0;
+  for (int g = p.ngroups; g <= 4; ++g) sk.iter_start[g] = (int)I;
+  auto iter_of_tile = [&](int t) {
+    int g = 0;
+    while (g + 1 < p.ngroups && t >= p.g[g + 1].tile_start) ++g;
+    return sk.iter_start[g] + (t - p.g[g].tile_start) * sk.nk[g];
+  };
+  // per-XCD chunks: cut at the tile boundary nearest to x/8 of the work
+  const int PL = P / 8;
+  int chunk_tile[9];
+  for (int x = 0; x <= 8; ++x) {
+    const int64_t target = I * x / 8;
+    int g = 0;
+    while (g + 1 < p.ngroups && target >= sk.iter_start[g + 1]) ++g;
+    const int64_t j = (target - sk.iter_start[g] + sk.nk[g] / 2) / sk.nk[g];
+    chunk_tile[x] = p.g[g].tile_start + (int)j;
+  }
+  chunk_tile[0] = 0;
+  chunk_tile[8] = T;
+  for (int x = 0; x < 8; ++x) {
+    const int Tc = chunk_tile[x + 1] - chunk_tile[x];
+    sk.chunk_tile[x] = chunk_tile[x];
+    sk.chunk_end[x] = chunk_tile[x + 1] == T ? (int)I : iter_of_tile(chunk_tile[x + 1]);
+    // the stream-K region is the remainder after the full rounds (workers are out of K-phase there and share less
+    // in the L2, so it is kept short); if that leaves < 8 K-tiles per worker, the last full round joins it
+    sk.dp_rounds[x] = Tc / PL;
+    if (sk.dp_rounds[x] > 0 && sk.chunk_end[x] - iter_of_tile(chunk_tile[x] + sk.dp_rounds[x] * PL) < PL * 8) --sk.dp_rounds[x];
+    sk.sk_begin[x] = iter_of_tile(chunk_tile[x] + sk.dp_rounds[x] * PL);
+    if (sk.chunk_end[x] - sk.sk_begin[x] < PL * 4) return 0;  // < 4 K-tiles per worker: not worth slicing
+  }
+  sk.flags = (int*)ws;
+  sk.partials = (float*)((char*)ws + WS_FLAG_BYTES);
+  constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
+  constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
+  static bool attr_set = false;
+  auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN>;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  RF_LAUNCH_CHECK();
+  g_last_path = 2;
+  return 1;
 }
 
 // out[m][n] = bf16( sum_s ws[s][m][n] + bias[n] ), slices summed in index order (deterministic)
@@ -612,8 +875,8 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
   p.ksplit = 1;
   if (d->splitk_ws != nullptr) {
     RF_REQUIRE(aligned16(d->splitk_ws) && d->splitk_ws_bytes >= 0, RF_ERR_ALIGN, "rf_gemm_bf16: splitk_ws must be 16-byte aligned");
-    p.ws = (float*)d->splitk_ws;
-    p.ws_slice = d->splitk_ws_bytes;  // bytes for now; dispatch() turns it into the slice stride
+    p.scratch = (float*)d->splitk_ws;
+    p.scratch_bytes = d->splitk_ws_bytes;
   }
   if (d->rope_cos != nullptr) {
     RF_REQUIRE(qkv && d->rope_sin != nullptr && aligned16(d->rope_cos) && aligned16(d->rope_sin), RF_ERR_ALIGN,
@@ -636,8 +899,15 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   // split-K: a plain-store, single-group GEMM with a handful of tiles and a long K (LoRA down-projection:
   // [S_cond x K] . [r_pad x K]^T = 8 tiles x up to 240 K-tiles) would run on 8 of 256 CUs.  Slice K over
   // blockIdx.y, >= 4 K-tiles per slice, ~256 blocks in flight, fp32 partials in caller-owned scratch.
-  const int64_t ws_bytes = p.ws != nullptr ? p.ws_slice : 0;
+  float* const ws_base = p.scratch;
+  const int64_t ws_total = ws_base != nullptr ? p.scratch_bytes : 0;
+  const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
+  p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
+  if (tile == 256 && p.vec_ok && g_force_sk != 0) {
+    const int rc = try_launch_gemm_sk<256, 256, 4, 2>(p, ws_base, ws_total, stream);
+    if (rc != 0) return rc < 0 ? rc : RF_OK;
+  }
   if (ws_bytes > 0 && tile == 128 && p.ngroups == 1 && p.epi == RF_EPI_STORE && p.vec_ok) {
     const GemmGroupDev& G = p.g[0];
     const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
@@ -656,9 +926,11 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, stream, p.ws, slice, p.ws_ld,
                          p.ksplit, G.bias, G.out, G.ldo, G.M, p.N);
       RF_LAUNCH_CHECK();
+      g_last_path = 1;
       return RF_OK;
     }
   }
+  g_last_path = 0;
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
   if (tile == 256) return p.vec_ok ? launch_gemm<256, 256, 4, 2, true>(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
@@ -677,6 +949,14 @@ extern "C" int rf_gemm_bf16(const rf_gemm_desc* d, void* stream) {
 extern "C" int rf_debug_force_gemm_tile(int tile) {
   if (tile != 0 && tile != 128 && tile != 256) return RF_ERR_SHAPE;
   rf::g_force_tile = tile;
+  return RF_OK;
+}
+
+extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }
+
+extern "C" int rf_debug_force_gemm_sk(int mode) {
+  if (mode < -1 || mode > 1) return RF_ERR_SHAPE;
+  rf::g_force_sk = mode;
   return RF_OK;
 }
 

@@ -108,12 +108,22 @@ def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STOR
 
 
 def gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, **kw):
+    """Grouped GEMM launch.  splitk_ws=None (default) attaches the per-stream scratch so the library may use
+    stream-K / split-K; splitk_ws=False forbids both."""
+    if kw.get("splitk_ws", None) is None:
+        kw["splitk_ws"] = splitk_scratch(groups[0].segs[0].A.device)
+    elif kw["splitk_ws"] is False:
+        kw["splitk_ws"] = None
     d = build_gemm_desc(groups, N, epilogue, **kw)
     L.check(L.load().rf_gemm_bf16(C.byref(d), stream_ptr()), "rf_gemm_bf16")
 
 
 def time_gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, iters: int = 10, **kw) -> float:
     """Average duration (seconds) of one launch, measured with hipEvents on the launch stream."""
+    if kw.get("splitk_ws", None) is None:
+        kw["splitk_ws"] = splitk_scratch(groups[0].segs[0].A.device)
+    elif kw["splitk_ws"] is False:
+        kw["splitk_ws"] = None
     d = build_gemm_desc(groups, N, epilogue, **kw)
     us = C.c_float(0.0)
     L.check(L.load().rf_time_gemm(C.byref(d), iters, C.byref(us), stream_ptr()), "rf_time_gemm")
@@ -139,17 +149,17 @@ _SPLITK = {}
 
 
 def splitk_scratch(device) -> torch.Tensor:
-    """Per-(device, stream) 32 MiB fp32 scratch for the split-K LoRA down-projections of the per-block API
-    (the whole-forward engine carves its own out of the workspace)."""
+    """Per-(device, stream) GEMM scratch of the per-op API: 4 KiB of zeroed stream-K flags + 64 MiB of fp32
+    partial tiles (the whole-forward engine carves its own out of the workspace)."""
     key = (torch.device(device).index, stream_ptr())
     if key not in _SPLITK:
-        _SPLITK[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+        _SPLITK[key] = torch.zeros(1024 + (16 << 20), dtype=torch.float32, device=device)
     return _SPLITK[key]
 
 
 def lora_down(x: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
     """T = x . lora_A^T  ([M, r_pad]); few output tiles and a long K, so it runs split-K."""
-    return linear(x, A, splitk_ws=splitk_scratch(x.device))
+    return linear(x, A)
 
 
 def alloc_attn_operands(heads: int, S: int, device) -> tuple:

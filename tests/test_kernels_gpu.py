@@ -388,8 +388,9 @@ def test_gemm_splitk_lora_down(dev, M, N, K, K2, ws_mib):
         ref = ref + x2.float() @ A[:, K:].float().t()
     ws = torch.empty(ws_mib << 18, dtype=torch.float32, device=dev)
     outs = []
-    for scratch in (ws, ws, None):
-        ws.fill_(float("nan"))  # partial tiles must be fully overwritten before they are summed
+    for scratch in (ws, ws, False):
+        ws[1024:].fill_(float("nan"))  # partial tiles must be fully overwritten before they are summed
+        ws[:1024].zero_()             # (first 4 KiB = stream-K flags, zero by contract)
         y = torch.full((M, 256), 7.0, dtype=BF, device=dev)  # ldo > N as in the engine's LT buffer
         ops.gemm([ops.Group(segs, bias=b, out=y[:, :N])], N, ops.RF_EPI_STORE, splitk_ws=scratch)
         outs.append(y)
@@ -397,3 +398,78 @@ def test_gemm_splitk_lora_down(dev, M, N, K, K2, ws_mib):
     assert torch.equal(outs[0], outs[1]), "split-K is not deterministic"
     assert (outs[0][:, N:] == 7.0).all(), "split-K reduce wrote outside its N columns"
     assert_close(outs[0][:, :N], outs[2][:, :N].float(), "split-K vs unsplit", rtol=8e-3)
+
+
+# ------------------------------------------------------------------------------------- stream-K
+@pytest.fixture
+def force_sk(dev):
+    from reflectionflow_amd import _lib
+    lib = _lib.load()
+    lib.rf_debug_force_gemm_tile(256)
+    lib.rf_debug_force_gemm_sk(1)
+    yield lib
+    lib.rf_debug_force_gemm_sk(-1)
+    lib.rf_debug_force_gemm_tile(0)
+
+
+@pytest.mark.parametrize("rows,N,K,K2", [((4608,), 3072, 3072, 0),            # cfg2 out-proj: 216 tiles on 256 CUs
+                                         ((512, 4096, 1024), 3072, 1024, 128),  # cfg4: 264 tiles, LoRA segment on group 2
+                                         ((1500,), 2048, 2048, 0),              # 48 tiles: every tile cut in ~5 pieces
+                                         ((700, 300), 1000, 8192, 0),           # ragged M and N
+                                         ((4608,), 9216, 512, 0)])              # 648 tiles: whole tiles + head + tail
+def test_gemm_stream_k_gate_res(dev, force_sk, rows, N, K, K2):
+    """Stream-K launch (K-tile iterations cut evenly over the CUs, partial tiles fixed up in index order) of the
+    gated-residual GEMM: equals the one-tile-per-block launch up to fp32 summation order, the fp32 reference within
+    bf16 rounding, and itself bit-for-bit from run to run -- with fresh inputs every round, so a stale partial
+    tile or a missed flag cannot hide."""
+    from reflectionflow_amd import ops
+    lib = force_sk
+    for rnd_i in range(3):
+        groups, refs, outs = [], [], []
+        for gi, M in enumerate(rows):
+            x, W = rnd(M, K, dev=dev, seed=100 * rnd_i + gi), rnd(N, K, dev=dev, scale=0.05, seed=50 + 100 * rnd_i + gi)
+            b, gate, res = rnd(N, dev=dev, seed=gi + 7), rnd(N, dev=dev, seed=gi + 9), rnd(M, N, dev=dev, seed=gi + 11)
+            segs = [ops.Seg(x, W)]
+            y = x.float() @ W.float().t()
+            if K2 and gi == len(rows) - 1:
+                t, B = rnd(M, K2, dev=dev, seed=gi + 13), rnd(N, K2, dev=dev, scale=0.05, seed=gi + 15)
+                segs.append(ops.Seg(t, B))
+                y = y + t.float() @ B.float().t()
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            groups.append(ops.Group(segs, bias=b, out=out, residual=res, gate=gate))
+            refs.append(res.float() + gate.float() * (y + b.float()))
+            outs.append(out)
+        got = []
+        for mode in (1, 1, 0):
+            lib.rf_debug_force_gemm_sk(mode)
+            ops.gemm(groups, N, ops.RF_EPI_GATE_RES)
+            assert lib.rf_debug_last_gemm_path() == (2 if mode else 0), "stream-K path was not (de)selected"
+            got.append([o.clone() for o in outs])
+        for gi in range(len(rows)):
+            assert_close(got[0][gi], refs[gi], f"stream-K group {gi} vs fp32")
+            assert torch.equal(got[0][gi], got[1][gi]), "stream-K is not deterministic"
+            assert_close(got[0][gi], got[2][gi].float(), f"stream-K vs tile-per-block, group {gi}", rtol=8e-3)
+
+
+def test_gemm_stream_k_qkv_fused(dev, force_sk):
+    """Stream-K under the fused QKV + RMSNorm + RoPE epilogue (text / image / condition groups): q, k, V^T equal
+    the tile-per-block launch within bf16 rounding of the fp32-sum reorder."""
+    from reflectionflow_amd import ops
+    lib = force_sk
+    H, St, Si, Sc, K = 4, 512, 1024, 256, 3072
+    D, S = H * 128, St + Si + Sc
+    cos, sin = torch.rand(S, 128, device=dev), torch.rand(S, 128, device=dev)
+    res = []
+    for mode in (1, 0):
+        lib.rf_debug_force_gemm_sk(mode)
+        q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+        groups = []
+        for gi, (M, off) in enumerate([(St, 0), (Si, St), (Sc, St + Si)]):
+            x, W, b = rnd(M, K, dev=dev, seed=gi), rnd(3 * D, K, dev=dev, scale=0.05, seed=10 + gi), rnd(3 * D, dev=dev, seed=20 + gi)
+            nq, nk_ = rnd(128, dev=dev, seed=30 + gi) + 1.0, rnd(128, dev=dev, seed=40 + gi) + 1.0
+            groups.append(ops.Group([ops.Seg(x, W)], bias=b, tok_offset=off, norm_q=nq, norm_k=nk_))
+        ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin), q_scale=ops.QK_PRESCALE)
+        assert lib.rf_debug_last_gemm_path() == (2 if mode else 0)
+        res.append((q.clone(), k.clone(), vt.clone()))
+    for a, b, name in zip(res[0], res[1], "q k vt".split()):
+        assert_close(a, b.float(), f"stream-K {name}", rtol=8e-3)
