@@ -434,12 +434,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
     // vmcnt placement for LDS-DMA in a loop (see attention.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed for every wave; every wave is done with tile kt-1
-    // The next tile's 8 LDS-DMA pieces are issued two per k-step BEHIND that k-step's fragment reads rather than
-    // all at once after the barrier: the matrix pipe restarts ~300 cycles earlier per K-tile (+5-10 %, measured;
-    // the kernel is not DMA-latency bound -- profiles/r01_gemm_variants.md)
+    // The next tile's 8 LDS-DMA pieces are issued BEHIND the fragment reads of the first three k-steps rather than all
+    // at once after the barrier: the matrix pipe restarts ~300 cycles earlier per K-tile (+5-10 %, measured; profiles/r01_gemm_variants.md)
     const bool more = kt + 1 < nk;
     const char* base = smem + (kt & 1) * STAGE;
-    constexpr int PPS = (IA + IB + 3) / 4;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int coff = ((ks * 2 + h) ^ swz) << 4;
@@ -449,8 +447,13 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
 #pragma unroll
       for (int j = 0; j < FN; ++j) b[j] = *(const bf16x8*)(base + b_row_off + j * 32 * 128 + coff);
       if (more) {
+        // next tile's DMA pieces: 3, 3, 2, 0 over the four k-steps -- the last piece gets a whole k-step to land before
+        // the drain at the end of the tile (vs 2,2,2,2: +3..7 % on the FLUX shapes; 4,4,0,0 equal; 0,3,3,2 -3 %)
+        constexpr int NP = IA + IB;
+        const int q0 = ks * 3 < NP ? ks * 3 : NP, q1 = (ks + 1) * 3 < NP ? (ks + 1) * 3 : NP;
 #pragma unroll
-        for (int q = ks * PPS; q < (ks + 1) * PPS && q < IA + IB; ++q) stage_piece(q, kk, (kt + 1) & 1);
+        for (int q = 0; q < NP; ++q)
+          if (q >= q0 && q < q1) stage_piece(q, kk, (kt + 1) & 1);
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
