@@ -49,6 +49,7 @@ struct GemmParams {
   // K-tiles, fp32 partial tiles go to ws[slice][m][n_pad], splitk_reduce_kernel sums them in slice order
   int ksplit, kchunk; float* ws; int64_t ws_slice; int ws_ld;
   float* scratch; int64_t scratch_bytes;  // host side: the caller's scratch as passed (flags + partials)
+  unsigned long long* timeline;           // debug build of the kernel only (rf_debug_gemm_timeline)
   GemmGroupDev g[4];
 };
 
@@ -56,6 +57,18 @@ constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
+
+// buffer-resource LDS-DMA (buffer_load_dwordx4 ... lds).  The resource type and builtins only exist in the device
+// pass; the host pass (which still instantiates the kernel templates to take their addresses) sees inert stand-ins.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define RF_MAKE_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7fffffff, 0x00020000)
+#define RF_BUF_LOAD_LDS(r, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0)
+#else
+typedef int rsrc_t;
+#define RF_MAKE_RSRC(p) 0
+#define RF_BUF_LOAD_LDS(r, lds, voff, soff) ((void)0)
+#endif
 
 // ---- shared epilogue ---------------------------------------------------------------------------
 // acc[i][j]: 32x32 MFMA accumulators of one wave; fragment (i,j) covers rows wrow0 + i*32 .. and
@@ -334,10 +347,10 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
 
 // ---- main loop ----------------------------------------------------------------------------------------
 // acc += A[m0.., K-tiles kt_begin .. kt_begin+nk) . W[n0.., same)^T over the concatenation of G's K segments.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TL = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                               const int nk, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem, const int w,
-                                              const int lane) {
+                                              const int lane, unsigned long long* tl = nullptr) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -350,19 +363,25 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
   const int l31 = lane & 31, h = lane >> 5;
   const int M = G.M;
 
-  // ---- per-lane DMA source pointers -----------------------------------------------------
+  // ---- per-lane DMA source offsets ------------------------------------------------------
   // DMA instruction i of wave w fills LDS bytes [(i*NW + w)*1024, +1024): 8 rows of 128 B.
   // lane -> (row = +lane/8, physical chunk = lane%8); it fetches logical chunk = pc ^ swz(row).
-  const bf16_t* srcA[IA];
-  const bf16_t* srcB[IB];
+  // The loads are buffer_load_dwordx4 ... lds: SGPR resource (segment base) + 32-bit per-lane byte offset + SGPR
+  // K offset.  Against global_load_lds with 64-bit per-lane addresses this halves the address VGPRs and removes the
+  // per-piece 64-bit VALU add; the s_memtime timeline (tools/kb_timeline.py) showed the DMA *issue* -- not its
+  // latency: the end-of-tile drain is ~50 cycles -- to be the non-MFMA half of a wave's K-tile.
+  uint32_t offA[IA], offB[IB];
+  rsrc_t rsA, rsB;
   auto setup_ptrs = [&](const bf16_t* Ab, int64_t lda, const bf16_t* Wb, int64_t ldw) {
+    rsA = RF_MAKE_RSRC(Ab);
+    rsB = RF_MAKE_RSRC(Wb);
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const int row = (i * NW + w) * 8 + (lane >> 3);
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       int gm = m0 + row;
       gm = gm < M ? gm : M - 1;
-      srcA[i] = Ab + (int64_t)gm * lda + chunk * 8;
+      offA[i] = (uint32_t)(((int64_t)gm * lda + chunk * 8) * 2);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -370,7 +389,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       int gn = n0 + row;
       gn = gn < N ? gn : N - 1;
-      srcB[i] = Wb + (int64_t)gn * ldw + chunk * 8;
+      offB[i] = (uint32_t)(((int64_t)gn * ldw + chunk * 8) * 2);
     }
   };
 
@@ -378,11 +397,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
   auto stage_piece = [&](int q, int kt_in_seg, int buf) {
     char* base = smem + buf * STAGE;
     if (q < IA) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(srcA[q] + (int64_t)kt_in_seg * 64),
-                                       (lds_void*)(base + (q * NW + w) * 1024), 16, 0, 0);
+      RF_BUF_LOAD_LDS(rsA, (lds_void*)(base + (q * NW + w) * 1024), offA[q], kt_in_seg * 128);
     } else {
-      __builtin_amdgcn_global_load_lds((glb_void*)(srcB[q - IA] + (int64_t)kt_in_seg * 64),
-                                       (lds_void*)(base + A_BYTES + ((q - IA) * NW + w) * 1024), 16, 0, 0);
+      RF_BUF_LOAD_LDS(rsB, (lds_void*)(base + A_BYTES + ((q - IA) * NW + w) * 1024), offB[q - IA], kt_in_seg * 128);
     }
   };
   auto stage = [&](int kt_in_seg, int buf) {
@@ -429,11 +446,29 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
   stage(kk, 0);
   advance();
 
+  // TL: s_memtime at three points per K-tile (before the drain, after it, after the barrier), summed per wave
+  unsigned long long t_a = 0, t_b = 0, t_c = 0, s_drain = 0, s_bar = 0, s_body = 0, t_start = 0;
+  if constexpr (TL) {
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
+    t_c = t_start;
+  }
   for (int kt = 0; kt < nk; ++kt) {
+    if constexpr (TL) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a)::"memory");
+      if (kt > 0) s_body += t_a - t_c;
+    }
     // explicit drain of this wave's LDS-DMA before the barrier: never rely on the compiler's own
     // vmcnt placement for LDS-DMA in a loop (see attention.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (TL) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b)::"memory");
     __syncthreads();  // tile kt has landed for every wave; every wave is done with tile kt-1
+    if constexpr (TL) {
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c)::"memory");
+      s_drain += t_b - t_a;
+      s_bar += t_c - t_b;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // The next tile's 8 LDS-DMA pieces are issued BEHIND the fragment reads of the first three k-steps rather than all
     // at once after the barrier: the matrix pipe restarts ~300 cycles earlier per K-tile (+5-10 %, measured; profiles/r01_gemm_variants.md)
     const bool more = kt + 1 < nk;
@@ -463,6 +498,15 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
     }
     if (more) advance();
   }
+  if constexpr (TL) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a)::"memory");
+    s_body += t_a - t_c;
+    if (tl != nullptr && lane == 0) {
+      tl[w * 8 + 0] = s_drain; tl[w * 8 + 1] = s_bar; tl[w * 8 + 2] = s_body; tl[w * 8 + 3] = t_a - t_start;
+      tl[w * 8 + 4] = (unsigned long long)nk;
+    }
+  }
 }
 
 // local tile id of a group -> (tm, tn).  Grouped raster: column bands of GW tiles; consecutive ids (= one XCD's
@@ -479,7 +523,7 @@ __device__ __forceinline__ void tile_coords(const int lt, const int tiles_m, con
 }
 
 // VEC: LDS-staged 16-byte epilogue (all pointers 16-byte aligned, N % 8 == 0) vs the per-element fallback
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC, bool TL = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
@@ -507,7 +551,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   const int nk = p.ksplit > 1 ? ((nk_all - kt_begin) < p.kchunk ? (nk_all - kt_begin) : p.kchunk) : nk_all;
 
   f32x16 acc[FM][FN];
-  gemm_mainloop<BM, BN, WM, WN>(G, p.N, m0, n0, kt_begin, nk, acc, smem, w, lane);
+  gemm_mainloop<BM, BN, WM, WN, TL>(G, p.N, m0, n0, kt_begin, nk, acc, smem, w, lane,
+                                    TL ? p.timeline + (int64_t)(blockIdx.x % 16) * 64 : nullptr);
 
   if constexpr (VEC) {
     static_assert(FN == 4, "LDS-staged epilogue expects 128-column wave strips");
@@ -516,6 +561,211 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   } else {
     gemm_epilogue<FM, FN>(p, G, acc, m0, n0, wm * TM, wn * TN, lane & 31, lane >> 5);
   }
+}
+
+// ---- ping-pong main loop (256x256x64 tile, 8 waves) -------------------------------------------------------
+// s_memtime timeline of the plain loop (tools/kb_timeline.py): the two waves of a SIMD do NOT share its matrix pipe
+// fairly -- the older wave wins every arbitration, finishes its K-tile at single-wave speed (~1590 cycles) and then
+// waits ~1000 cycles at the barrier while the younger one finishes alone at ~60 % duty: 2750 cycles per K-tile for
+// 2048 cycles of MFMA work.  Here the alternation is enforced: the 8 waves form two groups of 4 (one wave of each
+// group per SIMD) that run half a phase apart; while one group multiplies, the other reads fragments and issues DMA.
+// A K-tile is 4 phases; a phase multiplies one 32x64 quadrant of the wave's 64x128 tile over the whole BK=64:
+//     p0: read A0,B0 | Q(A0,B0)     p1: read A1 | Q(A1,B0)     p2: read B1 | Q(A1,B1)     p3: -- | Q(A0,B1)
+// The tile is staged as four 16 KiB half-tiles {A0, A1, B0, B1} (sub-block s of EVERY wave), so each half-tile is
+// read in exactly one phase and can be re-staged two phases later while its tile is still being multiplied:
+//     p0: stage A1(t+1)   p1: stage B1(t+1)   p2: stage A0(t+2)   p3: stage B0(t+2); s_waitcnt vmcnt(4)
+// Hazards (cdna_hip_programming.md, "256^2 8-phase template"): a staged half-tile is read >= 1 phase after the
+// counted vmcnt + barrier that retires it (the p3 wait leaves only the two newest half-tiles in flight, which are
+// first read a tile later); a half-tile is re-staged >= 2 phases after its last read.  vmcnt never drains to 0 in
+// steady state.  (A first build of this schedule with global_load_lds + 64-bit per-lane addresses lost 8 %: its
+// load phases were longer than the 256-cycle MFMA phases; buffer_load ... lds makes them fit.)
+__device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                                 const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
+  constexpr int HT = 128 * 128;  // half-tile bytes
+  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
+  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M;
+
+  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
+  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
+  const int r8 = lane >> 3;
+  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
+  uint32_t rowA[2][2], rowB[2][2];  // [sub-block][instr] -> global row of A / W (clamped)
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
+      rowA[sb][i] = (uint32_t)(gm < M ? gm : M - 1);
+      const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
+      rowB[sb][i] = (uint32_t)(gn < N ? gn : N - 1);
+    }
+
+  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
+  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t lda2, ldw2; };
+  auto load_seg = [&](Cur& c) {
+    const KSegDev& S = G.seg[c.seg];
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W); c.lda2 = (uint32_t)(S.lda * 2); c.ldw2 = (uint32_t)(S.ldw * 2);
+  };
+  auto next = [&](Cur& c) {
+    ++c.kk;
+    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+      c.kk = 0;
+      ++c.seg;
+      load_seg(c);
+    }
+  };
+  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](const int kind, const Cur& c, const int buf) {
+    char* dst = smem + buf * BUF + kind * HT + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), rowA[kind & 1][i] * c.lda2 + chunk_b, c.kk * 128);
+      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), rowB[kind & 1][i] * c.ldw2 + chunk_b, c.kk * 128);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a buffer
+  const int swz = (l31 >> 1) & 7;
+  const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
+  const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
+
+  Cur c1;
+  c1.seg = 0; c1.kk = kt_begin;
+  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
+    c1.kk -= G.seg[c1.seg].nk;
+    ++c1.seg;
+  }
+  load_seg(c1);
+  // prologue: tile 0 entirely, A0/B0 of tile 1
+  stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
+  next(c1);   // c1 -> tile 1
+  Cur c2 = c1;
+  if (nk > 1) {
+    stage(0, c1, 1); stage(2, c1, 1);
+    next(c2);  // c2 -> tile 2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  bf16x8 a0[4], a1[4], bq[2][4];
+  for (int t = 0; t < nk; ++t) {
+    const char* base = smem + (t & 1) * BUF;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- p0 -------------------------------------------------------------------------------
+    if (more1) stage(1, c1, (t + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((ks * 2 + h) ^ swz) << 4;
+      a0[ks] = *(const bf16x8*)(base + a_off + coff);
+      bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
+      bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[0][ks], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[1][ks], acc[0][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- p1 -------------------------------------------------------------------------------
+    if (more1) stage(3, c1, (t + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a1[ks] = *(const bf16x8*)(base + HT + a_off + (((ks * 2 + h) ^ swz) << 4));
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[0][ks], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[1][ks], acc[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- p2 -------------------------------------------------------------------------------
+    if (more2) stage(0, c2, t & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((ks * 2 + h) ^ swz) << 4;
+      bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
+      bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[0][ks], acc[1][2], 0, 0, 0);
+      acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[1][ks], acc[1][3], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- p3 -------------------------------------------------------------------------------
+    if (more2) {
+      stage(2, c2, t & 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but this tile's p2/p3 stages has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[0][ks], acc[0][2], 0, 0, 0);
+      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[1][ks], acc[0][3], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    next(c1);
+    next(c2);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
+}
+
+// one 256x256 tile per block, ping-pong main loop, LDS-staged epilogue (vec_ok launches only)
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  int tm, tn;
+  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  f32x16 acc[2][4];
+  gemm_mainloop_pp(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+  gemm_epilogue_lds<2>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
 }
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
@@ -691,12 +941,12 @@ static void layout_tiles(GemmParams& p) {
   p.total_tiles = start;
 }
 
-template <int BM, int BN, int WM, int WN, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC, bool TL = false>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
   constexpr int LDS = (VEC && LDS_EPI > LDS_MAIN) ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, VEC>;
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, VEC, TL>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -704,6 +954,21 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   layout_tiles<BM, BN>(p);
   if (p.total_tiles == 0) return RF_OK;
   hipLaunchKernelGGL(kern, dim3(p.total_tiles, p.ksplit > 1 ? p.ksplit : 1), dim3(WM * WN * 64), LDS, stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
+  constexpr int LDS_MAIN = 2 * 4 * 128 * 128, LDS_EPI = 8 * EPI_REGION;
+  constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  layout_tiles<256, 256>(p);
+  if (p.total_tiles == 0) return RF_OK;
+  hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
@@ -907,6 +1172,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
+  if (tile == 257 && !p.vec_ok) tile = 256;
   if (tile == 256 && p.vec_ok && g_force_sk != 0) {
     const int rc = try_launch_gemm_sk<256, 256, 4, 2>(p, ws_base, ws_total, stream);
     if (rc != 0) return rc < 0 ? rc : RF_OK;
@@ -935,7 +1201,8 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   }
   g_last_path = 0;
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
-  if (tile == 256) return p.vec_ok ? launch_gemm<256, 256, 4, 2, true>(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
+  if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (A/B reference)
+  if (tile == 256) return p.vec_ok ? launch_gemm_pp(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }
 
@@ -950,9 +1217,21 @@ extern "C" int rf_gemm_bf16(const rf_gemm_desc* d, void* stream) {
 
 // test / tuning hook (not part of the drop-in surface): force a tile config (0 = heuristic)
 extern "C" int rf_debug_force_gemm_tile(int tile) {
-  if (tile != 0 && tile != 128 && tile != 256) return RF_ERR_SHAPE;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return RF_ERR_SHAPE;
   rf::g_force_tile = tile;
   return RF_OK;
+}
+
+// debug: run the 256x256 tile-per-block kernel with s_memtime instrumentation; out = device u64[16 blocks][8 waves][8]
+// (per wave: cycles in the DMA drain, in the barrier, in the K-tile bodies, total, K-tiles) of blocks 0..15 (mod 16)
+extern "C" int rf_debug_gemm_timeline(const rf_gemm_desc* d, unsigned long long* out, void* stream) {
+  rf::GemmParams p;
+  int rc = rf::build_params(d, p);
+  if (rc != RF_OK) return rc;
+  RF_REQUIRE(p.vec_ok && out != nullptr, RF_ERR_ALIGN, "rf_debug_gemm_timeline: needs the aligned path and an output buffer");
+  p.timeline = out;
+  p.ksplit = 1;
+  return rf::launch_gemm<256, 256, 4, 2, true, true>(p, (hipStream_t)stream);
 }
 
 extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }

@@ -48,7 +48,7 @@ def assert_close(got, ref, what, rtol=1.2e-2, atol=None):
 
 
 # ------------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 128), (1000, 768, 512), (512, 64, 256), (1, 512, 256),
                                    (1024, 1536, 1024), (130, 100, 64), (513, 3076, 128)])
 def test_gemm_store(dev, tile, M, N, K):
@@ -75,7 +75,7 @@ def test_gemm_transpose_detecting(dev):
     assert torch.equal(y.float(), W.float().t())
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 def test_gemm_epilogues_and_segments(dev, tile):
     from reflectionflow_amd import _lib, ops
     from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, Group, Seg
@@ -133,7 +133,7 @@ def vt_unpermute(vt, S):
     return v.permute(0, 1, 3, 2).reshape(H, nt * 64, 128)[:, :S]
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 @pytest.mark.parametrize("St,Si,Sc", [(32, 64, 16), (30, 70, 13), (512, 256, 0)])
 def test_gemm_qkv_epilogues(dev, tile, St, Si, Sc):
     from reflectionflow_amd import _lib, ops
@@ -311,7 +311,7 @@ def test_errors_are_loud(dev):
         ops.linear(torch.zeros(4, 64, device=dev), torch.zeros(8, 64, device=dev))    # fp32
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 @pytest.mark.parametrize("St,Si,Sc", [(32, 64, 16), (30, 70, 13), (512, 320, 0)])
 def test_gemm_qkv_fused_norm_rope(dev, tile, St, Si, Sc):
     """QKV GEMM with per-head RMSNorm (text rows: added-norm weights) + RoPE fused into the epilogue
