@@ -13,7 +13,7 @@
              the only collective is the round-boundary all-gather of verifier scores (RCCL).
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-    roofline     -- the dominant kernel (the 256x256 bf16 MFMA GEMM, rf::gemm_bf16_kernel<256,256,4,2,true>): algorithmic FLOPs of all its
+    roofline     -- the dominant kernel (the 256x256 bf16 MFMA GEMM, rf::gemm_bf16_pp_kernel (256x256x64 ping-pong)): algorithmic FLOPs of all its
                     launches in one forward / their summed hipEvent-timed durations, vs 2.5 PFLOP/s.
     cpu_baseline -- the CPU oracle (a port of the reference path) timed on the host cores over a
                     bounded sample of the same workload, extrapolated and labelled as such.
@@ -129,7 +129,7 @@ def gemm_roofline(dev, S_txt, S_img, D, mlp, heads, nd, ns):
         traffic_src = ("profiles/r01_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; algorithmic "
                        f"{round(pj['_summary']['gemm_algorithmic_bytes_per_launch_avg'])} B/launch; MFMA busy "
                        f"{pj['_summary']['gemm_mfma_busy_pct_weighted']:.1f} % of SIMD-cycles at the sustained clock)")
-    return {"bound": "mfma", "kernel": "rf::gemm_bf16_kernel<256,256,4,2,true>", "achieved": round(ach, 1),
+    return {"bound": "mfma", "kernel": "rf::gemm_bf16_pp_kernel (256x256x64 ping-pong)", "achieved": round(ach, 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "launches_per_forward": n_launch, "avg_launch_us": round(tot_t / n_launch * 1e6, 1),

@@ -859,7 +859,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
     int lane_i = lane, tid_i = tid;
     asm volatile("" : "+v"(lane_i), "+v"(tid_i));
     f32x16 acc[FM][FN];
-    gemm_mainloop<BM, BN, WM, WN>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    gemm_mainloop_pp(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
 
     if (!is_tail) {
       // head or middle piece: raw accumulators -> this block's slot, [quad k][thread] x 16 B, as agent-coherent
