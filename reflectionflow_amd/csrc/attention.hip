@@ -6,7 +6,7 @@
 //
 // Design (DESIGN.md "K3"):
 //   * one workgroup = 4 waves x 32 query rows; the 64-key K tile [64][128] and V^T tile
-//     [128][64] are streamed HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), double buffered,
+//     [128][64] are streamed HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), double buffered,
 //     one barrier per tile; both images are XOR-swizzled through the DMA source address so the
 //     ds_read_b128 fragment reads are bank-conflict free;
 //   * scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_32x32x16_bf16 with A=K, B=Q):
@@ -22,8 +22,6 @@
 
 namespace rf {
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
 struct AttnParams {
   const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* out;
@@ -59,6 +57,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
   const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
+  // K / V^T tiles are staged with buffer_load_dwordx4 ... lds (SGPR resource + 32-bit per-lane offset): about half the
+  // issue cost of global_load_lds with 64-bit per-lane addresses (see gemm_bf16.hip / profiles/r01_gemm_variants.md)
+  const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q, h) holds d = ks*16 + h*8 .. +8 ---
   bf16x8 qf[8];
@@ -88,15 +89,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     for (int i = 0; i < 4; ++i) {
       int kv = kv0 + k_row[i];
       kv = kv < S ? kv : S - 1;
-      __builtin_amdgcn_global_load_lds((glb_void*)(Kh + (int64_t)kv * 128 + k_chunk[i]),
-                                       (lds_void*)(base + (i * 4 + w) * 1024), 16, 0, 0);
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(base + (i * 4 + w) * 1024), (uint32_t)(kv * 256 + k_chunk[i] * 2), 0);
     }
-    const bf16_t* vt = Vh + (int64_t)t * (128 * 64);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(vt + v_off[i]),
-                                       (lds_void*)(base + ATT_K_BYTES + (i * 4 + w) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(base + ATT_K_BYTES + (i * 4 + w) * 1024), (uint32_t)(v_off[i] * 2), t * (128 * 64 * 2));
   };
 
   // ---- per-lane bias for the two key regions (log2 domain) -------------------------------
@@ -271,6 +268,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
   const int nt = (S + ATT_KV - 1) / ATT_KV;
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
   const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
+  // K / V^T tiles are staged with buffer_load_dwordx4 ... lds (SGPR resource + 32-bit per-lane offset): about half the
+  // issue cost of global_load_lds with 64-bit per-lane addresses (see gemm_bf16.hip / profiles/r01_gemm_variants.md)
+  const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
   char* const kring = smem;
   char* const vring = smem + ATT2_NK * 16384;
 
@@ -296,16 +296,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
     for (int i = 0; i < 2; ++i) {
       int kv = t * ATT_KV + k_row[i];
       kv = kv < S ? kv : S - 1;
-      __builtin_amdgcn_global_load_lds((glb_void*)(Kh + (int64_t)kv * 128 + k_chunk[i]),
-                                       (lds_void*)(base + (i * 8 + w) * 1024), 16, 0, 0);
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(base + (i * 8 + w) * 1024), (uint32_t)(kv * 256 + k_chunk[i] * 2), 0);
     }
   };
   auto issue_v = [&](int t) {
     char* base = vring + (t % ATT2_NV) * 16384;
-    const bf16_t* vt = Vh + (int64_t)t * (128 * 64);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void*)(vt + v_off[i]), (lds_void*)(base + (i * 8 + w) * 1024), 16, 0, 0);
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(base + (i * 8 + w) * 1024), (uint32_t)(v_off[i] * 2), t * (128 * 64 * 2));
   };
 
   const float NEG_INF = -__builtin_huge_valf();

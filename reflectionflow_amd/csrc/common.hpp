@@ -20,6 +20,22 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 constexpr int WAVE = 64;
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// buffer-resource LDS-DMA (buffer_load_dwordx4 ... lds).  The resource type and builtins only exist in the device
+// pass; the host pass (which still instantiates the kernel templates to take their addresses) sees inert stand-ins.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define RF_MAKE_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7fffffff, 0x00020000)
+#define RF_BUF_LOAD_LDS(r, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0)
+#else
+typedef int rsrc_t;
+#define RF_MAKE_RSRC(p) 0
+#define RF_BUF_LOAD_LDS(r, lds, voff, soff) ((void)0)
+#endif
+
+
 // ---- error plumbing (thread-local message, never throws across the C ABI) -------------
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);

@@ -55,20 +55,7 @@ struct GemmParams {
 
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
 
-// buffer-resource LDS-DMA (buffer_load_dwordx4 ... lds).  The resource type and builtins only exist in the device
-// pass; the host pass (which still instantiates the kernel templates to take their addresses) sees inert stand-ins.
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-#define RF_MAKE_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7fffffff, 0x00020000)
-#define RF_BUF_LOAD_LDS(r, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0)
-#else
-typedef int rsrc_t;
-#define RF_MAKE_RSRC(p) 0
-#define RF_BUF_LOAD_LDS(r, lds, voff, soff) ((void)0)
-#endif
 
 // ---- shared epilogue ---------------------------------------------------------------------------
 // acc[i][j]: 32x32 MFMA accumulators of one wave; fragment (i,j) covers rows wrow0 + i*32 .. and
