@@ -473,3 +473,33 @@ def test_gemm_stream_k_qkv_fused(dev, force_sk):
         res.append((q.clone(), k.clone(), vt.clone()))
     for a, b, name in zip(res[0], res[1], "q k vt".split()):
         assert_close(a, b.float(), f"stream-K {name}", rtol=8e-3)
+
+
+# ------------------------------------------------------------------------------------- ping-pong loop edge cases
+@pytest.mark.parametrize("tile", [256, 257])
+@pytest.mark.parametrize("Ks", [(64,), (128,), (64, 64), (64, 128, 64), (192, 64), (64, 64, 64), (320, 64, 128), (1024, 128)])
+def test_gemm_k_segment_boundaries(dev, tile, Ks):
+    """K-tile counts 1..17 and every segment-boundary position of the staging cursors (the ping-pong loop stages tile
+    t+1 and t+2 from two cursors that may sit in different segments; its prologue/tail switch between counted and
+    draining vmcnt).  Ragged M and N, GELU epilogue, vs fp32; tile 257 = plain-loop twin, must agree bit for bit."""
+    from reflectionflow_amd import _lib, ops
+    lib = _lib.load()
+    M, N = 700, 1032
+    segs, ref = [], torch.zeros(M, N, device=dev)
+    for i, K in enumerate(Ks):
+        x, W = rnd(M, K, dev=dev, seed=3 * i + len(Ks)), rnd(N, K, dev=dev, scale=0.05, seed=3 * i + 1)
+        segs.append(ops.Seg(x, W))
+        ref += x.float() @ W.float().t()
+    b = rnd(N, dev=dev, seed=99)
+    ref = F.gelu(ref + b.float(), approximate="tanh")
+    outs = {}
+    for t in (tile, 256 + 257 - tile):
+        lib.rf_debug_force_gemm_tile(t)
+        try:
+            y = torch.empty(M, N, dtype=BF, device=dev)
+            ops.gemm([ops.Group(segs, bias=b, out=y)], N, ops.RF_EPI_GELU, splitk_ws=False)
+            outs[t] = y
+        finally:
+            lib.rf_debug_force_gemm_tile(0)
+    assert_close(outs[tile], ref, f"K segments {Ks}, tile {tile}")
+    assert torch.equal(outs[256], outs[257]), "ping-pong and plain loops disagree"
