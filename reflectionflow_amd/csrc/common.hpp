@@ -91,11 +91,12 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
 }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-  // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  // tanh(u) = 1 - 2 / (exp(2u) + 1); exp overflow -> inf -> tanh = 1 (correct limit)
-  const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  // F.gelu(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With 0.5 (1 + tanh(u)) =
+  // sigmoid(2u) this is x / (1 + exp(-2u)): one v_exp_f32 and one v_rcp_f32 (1 ulp) per element -- an IEEE division
+  // here compiled to a 10-instruction v_div_scale/fmas/fixup sequence in every GELU epilogue lane.
+  // exp overflow -> inf -> rcp = 0 -> x * 0 (the correct limit for x -> -inf).
+  const float z = x * (-2.3022082f - 0.1029432f * x * x);  // -2u * log2(e)
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
 }
 
 // XCD-aware, bijective block-id remap (8 XCDs, block b runs on XCD b % 8): give each XCD a
