@@ -503,3 +503,33 @@ def test_gemm_k_segment_boundaries(dev, tile, Ks):
             lib.rf_debug_force_gemm_tile(0)
     assert_close(outs[tile], ref, f"K segments {Ks}, tile {tile}")
     assert torch.equal(outs[256], outs[257]), "ping-pong and plain loops disagree"
+
+
+def test_gemm_stream_k_graph_replay(dev, force_sk):
+    """A stream-K launch leaves its flags as it found them (the single consumer of a partial resets its flag), so it
+    can be captured in a hipGraph and replayed: three back-to-back launches, replayed twice with fresh inputs."""
+    from reflectionflow_amd import ops
+    lib = force_sk
+    M, N, K = 1500, 2048, 2048
+    x, W = torch.empty(M, K, dtype=BF, device=dev), rnd(N, K, dev=dev, scale=0.05, seed=2)
+    outs = [torch.empty(M, N, dtype=BF, device=dev) for _ in range(3)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        x.copy_(rnd(M, K, dev=dev, seed=1))
+        ops.gemm([ops.Group([ops.Seg(x, W)], out=outs[0])], N)   # allocates this stream's scratch outside the capture
+        assert lib.rf_debug_last_gemm_path() == 2
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for o in outs:
+            ops.gemm([ops.Group([ops.Seg(x, W)], out=o)], N)
+    for seed in (5, 6):
+        xin = rnd(M, K, dev=dev, seed=seed)
+        x.copy_(xin)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = xin.float() @ W.float().t()
+        for o in outs:
+            assert_close(o, ref, f"graph replay, seed {seed}")
+            assert torch.equal(o, outs[0])

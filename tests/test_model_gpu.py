@@ -376,6 +376,23 @@ def test_full_flux_dev_forward_deterministic_and_matches_oracle(dev):
     torch.cuda.synchronize()
     assert all(torch.isfinite(o.float()).all() for o in outs)
     assert all(torch.equal(o, outs[0]) for o in outs[1:]), "kernel sequence is not deterministic run-to-run"
+    # a forward allocates nothing, never synchronises and only enqueues on the given stream, so it
+    # can be captured into a hipGraph and replayed; the replay must reproduce the eager result bit for bit
+    gout = torch.empty_like(lat)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.forward(lat, pe, mod, cos, sin, out=gout)          # warm the per-stream workspace outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        eng.forward(lat, pe, mod, cos, sin, out=gout)
+    for _ in range(2):
+        gout.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gout, outs[0]), "hipGraph replay of rf_flux_forward differs from the eager launch sequence"
+    del graph
     with torch.device(dev):
         om = O.FluxTransformer2DModel().float().eval()
     om.load_state_dict({k: v.float() for k, v in tr.state_dict().items()})
