@@ -965,28 +965,10 @@ constexpr int64_t WS_FLAG_BYTES = 4096;
 static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K (test introspection)
 static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = whenever feasible (tests)
 
-// stream-K launch of the 256x256 kernel; returns 1 if it launched, 0 if the shape does not qualify, < 0 on error
-template <int BM, int BN, int WM, int WN>
-static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStream_t stream) {
-  static int num_cus = 0;
-  if (num_cus == 0) {
-    int dev = 0;
-    RF_CHECK_HIP(hipGetDevice(&dev));
-    RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  const int P = num_cus / 8 * 8;  // one persistent block per CU, 8 XCD chunks
-  if (P < 8 || (int64_t)P * 4 > WS_FLAG_BYTES) return 0;
-  if (ws == nullptr || ws_bytes < WS_FLAG_BYTES + (int64_t)P * BM * BN * 4) return 0;
-  layout_tiles<BM, BN>(p);
+// stream-K work plan (pure host arithmetic; also reachable through rf_debug_sk_plan so the CPU tests can check its
+// invariants without a GPU).  Needs layout_tiles() done.  Returns 1 if the launch qualifies, 0 otherwise.
+static int sk_make_plan(const GemmParams& p, const int P, SkParams& sk) {
   const int T = p.total_tiles;
-  if (T == 0) return 0;
-  const int rounds = cdiv(T, P);
-  // Measured on MI355X (tools/kb_sk.py, profiles/r01_stream_k.md): the chip is power-limited (~1.39 kW at 1.87 GHz
-  // under this kernel), so a last round that leaves CUs idle costs less than its tile count suggests, while the
-  // stream-K region loses the lock-step L2 sharing of A/W panels.  Stream-K wins below ~83 % round utilisation
-  // (S=5632: 264 tiles +40..58 %, 792 tiles +9 %, 1056 tiles +5 %) and loses above it (S=4608: 0.84 -> -2..-10 %).
-  if (g_force_sk < 0 && (double)T / ((double)rounds * P) >= 0.83) return 0;
-  SkParams sk;
   memset(&sk, 0, sizeof(sk));
   int64_t I = 0;
   for (int g = 0; g < p.ngroups; ++g) {
@@ -1023,6 +1005,35 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
     if (sk.dp_rounds[x] > 0 && sk.chunk_end[x] - iter_of_tile(chunk_tile[x] + sk.dp_rounds[x] * PL) < PL * 8) --sk.dp_rounds[x];
     sk.sk_begin[x] = iter_of_tile(chunk_tile[x] + sk.dp_rounds[x] * PL);
     if (sk.chunk_end[x] - sk.sk_begin[x] < PL * 4) return 0;  // < 4 K-tiles per worker: not worth slicing
+  }
+  return 1;
+}
+
+// stream-K launch of the 256x256 kernel; returns 1 if it launched, 0 if the shape does not qualify, < 0 on error
+template <int BM, int BN, int WM, int WN>
+static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStream_t stream) {
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    RF_CHECK_HIP(hipGetDevice(&dev));
+    RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int P = num_cus / 8 * 8;  // one persistent block per CU, 8 XCD chunks
+  if (P < 8 || (int64_t)P * 4 > WS_FLAG_BYTES) return 0;
+  if (ws == nullptr || ws_bytes < WS_FLAG_BYTES + (int64_t)P * BM * BN * 4) return 0;
+  layout_tiles<BM, BN>(p);
+  const int T = p.total_tiles;
+  if (T == 0) return 0;
+  const int rounds = cdiv(T, P);
+  // Measured on MI355X (tools/kb_sk.py, profiles/r01_stream_k.md): the chip is power-limited (~1.39 kW at 1.87 GHz
+  // under this kernel), so a last round that leaves CUs idle costs less than its tile count suggests, while the
+  // stream-K region loses the lock-step L2 sharing of A/W panels.  Stream-K wins below ~83 % round utilisation
+  // (S=5632: 264 tiles +40..58 %, 792 tiles +9 %, 1056 tiles +5 %) and loses above it (S=4608: 0.84 -> -2..-10 %).
+  if (g_force_sk < 0 && (double)T / ((double)rounds * P) >= 0.83) return 0;
+  SkParams sk;
+  {
+    const int ok = sk_make_plan(p, P, sk);
+    if (ok != 1) return ok;
   }
   sk.flags = (int*)ws;
   sk.partials = (float*)((char*)ws + WS_FLAG_BYTES);
@@ -1219,6 +1230,29 @@ extern "C" int rf_debug_gemm_timeline(const rf_gemm_desc* d, unsigned long long*
   p.timeline = out;
   p.ksplit = 1;
   return rf::launch_gemm<256, 256, 4, 2, true, true>(p, (hipStream_t)stream);
+}
+
+// debug / CPU tests: the stream-K plan of a launch for a chip with num_cus CUs (no device access).
+// out[0..4] iter_start, [5..8] nk, [9..16] chunk_tile, [17..24] dp_rounds, [25..32] sk_begin, [33..40] chunk_end,
+// [41] tiles_n, [42..45] tiles_m per group, [46..49] tile_start per group, [50] total tiles.  Returns 1 = plan made,
+// 0 = launch does not qualify, < 0 error.
+extern "C" int rf_debug_sk_plan(const rf_gemm_desc* d, int32_t num_cus, int32_t* out) {
+  rf::GemmParams p;
+  int rc = rf::build_params(d, p);
+  if (rc != RF_OK) return rc;
+  RF_REQUIRE(out != nullptr && num_cus >= 8, RF_ERR_NULL, "rf_debug_sk_plan: bad arguments");
+  rf::layout_tiles<256, 256>(p);
+  if (p.total_tiles == 0) return 0;
+  rf::SkParams sk;
+  const int ok = rf::sk_make_plan(p, num_cus / 8 * 8, sk);
+  if (ok != 1) return ok;
+  for (int i = 0; i < 5; ++i) out[i] = sk.iter_start[i];
+  for (int i = 0; i < 4; ++i) out[5 + i] = sk.nk[i];
+  for (int i = 0; i < 8; ++i) { out[9 + i] = sk.chunk_tile[i]; out[17 + i] = sk.dp_rounds[i]; out[25 + i] = sk.sk_begin[i]; out[33 + i] = sk.chunk_end[i]; }
+  out[41] = p.tiles_n;
+  for (int i = 0; i < 4; ++i) { out[42 + i] = i < p.ngroups ? p.g[i].tiles_m : 0; out[46 + i] = i < p.ngroups ? p.g[i].tile_start : 0; }
+  out[50] = p.total_tiles;
+  return 1;
 }
 
 extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }
