@@ -533,3 +533,31 @@ def test_gemm_stream_k_graph_replay(dev, force_sk):
         for o in outs:
             assert_close(o, ref, f"graph replay, seed {seed}")
             assert torch.equal(o, outs[0])
+
+
+def test_gemm_pingpong_cold_cache_stress(dev):
+    """Hazard screen for the ping-pong loop's counted-vmcnt schedule: with operands that are cold in L2 / Infinity
+    Cache (a 1.5 GiB flush between launches) the LDS-DMA pieces arrive late and out of step, which is when a read
+    placed too early after its wait would show.  Fresh inputs every round; the plain loop (one drain + barrier per
+    K-tile) is the bit-exact reference."""
+    from reflectionflow_amd import _lib, ops
+    lib = _lib.load()
+    M, N, K = 4608, 3072, 6144
+    flush = torch.empty(3 << 28, dtype=torch.float32, device=dev)  # 3 GiB > 256 MiB Infinity Cache
+    try:
+        for it in range(8):
+            x, W = rnd(M, K, dev=dev, seed=200 + it), rnd(N, K, dev=dev, scale=0.05, seed=300 + it)
+            b, gate, res = rnd(N, dev=dev, seed=it), rnd(N, dev=dev, seed=it + 50), rnd(M, N, dev=dev, seed=it + 70)
+            outs = []
+            for tile in (256, 257, 256):
+                lib.rf_debug_force_gemm_tile(tile)
+                flush.fill_(float(it))
+                y = torch.empty(M, N, dtype=BF, device=dev)
+                ops.gemm([ops.Group([ops.Seg(x, W)], bias=b, out=y, residual=res, gate=gate)], N, ops.RF_EPI_GATE_RES, splitk_ws=False)
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1]), f"round {it}: ping-pong loop differs from the plain loop on cold operands"
+            assert torch.equal(outs[0], outs[2]), f"round {it}: ping-pong loop is not reproducible on cold operands"
+    finally:
+        lib.rf_debug_force_gemm_tile(0)
+        del flush
+        torch.cuda.empty_cache()
