@@ -258,6 +258,26 @@ int rf_flux_denoise(const rf_flux_dims* dims, const rf_flux_model* m,
  * shape with hipEvents on `stream`; returns average microseconds in *us. */
 int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
 
+/* In-sequence timing hook (bench.py's `roofline`): between rf_profile_begin and rf_profile_end every kernel the
+ * library launches is bracketed by a hipEvent pair on ITS launch stream, so the durations are those of the
+ * kernels inside the real 57-block sequence (cold operands, real neighbours), not of isolated re-launches.
+ * rf_profile_end synchronises, then fills, per rf_kernel_class: summed duration (us), launch count and summed
+ * algorithmic work (FLOPs: 2MNK per GEMM over all groups and K-segments, 4*S^2*128*heads per attention launch;
+ * BYTES read+written for the row kernels).  `dropped` = launches beyond max_launches (not timed).
+ * Not thread-safe, not for use during hipGraph capture; costs two event records per launch while open. */
+typedef enum rf_kernel_class {
+  RF_KC_GEMM_MAIN = 0,   /* 256x256-tile MFMA GEMM launches (tile-per-block ping-pong loop and stream-K) */
+  RF_KC_GEMM_SMALL = 1,  /* 128x128-tile launches (embedders, LoRA down-projections incl. split-K + reduce) */
+  RF_KC_ATTN = 2,        /* rf_attention_fwd */
+  RF_KC_ROWOP = 3,       /* LayerNorm+modulate, RMSNorm+RoPE, Euler, SiLU, add */
+  RF_KC_GEMM_W8 = 4,     /* fp8-weight GEMM launches (rf_gemm_w8a8) */
+  RF_KC_QUANT = 5,       /* activation quantisation row kernels of the fp8 path */
+  RF_KC_COUNT = 6
+} rf_kernel_class;
+int rf_profile_begin(int32_t max_launches);
+int rf_profile_end(double* us_sum /*[RF_KC_COUNT]*/, int64_t* launches /*[RF_KC_COUNT]*/,
+                   double* work_sum /*[RF_KC_COUNT]*/, int32_t* dropped /* may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

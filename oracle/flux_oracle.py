@@ -779,9 +779,33 @@ def condition_ids_for(cond_size: int, position_delta=None, dtype=torch.float32):
 @torch.no_grad()
 def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_inference_steps,
             guidance_scale=3.5, condition_latents=None, condition_ids=None, model_config=None,
-            image_hw=None, scheduler=None, callback=None, conditioning_dtype=None):
+            image_hw=None, scheduler=None, callback=None, conditioning_dtype=None,
+            image_guidance_scale=1.0, condition_scale=1.0):
     """generate.py:193-299 with output_type='latent' (the T-step hot loop + Euler step).
-    `conditioning_dtype`: see tranformer_forward (default None = exact restatement)."""
+    `conditioning_dtype`: see tranformer_forward (default None = exact restatement).
+    `condition_scale` != 1: every `*.attn` module gets `c_factor` for the duration of the call
+    (generate.py:86-90, removed again :312-316).
+    `image_guidance_scale` != 1: the second forward of generate.py:250-272 with guidance = 1 and the
+    "unconditional" condition tokens -- which the reference's Condition.encode(empty=True) overwrites with the
+    REAL condition's tokens (condition.py:114-121), so both passes see the same condition latents."""
+    if condition_scale != 1:
+        for name, module in transformer.named_modules():                     # :86-90
+            if name.endswith(".attn"):
+                module.c_factor = torch.ones(1, 1) * condition_scale
+    try:
+        return _denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_inference_steps,
+                        guidance_scale, condition_latents, condition_ids, model_config, image_hw, scheduler,
+                        callback, conditioning_dtype, image_guidance_scale)
+    finally:
+        if condition_scale != 1:
+            for name, module in transformer.named_modules():                 # :312-316
+                if name.endswith(".attn"):
+                    del module.c_factor
+
+
+def _denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_inference_steps, guidance_scale,
+             condition_latents, condition_ids, model_config, image_hw, scheduler, callback, conditioning_dtype,
+             image_guidance_scale):
     scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
     B, S_i, _ = latents.shape
     dtype, device = prompt_embeds.dtype, latents.device
@@ -801,15 +825,17 @@ def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_infer
             guidance = torch.tensor([guidance_scale], device=device).expand(latents.shape[0])
         else:
             guidance = None
-        noise_pred = tranformer_forward(
-            transformer, model_config=model_config,
-            condition_latents=condition_latents if use_condition else None,
-            condition_ids=condition_ids if use_condition else None,
-            condition_type_ids=None, hidden_states=latents, timestep=timestep / 1000,
-            guidance=guidance, pooled_projections=pooled_prompt_embeds,
-            encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
-            joint_attention_kwargs=None, return_dict=False,
-            conditioning_dtype=conditioning_dtype)[0]                        # :230-248
+        common = dict(model_config=model_config,
+                      condition_latents=condition_latents if use_condition else None,
+                      condition_ids=condition_ids if use_condition else None,
+                      condition_type_ids=None, hidden_states=latents, timestep=timestep / 1000,
+                      pooled_projections=pooled_prompt_embeds,
+                      encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_image_ids,
+                      joint_attention_kwargs=None, return_dict=False, conditioning_dtype=conditioning_dtype)
+        noise_pred = tranformer_forward(transformer, guidance=guidance, **common)[0]          # :230-248
+        if image_guidance_scale != 1.0:                                      # :250-272
+            unc_pred = tranformer_forward(transformer, guidance=torch.ones_like(guidance), **common)[0]
+            noise_pred = unc_pred + image_guidance_scale * (noise_pred - unc_pred)
         latents = scheduler.step(noise_pred, t, latents, return_dict=False)[0]   # :276
         if callback is not None:
             callback(i, t, latents)

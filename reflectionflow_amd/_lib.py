@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 
@@ -101,7 +101,11 @@ _SIGS = {
     "rf_flux_denoise": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_flux_model), _P, _P, _P, _P, C.c_int64, _P,
                                   _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.POINTER(rf_workspace), _P]),
     "rf_time_gemm": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
+    "rf_profile_begin": (C.c_int, [C.c_int32]),
+    "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_int32)]),
 }
+RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant")
 # test / tuning hook, not part of the declared drop-in surface
 _EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
                "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_last_gemm_path": (C.c_int, []),

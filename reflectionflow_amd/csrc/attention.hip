@@ -499,6 +499,7 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
   }
   hipStream_t st = (hipStream_t)stream;
   const bool pre = q_prescaled != 0;
+  ProfScope prof(RF_KC_ATTN, 4.0 * (double)S * (double)S * 128.0 * heads, st);
   if (use_v2) {
     const dim3 grid2(heads * cdiv(S, 256)), blk(512);
     const bool generic = !(mode == 0 && S % 64 == 0);

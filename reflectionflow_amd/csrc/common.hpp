@@ -56,6 +56,17 @@ int hip_fail(hipError_t e, const char* what);
 
 #define RF_LAUNCH_CHECK() RF_CHECK_HIP(hipGetLastError())
 
+// kernel-class timing hook (rf_profile_begin / rf_profile_end): a no-op unless a profile is open
+struct ProfScope {
+  ProfScope(int cls, double work, hipStream_t s);
+  ~ProfScope();
+  ProfScope(const ProfScope&) = delete;
+  ProfScope& operator=(const ProfScope&) = delete;
+ private:
+  int idx_;
+  hipStream_t s_;
+};
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -20,6 +20,7 @@
 //     W = scaling*lora_B) without materialising a concat or a merged weight;
 //   * blockIdx is remapped so that every XCD works on a contiguous chunk of tiles (private L2).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace rf {
 
@@ -965,6 +966,20 @@ constexpr int64_t WS_FLAG_BYTES = 4096;
 static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K (test introspection)
 static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = whenever feasible (tests)
 
+// The stream-K launch relies on two properties HIP does not promise: lower-indexed blocks are dispatched first and
+// block b runs on XCD b % 8 (observed on MI355X in SPX mode; a wrong guess about the XCD costs speed only, but a
+// partition mode that breaks dispatch order could make a consumer wait on a block that is not resident).  It is
+// therefore enabled only on the device it was verified on (gfx950 with 256 CUs = MI355X SPX) and can be switched
+// off with RF_DISABLE_STREAMK=1; everything then runs one tile per block.
+static bool streamk_allowed(int num_cus) {
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("RF_DISABLE_STREAMK");
+    env = (e != nullptr && e[0] != '\0' && e[0] != '0') ? 1 : 0;
+  }
+  return env == 0 && num_cus == 256;
+}
+
 // stream-K work plan (pure host arithmetic; also reachable through rf_debug_sk_plan so the CPU tests can check its
 // invariants without a GPU).  Needs layout_tiles() done.  Returns 1 if the launch qualifies, 0 otherwise.
 static int sk_make_plan(const GemmParams& p, const int P, SkParams& sk) {
@@ -1018,6 +1033,7 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
     RF_CHECK_HIP(hipGetDevice(&dev));
     RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
+  if (!streamk_allowed(num_cus) && g_force_sk != 1) return 0;
   const int P = num_cus / 8 * 8;  // one persistent block per CU, 8 XCD chunks
   if (P < 8 || (int64_t)P * 4 > WS_FLAG_BYTES) return 0;
   if (ws == nullptr || ws_bytes < WS_FLAG_BYTES + (int64_t)P * BM * BN * 4) return 0;
@@ -1113,6 +1129,11 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
       RF_REQUIRE(ks.A && ks.W, RF_ERR_NULL, "rf_gemm_bf16: group %d segment %d A/W NULL", g, k);
       RF_REQUIRE(aligned16(ks.A) && aligned16(ks.W) && ks.lda % 8 == 0 && ks.ldw % 8 == 0, RF_ERR_ALIGN,
                  "rf_gemm_bf16: group %d segment %d operands must be 16-byte aligned", g, k);
+      // the LDS-DMA addresses operands as buffer resource (num_records 2^31-1) + 32-bit byte offset: the last byte any
+      // lane can touch must stay inside that window, or the hardware range check silently returns zeros
+      RF_REQUIRE(((int64_t)s.M - 1) * ks.lda * 2 + (int64_t)ks.K * 2 < 0x7fffffffll &&
+                     ((int64_t)d->N - 1) * ks.ldw * 2 + (int64_t)ks.K * 2 < 0x7fffffffll,
+                 RF_ERR_SHAPE, "rf_gemm_bf16: group %d segment %d operand spans >= 2 GiB (32-bit buffer offsets)", g, k);
       KSegDev& kd = t.seg[ns++];  // compact: empty segments are dropped
       kd.A = (const bf16_t*)ks.A; kd.lda = ks.lda; kd.W = (const bf16_t*)ks.W; kd.ldw = ks.ldw; kd.nk = ks.K / 64;
     }
@@ -1162,6 +1183,10 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
     const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
     tile = (t256 >= 200) ? 256 : 128;
   }
+  double flops = 0.0;  // algorithmic: 2 M N K over groups and K-segments
+  for (int g = 0; g < p.ngroups; ++g)
+    flops += 2.0 * p.g[g].M * (double)p.N * 64.0 * (p.g[g].seg[0].nk + p.g[g].seg[1].nk + p.g[g].seg[2].nk);
+  ProfScope prof(tile >= 256 ? RF_KC_GEMM_MAIN : RF_KC_GEMM_SMALL, flops, stream);
   // split-K: a plain-store, single-group GEMM with a handful of tiles and a long K (LoRA down-projection:
   // [S_cond x K] . [r_pad x K]^T = 8 tiles x up to 240 K-tiles) would run on 8 of 256 CUs.  Slice K over
   // blockIdx.y, >= 4 K-tiles per slice, ~256 blocks in flight, fp32 partials in caller-owned scratch.

@@ -171,6 +171,7 @@ extern "C" int rf_layernorm_modulate(const void* x, int64_t ldx, void* out, int6
              RF_ERR_ALIGN, "rf_layernorm_modulate: operands must be 16-byte aligned");
   const dim3 grid(cdiv(rows, 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, 4.0 * rows * (double)D, s);  // bytes: one bf16 row in, one out
   const int nch = cdiv(D, 512);
 #define RF_LN_CASE(N)                                                                                          \
   case N:                                                                                                      \
@@ -199,6 +200,7 @@ extern "C" int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, in
   const int64_t rows = (int64_t)2 * heads * S;
   int64_t blocks = (rows + 15) / 16;
   if (blocks > 256 * 16) blocks = 256 * 16;
+  ProfScope prof(RF_KC_ROWOP, (double)rows * 128.0 * 4.0, (hipStream_t)stream);
   hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)q, (bf16_t*)k,
                      heads, S, s_pad, n_added, (const bf16_t*)w_q, (const bf16_t*)w_k, (const bf16_t*)w_added_q,
                      (const bf16_t*)w_added_k, cos_tab, sin_tab, eps);
@@ -211,6 +213,7 @@ extern "C" int rf_euler_step(void* x, const void* v, int64_t n, float dt, void* 
   if (n <= 0) return RF_OK;
   RF_REQUIRE(x && v, RF_ERR_NULL, "rf_euler_step: NULL pointer");
   RF_REQUIRE(aligned16(x) && aligned16(v), RF_ERR_ALIGN, "rf_euler_step: operands must be 16-byte aligned");
+  ProfScope prof(RF_KC_ROWOP, 6.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
                      (const bf16_t*)v, n, dt);
   RF_LAUNCH_CHECK();
@@ -221,6 +224,7 @@ extern "C" int rf_silu(const void* x, void* out, int64_t n, void* stream) {
   using namespace rf;
   if (n <= 0) return RF_OK;
   RF_REQUIRE(x && out, RF_ERR_NULL, "rf_silu: NULL pointer");
+  ProfScope prof(RF_KC_ROWOP, 4.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                      (bf16_t*)out, n);
   RF_LAUNCH_CHECK();
@@ -232,6 +236,7 @@ extern "C" int rf_add_inplace(void* out, const void* x, int64_t n, void* stream)
   if (n <= 0) return RF_OK;
   RF_REQUIRE(x && out, RF_ERR_NULL, "rf_add_inplace: NULL pointer");
   RF_REQUIRE(aligned16(x) && aligned16(out), RF_ERR_ALIGN, "rf_add_inplace: operands must be 16-byte aligned");
+  ProfScope prof(RF_KC_ROWOP, 6.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out,
                      (const bf16_t*)x, n);
   RF_LAUNCH_CHECK();

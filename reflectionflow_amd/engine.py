@@ -59,6 +59,34 @@ def _fused_lora(linears) -> Optional[Tuple[torch.Tensor, torch.Tensor, int]]:
     return _pad_lora(A, B)
 
 
+# Modules the engine has a LoRA K-segment (or a modulation-table term) for.  enable_lora() gating in the reference
+# (lora_controller.py:5-42; call sites block.py:23,185,148-155,252-259,288-296,319-322, transformer.py:91) covers
+# exactly the `gated` kinds: there LoRA acts on condition rows always and on image/text rows iff latent_lora.
+# LoRA on norm1_context.linear / norm_out.linear is never gated by the reference (no enable_lora around them):
+# always on.  Any other LoRA'd linear (add_*_proj, to_add_out, ff.net.0.proj, ff_context.*, context_embedder,
+# proj_out, time_text_embed.* -- reachable with PEFT `target_modules: all-linear`, train/model.py:73) has no
+# segment here and would be silently ignored, so packing refuses it.
+_LORA_GATED = (r"x_embedder", r"transformer_blocks\.\d+\.norm1\.linear", r"transformer_blocks\.\d+\.attn\.to_[qkv]",
+               r"transformer_blocks\.\d+\.attn\.to_out\.0", r"transformer_blocks\.\d+\.ff\.net\.2",
+               r"single_transformer_blocks\.\d+\.norm\.linear", r"single_transformer_blocks\.\d+\.proj_mlp",
+               r"single_transformer_blocks\.\d+\.proj_out", r"single_transformer_blocks\.\d+\.attn\.to_[qkv]")
+_LORA_ALWAYS = (r"transformer_blocks\.\d+\.norm1_context\.linear", r"norm_out\.linear")
+
+
+def check_lora_placement(transformer=None, names=None) -> None:
+    """Raise RFError if a LoraLinear sits (or, given `names`, would be put) on a module the HIP engine cannot
+    apply it for."""
+    import re
+    ok = re.compile("^(?:" + "|".join(_LORA_GATED + _LORA_ALWAYS) + ")$")
+    if names is None:
+        names = [n for n, m in transformer.named_modules() if isinstance(m, M.LoraLinear)]
+    bad = [n for n in names if not ok.match(n)]
+    if bad:
+        raise ops.RFError("LoRA on modules the HIP engine has no K-segment for (it would be silently dropped): "
+                          f"{bad[:6]}{' ...' if len(bad) > 6 else ''}; supported: the FLUX-Corrector target list "
+                          "(train_flux/config.yaml:53) plus norm1_context.linear / norm_out.linear")
+
+
 class _Packed:
     """A C weights struct plus the tensors its pointers refer to (kept alive together)."""
 
@@ -153,7 +181,9 @@ def make_dims(D: int, heads: int, mlp: int, S_txt: int, S_img: int, S_cond: int 
     return d
 
 
-_WS_CACHE: Dict[tuple, torch.Tensor] = {}
+_WS_CACHE: "Dict[tuple, torch.Tensor]" = {}
+_WS_CACHE_MAX = 4     # geometries x streams kept alive; least-recently-used entries are dropped (a long search
+                      # walks few geometries at a time: plain round, conditioned round, maybe a second resolution)
 
 
 def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
@@ -161,12 +191,16 @@ def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
     stream (calls on different streams may overlap on the device, so they must not share scratch)."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, d.D, d.heads, d.mlp, d.S_txt, d.S_img, d.S_cond,
            d.lora_on_main)
-    buf = _WS_CACHE.get(key)
+    buf = _WS_CACHE.pop(key, None)
     if buf is None:
         n = int(L.load().rf_workspace_bytes(C.byref(d)))
+        while len(_WS_CACHE) >= _WS_CACHE_MAX:
+            # evict the least recently used workspace; work already enqueued on its stream keeps the memory alive
+            # through the caching allocator's stream-ordered reuse (the buffer was allocated on that stream)
+            _WS_CACHE.pop(next(iter(_WS_CACHE)))
         # zero-filled: padded key rows of V^T must be finite (they are multiplied by p = 0)
         buf = torch.zeros(n, dtype=torch.uint8, device=device)
-        _WS_CACHE[key] = buf
+    _WS_CACHE[key] = buf          # (re-)insert at the most-recently-used end
     ws = L.rf_workspace()
     ws.base, ws.bytes = buf.data_ptr(), buf.numel()
     return ws
@@ -191,6 +225,7 @@ class FluxEngine:
     # ------------------------------------------------------------------ packing
     def _pack(self):
         tr = self.tr
+        check_lora_placement(tr)
         nd, ns = len(tr.transformer_blocks), len(tr.single_transformer_blocks)
         self._dbl = (L.rf_double_block_weights * max(nd, 1))()
         self._sgl = (L.rf_single_block_weights * max(ns, 1))()
@@ -217,12 +252,15 @@ class FluxEngine:
         self.model = m
         self.mod_cols = int(self.lib.rf_mod_table_cols(C.byref(m), self.D))
         # AdaLN linears in table order: per double block [norm1 (img) | norm1_context (txt)], singles, norm_out
-        self._mod_linears = []
+        self._mod_linears, self._mod_always = [], []      # _mod_always[i]: LoRA not gated by enable_lora in the reference
         for b in tr.transformer_blocks:
             self._mod_linears += [b.norm1.linear, b.norm1_context.linear]
+            self._mod_always += [False, True]
         for b in tr.single_transformer_blocks:
             self._mod_linears.append(b.norm.linear)
+            self._mod_always.append(False)
         self._mod_linears.append(tr.norm_out.linear)
+        self._mod_always.append(True)
         self._mod_lora = [(_pad_lora(*l.lora_factors()) if isinstance(l, M.LoraLinear) else None)
                           for l in self._mod_linears]
 
@@ -253,17 +291,19 @@ class FluxEngine:
         return te(timestep, guidance, pooled) if guidance is not None else te(timestep, pooled)
 
     def mod_table(self, temb: torch.Tensor, lora: bool = False) -> torch.Tensor:
-        """[M, D] conditioning rows -> [M, mod_cols] modulation table (all AdaLN linears)."""
+        """[M, D] conditioning rows -> [M, mod_cols] modulation table (all AdaLN linears).
+        `lora`: apply the enable_lora-gated LoRA terms (norm1.linear / norm.linear: condition rows, or
+        latent_lora); LoRA on norm1_context.linear / norm_out.linear is un-gated in the reference and always applied."""
         if temb.dim() != 2 or temb.shape[1] != self.D:
             raise ops.RFError("mod_table: temb must be [M, D]")
         s = ops.silu(temb.to(torch.bfloat16).contiguous())
         table = torch.empty(s.shape[0], self.mod_cols, dtype=torch.bfloat16, device=self.device)
         col = 0
-        for lin, lo in zip(self._mod_linears, self._mod_lora):
+        for lin, lo, always in zip(self._mod_linears, self._mod_lora, self._mod_always):
             base = _base(lin)
             n = base.out_features
             extra = []
-            if lora and lo is not None:
+            if (lora or always) and lo is not None:
                 A, B, _ = lo
                 extra = [ops.Seg(ops.linear(s, A), B)]
             ops.linear(s, base.weight, base.bias, extra=extra, out=table[:, col:col + n])
@@ -321,5 +361,10 @@ def engine_for(transformer) -> FluxEngine:
 
 
 def invalidate(transformer):
+    """Drop every cached packed-weight copy: the engine AND the per-block caches the public
+    block_forward / single_block_forward use (they hold concatenated qkv / fused weight copies)."""
     if hasattr(transformer, "_rf_engine"):
         object.__delattr__(transformer, "_rf_engine")
+    for b in list(getattr(transformer, "transformer_blocks", [])) + list(getattr(transformer, "single_transformer_blocks", [])):
+        if hasattr(b, "_rf_packed"):
+            object.__delattr__(b, "_rf_packed")

@@ -56,7 +56,6 @@ class FluxPipeline:
         self.vae_scale_factor = 8
         self.default_sample_size = 128
         self.interrupt = False
-        self.joint_attention_kwargs = None
         self._joint_attention_kwargs = None
         self._guidance_scale = 3.5
         self._progress = {}
@@ -82,7 +81,14 @@ class FluxPipeline:
                 f"no local FLUX checkpoint at {tdir!r} (no network here). Use FluxPipeline.synthetic() for "
                 "random-init weights of the same architecture.")
         from safetensors.torch import load_file
-        tr = M.FluxTransformer2DModel().to(torch_dtype)
+        # diffusers layout: transformer/config.json carries the architecture (FluxTransformer2DModel.__init__ kwargs);
+        # absent -> FLUX.1-dev
+        cfg, cfg_path = {}, os.path.join(tdir, "config.json")
+        if os.path.exists(cfg_path):
+            import json
+            raw = json.load(open(cfg_path))
+            cfg = {k: (tuple(raw[k]) if k == "axes_dims_rope" else raw[k]) for k in M.FLUX_DEV_CONFIG if k in raw}
+        tr = M.FluxTransformer2DModel(**cfg).to(torch_dtype)
         sd = {}
         for f in sorted(os.listdir(tdir)):
             if f.endswith(".safetensors"):
@@ -110,6 +116,12 @@ class FluxPipeline:
     _execution_device = device
 
     @property
+    def joint_attention_kwargs(self):
+        """diffusers exposes the kwargs of the running call as a read-only property; generate() sets the
+        private attribute (reference generate.py:139) and the per-step path reads this one (:243)."""
+        return self._joint_attention_kwargs
+
+    @property
     def dtype(self):
         return self.transformer.dtype
 
@@ -128,6 +140,7 @@ class FluxPipeline:
         else:
             sd = dict(path_or_state_dict)
         pat = re.compile(r"^(?:transformer\.)?(.+)\.lora_A(?:\.[^.]+)?\.weight$")
+        E.check_lora_placement(names=[pat.match(k).group(1) for k in sd if pat.match(k)])   # before touching the model
         n = 0
         for key in sorted(sd):
             m = pat.match(key)
@@ -153,9 +166,6 @@ class FluxPipeline:
         if n == 0:
             raise ValueError("no `*.lora_A.weight` keys found in the LoRA state dict")
         E.invalidate(self.transformer)
-        for b in list(self.transformer.transformer_blocks) + list(self.transformer.single_transformer_blocks):
-            if hasattr(b, "_rf_packed"):
-                object.__delattr__(b, "_rf_packed")
         return n
 
     def set_adapters(self, *a, **k):

@@ -16,11 +16,35 @@ from . import _lib as L
 from ._lib import (RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, RF_EPI_STORE, RFError)
 
 __all__ = ["linear", "gemm", "build_gemm_desc", "time_gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
-           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError", "QK_PRESCALE"]
+           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError", "QK_PRESCALE", "profile"]
 
 
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+class profile:
+    """`with ops.profile(max_launches) as pr:` -- every library kernel launched inside is timed by a hipEvent
+    pair on its own launch stream (rf_profile_begin / rf_profile_end).  After the block, `pr.classes` maps
+    kernel class -> {"launches", "us", "work"} (work = algorithmic FLOPs, bytes for row kernels)."""
+
+    def __init__(self, max_launches: int = 4096):
+        self.max_launches, self.classes, self.dropped = max_launches, {}, 0
+
+    def __enter__(self):
+        L.check(L.load().rf_profile_begin(self.max_launches), "rf_profile_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        n = len(L.RF_KC_NAMES)
+        us, cnt, work, dropped = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), C.c_int32(0)
+        rc = L.load().rf_profile_end(us, cnt, work, C.byref(dropped))
+        if et is None:
+            L.check(rc, "rf_profile_end")
+        self.dropped = dropped.value
+        self.classes = {name: {"launches": int(cnt[i]), "us": float(us[i]), "work": float(work[i])}
+                        for i, name in enumerate(L.RF_KC_NAMES) if cnt[i] > 0}
+        return False
 
 
 def _chk(t: torch.Tensor, name: str, dtype=torch.bfloat16):

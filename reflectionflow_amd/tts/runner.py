@@ -99,12 +99,19 @@ def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: F
 
 def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
                           start_index: int = 0, verifier=search.stub_verifier) -> List[dict]:
+    """Reflection rounds.  Deliberate deviation from tts_reflectionflow.py:314-322: the reference's `generate`
+    call passes neither `latents`, `num_inference_steps` nor `guidance_scale` (so its defaults -- 28 steps,
+    guidance 3.5, noise from the global RNG -- apply and the `get_noises` seeds only name files, SURVEY 8a quirks);
+    here the config's steps/guidance and the per-candidate seeded noise ARE passed, so that a candidate is a pure
+    function of (prompt, round, index) and results do not depend on the world size.  Each prompt's
+    `search_log.jsonl` holds that prompt's rounds only; the return value is the concatenation over prompts."""
     pa, sa, model_cfg = config["pipeline_args"], config["search_args"], config.get("model", {})
     dev, dtype = pipe.device, pipe.dtype
     N, topk = sa["search_branch"], max(1, sa.get("topk", 1))
-    log = []
+    all_logs: List[dict] = []
     for index, prompt in enumerate(prompts):
         pdir = os.path.join(output_dir, f"{index + start_index:0>5}")
+        log: List[dict] = []                                                    # this prompt's rounds only
         kept: List[torch.Tensor] = []                                           # selected latents, identical on every rank
         for rnd in range(0, sa["search_rounds"] + 1):
             seeds = candidate_seeds(index + start_index, rnd, N)
@@ -133,7 +140,9 @@ def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pip
                 kept.append(lat)
             log.append({"prompt": prompt, "round": rnd, "seeds": seeds, "scores": scores, "selected": sel})
         if shard.rank == 0:
+            os.makedirs(pdir, exist_ok=True)
             with open(os.path.join(pdir, "search_log.jsonl"), "w") as f:
                 for r in log:
                     f.write(json.dumps(r) + "\n")
-    return log
+        all_logs += log
+    return all_logs

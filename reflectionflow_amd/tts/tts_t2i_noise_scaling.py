@@ -1,50 +1,10 @@
 #!/usr/bin/env python3
-"""MI355X counterpart of the reference's tts/tts_t2i_noise_scaling.py (same CLI flags; see runner.py for what is and is
-not carried over).  Launch one process per GPU:
-
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        -m reflectionflow_amd.tts.tts_t2i_noise_scaling --pipeline_config_path <json> --meta_path <jsonl> --output_dir out
-"""
-import argparse
-import json
-import os
-
-import torch
-
-from . import runner, search
+"""MI355X counterpart of the reference's tts/tts_t2i_noise_scaling.py: entry point of cli.main("noise_scaling")."""
+from .cli import main as _main, parse_cli_args  # noqa: F401
 
 
-def parse_cli_args():
-    p = argparse.ArgumentParser()
-    here = os.path.dirname(os.path.abspath(__file__))
-    p.add_argument("--pipeline_config_path", type=str, default=os.path.join(here, "configs", "flux1_dev_mi355x.json"))
-    p.add_argument("--start_index", type=int, default=0)
-    p.add_argument("--end_index", type=int, default=-1)
-    p.add_argument("--imgpath", type=str, default="")
-    p.add_argument("--output_dir", type=str, default="output")
-    p.add_argument("--meta_path", type=str, default="meta.jsonl")
-    p.add_argument("--synthetic", action="store_true", help="random-init FLUX.1-dev-shaped weights (no checkpoint offline)")
-    p.add_argument("--small", action="store_true", help="with --synthetic: 2+2-block model for plumbing tests")
-    return p.parse_args()
-
-
-@torch.no_grad()
-def main():
-    args = parse_cli_args()
-    with open(args.pipeline_config_path) as f:
-        config = json.load(f)
-    config.update(vars(args))
-    shard = search.init_distributed()
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    with open(args.meta_path) as fp:
-        metadatas = [json.loads(line) for line in fp]
-    metadatas = metadatas[args.start_index:] if args.end_index == -1 else metadatas[args.start_index:args.end_index]
-    pipe = runner.build_pipeline(config, dev, synthetic=args.synthetic, small=args.small)
-    prompts = [m["prompt"] for m in metadatas]
-    os.makedirs(args.output_dir, exist_ok=True)
-    fn = runner.run_noise_scaling if "tts_t2i_noise_scaling" == "tts_t2i_noise_scaling" else runner.run_reflection_search
-    fn(config, prompts, args.output_dir, pipe, shard, start_index=args.start_index)
+def main(argv=None):
+    return _main("noise_scaling", argv)
 
 
 if __name__ == "__main__":

@@ -369,6 +369,19 @@ def gen_loop(geom):
         eq(b, a, f"generate loop [{key}]")
         out[f"final_{key}"] = a
         out[f"traj_{key}"] = torch.stack(traj)
+        if use_c:
+            # round 2: the two product branches the tts scripts leave at their defaults -- image-CFG second
+            # forward (generate.py:250-272) and condition_scale -> attn.c_factor (generate.py:86-90,312-316)
+            for tag, kw in (("imgcfg", dict(image_guidance_scale=1.5)), ("cscale", dict(condition_scale=1.5))):
+                a = RG.generate(pipe, conditions=[_FixedCondition(cond, cond_ids)], model_config=cfg,
+                                default_lora=True, height=H, width=W, num_inference_steps=T, guidance_scale=3.5,
+                                latents=lat.clone(), prompt_embeds=pe, pooled_prompt_embeds=pooled,
+                                output_type="latent", **kw).images
+                b = O.denoise(m, lat.clone(), pe, pooled, T, guidance_scale=3.5, condition_latents=cond,
+                              condition_ids=cond_ids, model_config=cfg, image_hw=(s["gh"], s["gw"]), **kw)
+                eq(b, a, f"generate loop [cond, {tag}]")
+                assert not any(hasattr(mod, "c_factor") for mod in m.modules()), "c_factor must be removed again"
+                out[f"final_cond_{tag}"] = a
     save(f"loop_{geom}", **out)
 
 

@@ -137,3 +137,72 @@ def test_config_schema_and_pipeline_surface():
         assert hasattr(pipe, attr), attr
     with pytest.raises(ValueError):
         pipe.check_inputs("p", None, 100, 64)
+
+
+def test_checkpoint_and_lora_files_load_unchanged(tmp_path):
+    """INTEGRATION.md's claim, end to end on files: a diffusers-layout checkpoint directory
+    (`transformer/config.json` + `*.safetensors` with diffusers key names) and a FLUX-Corrector style
+    `pytorch_lora_weights.safetensors` (keys `transformer.<module>.lora_{A,B}.weight`, written by
+    FluxPipeline.save_lora_weights in the reference's train/model.py:87-92) load through
+    `FluxPipeline.from_pretrained` / `.load_lora_weights(path, adapter_name=)` exactly as the tts scripts call
+    them (tts_reflectionflow.py:498-505) and reproduce every tensor bit for bit."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from reflectionflow_amd import engine as E
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.flux.pipeline import FluxPipeline, lora_target_names, synthetic_lora_state_dict
+    from tests.golden_util import GEOMS
+    cfg = dict(GEOMS["hd128"])
+    src = M.FluxTransformer2DModel(**cfg).to(torch.bfloat16)
+    M.init_synthetic_(src, seed=4)
+    root = tmp_path / "ckpt"
+    os.makedirs(root / "transformer")
+    json.dump({**{k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()},
+               "_class_name": "FluxTransformer2DModel"}, open(root / "transformer" / "config.json", "w"))
+    sd = {k: v.contiguous() for k, v in src.state_dict().items()}
+    keys = sorted(sd)
+    half = len(keys) // 2                                   # two shards, like the real checkpoint
+    save_file({k: sd[k] for k in keys[:half]}, str(root / "transformer" / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({k: sd[k] for k in keys[half:]}, str(root / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    # diffusers key names are the attribute paths of SURVEY 8b
+    for k in ("transformer_blocks.0.attn.to_q.weight", "transformer_blocks.1.norm1.linear.weight",
+              "transformer_blocks.0.ff.net.0.proj.weight", "transformer_blocks.0.ff.net.2.weight",
+              "single_transformer_blocks.1.proj_mlp.weight", "time_text_embed.timestep_embedder.linear_1.weight",
+              "transformer_blocks.0.attn.norm_added_q.weight", "norm_out.linear.bias", "x_embedder.weight"):
+        assert k in sd, k
+    pipe = FluxPipeline.from_pretrained(str(root), torch_dtype=torch.bfloat16)
+    got = pipe.transformer.state_dict()
+    assert sorted(got) == keys and all(torch.equal(got[k], sd[k]) for k in keys)
+    assert pipe.transformer.config.num_layers == cfg["num_layers"]
+    # LoRA file
+    lora = synthetic_lora_state_dict(pipe.transformer, r=8, seed=2)
+    ldir = tmp_path / "corrector"
+    os.makedirs(ldir)
+    save_file({k: v.contiguous() for k, v in lora.items()}, str(ldir / "pytorch_lora_weights.safetensors"))
+    n = pipe.load_lora_weights(str(ldir), adapter_name="reflection")
+    assert n == len(lora_target_names(pipe.transformer)) == len(lora) // 2
+    mods = dict(pipe.transformer.named_modules())
+    for name in lora_target_names(pipe.transformer):
+        m = mods[name]
+        assert isinstance(m, M.LoraLinear) and m.active_adapters == ["reflection"] and m.scaling["reflection"] == 1.0
+        assert torch.equal(m.lora_A["reflection"].weight, lora[f"transformer.{name}.lora_A.weight"])
+        assert torch.equal(m.lora_B["reflection"].weight, lora[f"transformer.{name}.lora_B.weight"])
+        assert torch.equal(m.base_layer.weight, sd[name + ".weight"])
+    # a LoRA file that targets a module the engine has no K-segment for is refused, not silently dropped
+    bad = {"transformer.transformer_blocks.0.attn.add_q_proj.lora_A.weight": torch.zeros(8, 256, dtype=torch.bfloat16),
+           "transformer.transformer_blocks.0.attn.add_q_proj.lora_B.weight": torch.zeros(256, 8, dtype=torch.bfloat16)}
+    with pytest.raises(E.ops.RFError, match="no K-segment"):
+        pipe.load_lora_weights(bad)
+
+
+def test_joint_attention_kwargs_scale_is_not_silently_ignored():
+    """pipeline.joint_attention_kwargs must reflect the running call so the `scale != 1 unsupported`
+    guard in tranformer_forward can fire."""
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.flux.pipeline import FluxPipeline
+    from tests.golden_util import GEOMS
+    pipe = FluxPipeline(M.FluxTransformer2DModel(**GEOMS["hd128"]))
+    assert pipe.joint_attention_kwargs is None
+    pipe._joint_attention_kwargs = {"scale": 0.5}
+    assert pipe.joint_attention_kwargs == {"scale": 0.5}

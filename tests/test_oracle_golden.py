@@ -98,6 +98,14 @@ def test_generate_loop(geom):
         key = "cond" if use_c else "nocond"
         close(b, z[f"final_{key}"], f"final[{key}]")
         close(torch.stack(traj), z[f"traj_{key}"], f"traj[{key}]")
+        if use_c:
+            # image-CFG second forward (generate.py:250-272) and condition_scale -> c_factor (generate.py:86-90)
+            for tag, kw in (("imgcfg", dict(image_guidance_scale=1.5)), ("cscale", dict(condition_scale=1.5))):
+                b = O.denoise(m, T(z["lat"]).clone(), T(z["pe"]), T(z["pooled"]), 4, guidance_scale=3.5,
+                              condition_latents=T(z["cond"]), condition_ids=T(z["cond_ids"]), model_config=cfg,
+                              image_hw=(s["gh"], s["gw"]), **kw)
+                close(b, z[f"final_cond_{tag}"], f"final[cond,{tag}]")
+                assert not torch.equal(b, T(z["final_cond"])), f"{tag} must change the result"
 
 
 def test_schedule_fixture_and_formulae():

@@ -56,3 +56,96 @@ def test_two_rank_round_equals_single_rank():
     for rank, sel, scores in got:
         assert sel == ref_sel, f"rank {rank} selected {sel}, single-process {ref_sel}"
         assert scores == pytest.approx(ref_scores)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the multi-rank branch of run_reflection_search: candidate sharding + score all-gather + the BROADCAST of the
+# selected latents to every rank (runner.py), with generate() replaced by a deterministic CPU stand-in so the
+# control flow runs without a GPU.  Two ranks must log exactly what one rank logs and hold identical `kept` latents.
+def _fake_generate(pipe, prompt=None, conditions=None, latents=None, **kw):
+    from reflectionflow_amd.flux.pipeline import FluxPipelineOutput
+    x = latents.float() * 0.5
+    if conditions:
+        x = x + conditions[0].tokens.float().mean()
+    return FluxPipelineOutput(images=x.to(latents.dtype))
+
+
+class _FakePipe:
+    device, dtype, vae, image_processor = torch.device("cpu"), torch.float32, None, None
+
+
+def _search_cfg():
+    return {"pipeline_args": dict(height=64, width=64, condition_size=32, num_inference_steps=2, guidance_scale=3.5),
+            "search_args": dict(search_branch=5, search_rounds=2, topk=2), "model": {}}
+
+
+def _run_search(shard, out_dir):
+    from reflectionflow_amd.tts import runner
+    seen = []
+    orig_gen, orig_l2c = runner.generate, runner.latent_to_condition
+
+    def l2c(latents, h, w, cs):
+        seen.append(latents.clone())
+        return orig_l2c(latents, h, w, cs)
+    runner.generate, runner.latent_to_condition = _fake_generate, l2c
+    try:
+        log = runner.run_reflection_search(_search_cfg(), ["p0", "p1"], out_dir, _FakePipe(), shard)
+    finally:
+        runner.generate, runner.latent_to_condition = orig_gen, orig_l2c
+    return log, seen
+
+
+def _search_worker(rank, world, port, q, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    shard = search.init_distributed("gloo")
+    log, seen = _run_search(shard, out_dir)
+    q.put((rank, log, [s.sum().item() for s in seen]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_reflection_search_two_ranks_broadcast_handoff(tmp_path):
+    import json
+    ref_log, ref_seen = _run_search(search.Shard(0, 1), str(tmp_path / "single"))
+    assert [r["round"] for r in ref_log] == [0, 1, 2, 0, 1, 2]
+    # per-prompt log files hold that prompt's rounds only (round-1 bug: prompt k's file also held prompts < k)
+    for i in range(2):
+        rows = [json.loads(l) for l in open(tmp_path / "single" / f"{i:05d}" / "search_log.jsonl")]
+        assert [r["round"] for r in rows] == [0, 1, 2] and all(r["prompt"] == f"p{i}" for r in rows)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_search_worker, args=(r, 2, port, q, str(tmp_path / "dist"))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=150) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, log, seen in got:
+        assert log == ref_log, f"rank {rank}: 2-rank search log differs from the single-rank one"
+    # every rank conditions ITS candidates on the broadcast latents: the union over ranks of the latents seen by
+    # latent_to_condition equals the single-rank sequence (candidate i -> kept[i % len(kept)])
+    all_seen = sorted(x for _, _, seen in got for x in seen)
+    assert all_seen == pytest.approx(sorted(s.sum().item() for s in ref_seen))
+
+
+@pytest.mark.timeout(180)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher must start 2 ranks itself and print ONE JSON line from rank 0
+    (the driver calls it exactly like that); --launch-check swaps the GPU work for the score exchange over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["launch_check"] is True and j["selected_candidate"] == 3
