@@ -224,6 +224,7 @@ def cpu_baseline(S_txt, S_img, T, D=3072, heads=24, nd=19, ns=38):
     from oracle import flux_oracle as O
     model, cores, logical = host_cpu()
     torch.set_num_threads(cores)
+    t_begin = time.perf_counter()
     with torch.no_grad():
         m = O.FluxTransformer2DModel(num_layers=1, num_single_layers=1, num_attention_heads=heads,
                                       attention_head_dim=D // heads).float().eval()
@@ -237,9 +238,18 @@ def cpu_baseline(S_txt, S_img, T, D=3072, heads=24, nd=19, ns=38):
         xe = torch.cat([e, x], 1)
         O.block_forward(dbl, x, e, None, temb, None, image_rotary_emb=rope)              # warm-up (cold: ~4x slower)
         O.single_block_forward(sgl, xe, temb, image_rotary_emb=rope)
-        t0 = time.perf_counter()
-        O.block_forward(dbl, x, e, None, temb, None, image_rotary_emb=rope)
-        td = time.perf_counter() - t0
+        # torch's CPU GEMMs do not scale to every core of a big host (128 threads measured SLOWER than 32 on these
+        # shapes): take the best of a few thread counts, and say which
+        best = None
+        for n in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 16)}, reverse=True):
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            O.block_forward(dbl, x, e, None, temb, None, image_rotary_emb=rope)
+            td_n = time.perf_counter() - t0
+            if best is None or td_n < best[1]:
+                best = (n, td_n)
+        threads, td = best
+        torch.set_num_threads(threads)
         t0 = time.perf_counter()
         O.single_block_forward(sgl, xe, temb, image_rotary_emb=rope)
         ts = time.perf_counter() - t0
@@ -248,21 +258,31 @@ def cpu_baseline(S_txt, S_img, T, D=3072, heads=24, nd=19, ns=38):
         m.single_transformer_blocks = nn.ModuleList([sgl] * ns)
         lat = O.get_noises([0], 256, 256, dtype=torch.float32)[0]
         pe, pooled = torch.randn(1, S_txt, 4096, generator=g), torch.randn(1, 768, generator=g)
+        # bounded sample: all 4 steps when one probe step says they fit ~40 s, else 1 step timed and x4 stated
         t0 = time.perf_counter()
-        out = O.denoise(m, lat, pe, pooled, 4, image_hw=(16, 16))
-        t_cfg1 = time.perf_counter() - t0
+        out = O.denoise(m, lat, pe, pooled, 1, image_hw=(16, 16))
+        t_step = time.perf_counter() - t0
+        steps_timed = 1
+        if 4 * t_step <= 40.0:
+            t0 = time.perf_counter()
+            out = O.denoise(m, lat, pe, pooled, 4, image_hw=(16, 16))
+            t_cfg1, steps_timed = time.perf_counter() - t0, 4
+        else:
+            t_cfg1 = 4 * t_step
         assert torch.isfinite(out).all()
     per_latent = T * (nd * td + ns * ts)
     f1 = flops_per_forward(S_txt, 256, D, 4 * D, nd, ns)[0] * 4
-    return {"value": 1.0 / per_latent, "unit": "latents/s", "cores": cores, "kind": "port",
-            "cpu_model": model, "logical_cpus": logical, "threads": cores,
-            "sample": f"oracle fp32 on {cores} physical cores ({model}); after one warm-up call each: 1 DoubleStream "
+    return {"value": 1.0 / per_latent, "unit": "latents/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "physical_cores": cores, "logical_cpus": logical, "threads": threads,
+            "sample": f"oracle fp32, {threads} threads (best of a sweep up to the {cores} physical cores of {model}); after one warm-up call each: 1 DoubleStream "
                       f"({td:.2f} s) + 1 SingleStream ({ts:.2f} s) block at S={S_txt + S_img}, D={D}; extrapolated "
                       f"x({nd},{ns}) blocks x {T} steps = {per_latent:.0f} s/latent",
             "extrapolated": True,
             "cfg1_end_to_end": {"workload": "BASELINE cfg1: 256x256, 4 Euler steps, fp32, N=1 (weights of one block "
                                             "instance per kind reused over depth)", "seconds": round(t_cfg1, 2),
-                                "latents_per_s": round(1.0 / t_cfg1, 5), "tflops": round(f1 / t_cfg1 / 1e12, 3)}}
+                                "steps_timed": steps_timed, "extrapolated": steps_timed != 4,
+                                "latents_per_s": round(1.0 / t_cfg1, 5), "tflops": round(f1 / t_cfg1 / 1e12, 3)},
+            "wall_s_spent": round(time.perf_counter() - t_begin, 1)}
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -132,10 +132,17 @@ int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad
  *         block.py:115-122); 2 = mask (main<->cond) blocks (union_cond_attn=False, block.py:106-114)
  *   q_prescaled: 0 = scores are scaled by `scale` here; 1 = q already carries scale*log2(e)
  *         (rf_gemm_desc.q_scale), `scale` is ignored.
+ *   score_bound: 0 = unknown (online softmax with a running row maximum).  > 0: the caller GUARANTEES
+ *         |q.k * scale * log2(e)| <= score_bound for every query/key pair.  FLUX RMS-normalises q and k per head
+ *         (block.py:38-41,60-67), so sqrt(128) * max|norm_q.weight| * max|norm_k.weight| * log2(e) is such a bound
+ *         whatever the activations are (rf_*_block_weights.qk_bound).  With a bound <= 100, no bias/mask, S % 64 == 0
+ *         and a prescaled q the library runs the bounded-score kernel: softmax is shift invariant, so P = exp2(s)
+ *         needs no running maximum, no exchange and no rescaling of O (bf16 P / fp32 O,l have the exponent range).
+ *         A violated guarantee gives inf/NaN -- pass 0 when in doubt.
  * ---------------------------------------------------------------------------------- */
 int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                      int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
-                     float cross_bias, float scale, int32_t q_prescaled, void* stream);
+                     float cross_bias, float scale, int32_t q_prescaled, float score_bound, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm(no affine, eps) + (1+scale)*x + shift, row-wise over D
@@ -176,6 +183,9 @@ typedef struct rf_double_block_weights {   /* FluxTransformerBlock, SURVEY Appen
   const void *w_ffc1, *b_ffc1;         /* ff_context.net.0.proj */
   const void *w_ffc2, *b_ffc2;         /* ff_context.net.2 */
   rf_lora_seg lora_qkv, lora_out, lora_ff2;   /* FLUX-Corrector LoRA (config.yaml:53) */
+  float qk_bound;                      /* proven bound on |score * log2 e| from the four norm weights (see
+                                          rf_attention_fwd score_bound); 0 = none */
+  int32_t _pad;
 } rf_double_block_weights;
 
 typedef struct rf_single_block_weights {   /* FluxSingleTransformerBlock, Appendix A.3 */
@@ -183,6 +193,8 @@ typedef struct rf_single_block_weights {   /* FluxSingleTransformerBlock, Append
   const void *norm_q, *norm_k;
   const void *w_out, *b_out;           /* proj_out [D x 5D]: columns [0,D) attn, [D,5D) mlp */
   rf_lora_seg lora_qkv_mlp, lora_out;
+  float qk_bound;                      /* as in rf_double_block_weights */
+  int32_t _pad;
 } rf_single_block_weights;
 
 typedef struct rf_flux_dims {

@@ -200,7 +200,7 @@ class FluxSingleTransformerBlock(nn.Module):
 
 def get_1d_rotary_pos_embed(dim: int, pos: torch.Tensor, theta: float = 10000.0):
     """Appendix A.6 (use_real=True, repeat_interleave_real=True, freqs float64)."""
-    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: (dim // 2)] / dim))
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64, device=pos.device)[: (dim // 2)] / dim))
     freqs = torch.outer(pos.to(torch.float64), freqs)
     freqs_cos = freqs.cos().repeat_interleave(2, dim=1).float()
     freqs_sin = freqs.sin().repeat_interleave(2, dim=1).float()

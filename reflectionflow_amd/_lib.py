@@ -50,12 +50,13 @@ class rf_double_block_weights(C.Structure):
         "w_qkv", "b_qkv", "w_add_qkv", "b_add_qkv", "norm_q", "norm_k", "norm_added_q", "norm_added_k",
         "w_out", "b_out", "w_add_out", "b_add_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
         "w_ffc1", "b_ffc1", "w_ffc2", "b_ffc2")] + [
-        ("lora_qkv", rf_lora_seg), ("lora_out", rf_lora_seg), ("lora_ff2", rf_lora_seg)]
+        ("lora_qkv", rf_lora_seg), ("lora_out", rf_lora_seg), ("lora_ff2", rf_lora_seg),
+        ("qk_bound", C.c_float), ("_pad", C.c_int32)]
 
 
 class rf_single_block_weights(C.Structure):
     _fields_ = [(n, _P) for n in ("w_qkv_mlp", "b_qkv_mlp", "norm_q", "norm_k", "w_out", "b_out")] + [
-        ("lora_qkv_mlp", rf_lora_seg), ("lora_out", rf_lora_seg)]
+        ("lora_qkv_mlp", rf_lora_seg), ("lora_out", rf_lora_seg), ("qk_bound", C.c_float), ("_pad", C.c_int32)]
 
 
 class rf_flux_dims(C.Structure):
@@ -85,7 +86,7 @@ _SIGS = {
     "rf_qk_rmsnorm_rope": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
                                      C.c_float, _P]),
     "rf_attention_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
-                                   C.c_float, C.c_float, C.c_int32, _P]),
+                                   C.c_float, C.c_float, C.c_int32, C.c_float, _P]),
     "rf_layernorm_modulate": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, _P]),
     "rf_euler_step": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "rf_silu": (C.c_int, [_P, _P, C.c_int64, _P]),
@@ -108,6 +109,7 @@ _SIGS = {
 RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant")
 # test / tuning hook, not part of the declared drop-in surface
 _EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
+               "rf_debug_attn_v4": (C.c_int, [C.c_int]),
                "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_gemm_timeline": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_void_p, C.c_void_p]),
                "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)])}

@@ -171,7 +171,7 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
   // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE: fused into the QKV epilogue above
   // 4. joint attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, St + Si, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
-                          0.08838834764831845f /* 1/sqrt(128) */, /*q_prescaled=*/1, st));
+                          0.08838834764831845f /* 1/sqrt(128) */, /*q_prescaled=*/1, w->qk_bound, st));
   // 5. output projections + gated residual: x += gate_msa * proj(attn)
   {
     rf_gemm_desc d;
@@ -312,7 +312,7 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
   // 3. RMSNorm(q,k) + RoPE: fused into the epilogue above (no added-norm rows in single blocks)
   // 4. attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, Sm, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
-                          0.08838834764831845f, /*q_prescaled=*/1, st));
+                          0.08838834764831845f, /*q_prescaled=*/1, w->qk_bound, st));
   // 5. proj_out over cat([attn, mlp]) as two K segments + gated residual
   {
     rf_gemm_desc d;

@@ -138,6 +138,8 @@ def pack_double_block(b, refresh: bool = False) -> _Packed:
     pk.lora(w.lora_qkv, qkv)
     pk.lora(w.lora_out, [a.to_out[0]])
     pk.lora(w.lora_ff2, [b.ff.net[2]])
+    # |score| bound from the norm weights alone: lets attention skip the online softmax (rf_attention_fwd score_bound)
+    w.qk_bound = ops.qk_score_bound((a.norm_q.weight, a.norm_added_q.weight), (a.norm_k.weight, a.norm_added_k.weight))
     pk.D, pk.heads, pk.mlp = a.to_q.in_features, a.heads, b.ff.net[0].proj.out_features
     object.__setattr__(b, "_rf_packed", pk)
     return pk
@@ -159,6 +161,7 @@ def pack_single_block(b, refresh: bool = False) -> _Packed:
     w.w_out, w.b_out = pk.k(_base(b.proj_out).weight), pk.k(_base(b.proj_out).bias)
     pk.lora(w.lora_qkv_mlp, fused)
     pk.lora(w.lora_out, [b.proj_out])
+    w.qk_bound = ops.qk_score_bound((a.norm_q.weight,), (a.norm_k.weight,))
     pk.D, pk.heads, pk.mlp = a.to_q.in_features, a.heads, b.proj_mlp.out_features
     object.__setattr__(b, "_rf_packed", pk)
     return pk

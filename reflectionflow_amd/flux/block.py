@@ -95,6 +95,9 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
             mode, bias = 1, math.log(cf)
         elif not model_config.get("union_cond_attn", True):
             mode = 2
+    # the per-head RMSNorm bounds every score by the norm weights alone (ops.qk_score_bound)
+    bound = ops.qk_score_bound((attn.norm_q.weight,) + ((attn.norm_added_q.weight,) if has_txt else ()),
+                               (attn.norm_k.weight,) + ((attn.norm_added_k.weight,) if has_txt else ()))
     outs = []
     for b in range(B):
         q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
@@ -115,7 +118,8 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
         # QKV projections with per-head RMSNorm + RoPE fused into the epilogue
         ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin),
                  q_scale=ops.QK_PRESCALE)
-        outs.append(ops.attention(q, k, vt, S, n_main=St + Si, mode=mode, cross_bias=bias, q_prescaled=True))
+        outs.append(ops.attention(q, k, vt, S, n_main=St + Si, mode=mode, cross_bias=bias, q_prescaled=True,
+                                  score_bound=bound))
     hs = torch.stack(outs, 0)                                           # [B, S, D]
 
     if has_txt:

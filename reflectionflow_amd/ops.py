@@ -209,8 +209,20 @@ def qk_rmsnorm_rope(q, k, S: int, n_added: int, w_q, w_k, w_added_q, w_added_k, 
 QK_PRESCALE = (1.0 / math.sqrt(128.0)) * 1.4426950408889634   # softmax scale * log2(e), folded into q by the QKV GEMM
 
 
+def qk_score_bound(*norm_weights_qk) -> float:
+    """Proven bound on |q.k / sqrt(128)| * log2(e) for per-head RMS-normalised q and k (block.py:38-41,60-67):
+    |RMSNorm(x) * w| <= sqrt(128) max|w|, and RoPE is a rotation, so |q.k| <= 128 max|w_q| max|w_k|.
+    Arguments: (q weights..., ) and (k weights..., ) as two tuples/lists of tensors; 2 % margin for the bf16
+    rounding of q and k."""
+    wq, wk = norm_weights_qk
+    mq = max(float(w.detach().abs().max()) for w in wq)
+    mk = max(float(w.detach().abs().max()) for w in wk)
+    return 1.02 * math.sqrt(128.0) * mq * mk * 1.4426950408889634
+
+
 def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
-              cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False) -> torch.Tensor:
+              cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False,
+              score_bound: float = 0.0) -> torch.Tensor:
     lib = L.load()
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     heads, s_pad = q.shape[0], q.shape[1]
@@ -221,7 +233,7 @@ def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Opti
         scale = 1.0 / math.sqrt(128.0)
     L.check(lib.rf_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), heads, S, s_pad,
                                  out.stride(0), S if n_main is None else n_main, mode, cross_bias, scale,
-                                 1 if q_prescaled else 0, stream_ptr()), "rf_attention_fwd")
+                                 1 if q_prescaled else 0, float(score_bound), stream_ptr()), "rf_attention_fwd")
     return out
 
 

@@ -69,7 +69,7 @@ def test_argument_validation_is_loud(lib):
     assert lib.rf_gemm_bf16(C.byref(d), None) == -1 and b"multiple of 64" in lib.rf_last_error()
     d.g[0].seg[0].K = 64                                        # NULL operands
     assert lib.rf_gemm_bf16(C.byref(d), None) == -3
-    assert lib.rf_attention_fwd(None, None, None, None, 2, 64, 64, 256, 64, 0, 0.0, 1.0, 0, None) == -3
+    assert lib.rf_attention_fwd(None, None, None, None, 2, 64, 64, 256, 64, 0, 0.0, 1.0, 0, 0.0, None) == -3
     assert lib.rf_layernorm_modulate(1 << 4, 64, 1 << 4, 64, 2, 60, 1 << 4, 1 << 4, 1e-6, None) == -1   # D % 8
     dims = _lib.rf_flux_dims()
     dims.D, dims.heads, dims.mlp, dims.S_txt, dims.S_img = 256, 2, 1024, 32, 64

@@ -295,10 +295,11 @@ def test_reflection_search_runner_small(dev, tmp_path):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("St,Si,Sc", [(512, 4096, 0), (512, 4096, 1024)])
+@pytest.mark.parametrize("St,Si,Sc", [(512, 4096, 0), (512, 4096, 1024), (512, 16384, 1024)], ids=["cfg2", "cfg4", "cfg5"])
 def test_full_size_blocks_vs_oracle_on_gpu(dev, St, Si, Sc):
-    """BASELINE cfg2 / cfg4 token counts at FLUX.1-dev width (D=3072, 24 heads): one DoubleStream and one
-    SingleStream block through the HIP path vs the fp32 oracle evaluated on the same GPU."""
+    """BASELINE cfg2 / cfg4 / cfg5 (2048^2 + 512^2 condition: S = 17920) token counts at FLUX.1-dev width (D=3072,
+    24 heads): one DoubleStream and one SingleStream block through the HIP path vs the fp32 oracle evaluated on the
+    same GPU.  (Whole-model versions of all three: tests/test_fullsize_gpu.py.)"""
     from reflectionflow_amd.flux import modules as M
     from reflectionflow_amd.flux.block import block_forward, single_block_forward
     D, H = 3072, 24
@@ -349,58 +350,3 @@ def test_full_size_blocks_vs_oracle_on_gpu(dev, St, Si, Sc):
         e_ = rel_l2(a, b)
         print(f"  single/{name}: rel-L2 {e_:.3e}")
         assert e_ < 8e-3, f"single/{name}: rel-L2 {e_:.3e}"
-
-
-@torch.no_grad()
-def test_full_flux_dev_forward_deterministic_and_matches_oracle(dev):
-    """The whole FLUX.1-dev-shaped transformer (19 double + 38 single blocks, 11.9 B random-init params) at
-    the BASELINE cfg2 size (512 text + 4096 image tokens): HIP forward vs the fp32 oracle evaluated on the same
-    GPU, and bitwise run-to-run determinism of the kernel sequence (this is the test that exposes a missing
-    LDS-DMA wait: such races only show with cold caches inside the real sequence, not in isolated kernels)."""
-    import bench
-    from reflectionflow_amd import engine as E
-    pipe = bench.build_model(dev, {}, seed=0)
-    tr = pipe.transformer
-    eng = E.engine_for(tr)
-    gen = torch.Generator().manual_seed(1)
-    St, Si = 512, 4096
-    pe = torch.randn(St, 4096, generator=gen).to(dev).to(BF)
-    pooled = torch.randn(1, 768, generator=gen).to(dev).to(BF)
-    lat = torch.randn(Si, 64, generator=gen).to(dev).to(BF)
-    img_ids, txt_ids = O.prepare_latent_image_ids(64, 64), torch.zeros(St, 3)
-    t, gd = torch.tensor([0.5], device=dev), torch.tensor([4.0], device=dev)      # exact in bf16 after x1000
-    temb = eng.temb(t.to(BF) * 1000, gd.to(BF) * 1000, pooled)
-    mod = eng.mod_table(temb)[0].contiguous()
-    cos, sin = eng.rope_tables(txt_ids, img_ids)
-    outs = [eng.forward(lat, pe, mod, cos, sin).clone() for _ in range(6)]
-    torch.cuda.synchronize()
-    assert all(torch.isfinite(o.float()).all() for o in outs)
-    assert all(torch.equal(o, outs[0]) for o in outs[1:]), "kernel sequence is not deterministic run-to-run"
-    # DESIGN.md section 1: a forward allocates nothing, never synchronises and only enqueues on the given stream, so it
-    # can be captured into a hipGraph and replayed; the replay must reproduce the eager result bit for bit
-    gout = torch.empty_like(lat)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        eng.forward(lat, pe, mod, cos, sin, out=gout)          # warm the per-stream workspace outside the capture
-    torch.cuda.current_stream().wait_stream(side)
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=side):
-        eng.forward(lat, pe, mod, cos, sin, out=gout)
-    for _ in range(2):
-        gout.zero_()
-        graph.replay()
-        torch.cuda.synchronize()
-        assert torch.equal(gout, outs[0]), "hipGraph replay of rf_flux_forward differs from the eager launch sequence"
-    del graph
-    with torch.device(dev):
-        om = O.FluxTransformer2DModel().float().eval()
-    om.load_state_dict({k: v.float() for k, v in tr.state_dict().items()})
-    ref = O.tranformer_forward(om, None, None, None, model_config={}, hidden_states=lat.float()[None],
-                               encoder_hidden_states=pe.float()[None], pooled_projections=pooled.float(), timestep=t,
-                               guidance=gd, img_ids=img_ids, txt_ids=txt_ids, return_dict=False)[0][0]
-    e = rel_l2(outs[0], ref)
-    print(f"  full FLUX-dev forward: rel-L2 vs fp32 oracle {e:.3e} (57 blocks deep)")
-    assert e < 4e-2, f"full forward rel-L2 {e:.3e}"
-    del om
-    torch.cuda.empty_cache()

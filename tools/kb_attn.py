@@ -1,20 +1,23 @@
+"""Attention kernels A/B on one GPU: v1 (4 waves), v2 (8 waves, online softmax), v4 (8 waves, bounded score) at the
+BASELINE sequence lengths, realistic score scale (q, k ~ RMS-normalised rows, prescaled q), interleaved repetitions."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reflectionflow_amd import _lib, ops
 from tools.kbench import timeit
 dev = torch.device("cuda:0"); lib = _lib.load()
-for S in (4608, 5632):
+for S in (4608, 5632, 17920):
     H = 24
     q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
     q.normal_(); k.normal_(); vt.normal_()
+    q.mul_(ops.QK_PRESCALE)
+    bound = float(q.float().norm(dim=-1).max() * k.float().norm(dim=-1).max()) * 1.01
     out = torch.empty(S, H * 128, device=dev, dtype=torch.bfloat16)
     for rep in range(3):
-        line = []
-        outs = []
-        for v in (0, 1):
-            lib.rf_debug_attn_v2(v)
-            t = timeit(lambda: ops.attention(q, k, vt, S, out=out), 10)
+        line, outs = [], []
+        for name, v2, v4 in (("v1", 0, 0), ("v2", 1, 0), ("v4", 1, 1)):
+            lib.rf_debug_attn_v2(v2); lib.rf_debug_attn_v4(v4)
+            t = timeit(lambda: ops.attention(q, k, vt, S, out=out, q_prescaled=True, score_bound=bound), 10 if S < 10000 else 4)
             outs.append(out.clone())
-            line.append(f"v{v+1}: {t*1e6:7.1f} us {4.0*S*S*H*128/t/1e12:6.1f} TF")
-        print(f"S={S}", " | ".join(line), " maxdiff", float((outs[0].float()-outs[1].float()).abs().max()), flush=True)
-lib.rf_debug_attn_v2(-1)
+            line.append(f"{name}: {t*1e6:8.1f} us {4.0*S*S*H*128/t/1e12:6.1f} TF")
+        print(f"S={S} bound={bound:.1f}", " | ".join(line), " max|v4-v2|", float((outs[2].float()-outs[1].float()).abs().max()), flush=True)
+lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1)
