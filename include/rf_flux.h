@@ -74,6 +74,8 @@ typedef struct rf_gemm_group {
   const void* gate;                   /* GATE_RES: [N] */
   const void* norm_q;                 /* QKV + rope_cos: per-head RMSNorm weights [128] for this group's q rows */
   const void* norm_k;                 /*                 ... and k rows (text group: norm_added_q/k)             */
+  const float* a_scale;               /* rf_gemm_w8a8: fp32 [M] per-token dequantisation scale of this group's A rows  */
+  const float* w_scale;               /* rf_gemm_w8a8: fp32 [N] per-output-channel dequantisation scale of this group's W */
 } rf_gemm_group;
 
 typedef struct rf_gemm_desc {
@@ -107,6 +109,19 @@ typedef struct rf_gemm_desc {
 } rf_gemm_desc;
 
 int rf_gemm_bf16(const rf_gemm_desc* d, void* stream);
+
+/* The same GEMM with fp8 operands (BASELINE cfg5, "fp8 MFMA weights"; the reference has no fp8 path -- semantics are
+ * defined here): A and W are OCP e4m3fn bytes, symmetric absmax-quantised
+ *      A8[m,k] = e4m3(A[m,k] / a_scale[m]),  a_scale[m] = max_k |A[m,k]| / 448      (per token; rf_quant_rows_fp8)
+ *      W8[n,k] = e4m3(W[n,k] / w_scale[n]),  w_scale[n] = max_k |W[n,k]| / 448      (per output channel; packed once)
+ * and   out[m,n] = epi( a_scale[m] * w_scale[n] * sum_k A8[m,k] W8[n,k]  + bias[n] )   with fp32 accumulation, every
+ * epilogue of rf_gemm_bf16 (bias / gate / residual / outputs stay bf16).  The products run on the block-scaled fp8 MFMA
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales) at twice the bf16 MFMA rate.  Every segment of a group shares
+ * the group's a_scale (a two-segment input must be quantised with a common row scale); K % 128 == 0 per segment; lda /
+ * ldw / K count ELEMENTS (= bytes); needs the 16-byte aligned epilogue path.
+ * MIXED precision per token group: a group whose a_scale is NULL is an ordinary bf16 group (bf16 A / W, K % 64 == 0,
+ * LoRA K-segments allowed) and rides in the same launch -- cfg5's LoRA'd condition rows next to the fp8 text / image rows. */
+int rf_gemm_w8a8(const rf_gemm_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused per-head RMSNorm(q,k) + interleaved-pair RoPE, in place on head-major q,k
@@ -152,6 +167,16 @@ int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, in
 int rf_layernorm_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows, int32_t D,
                           const void* scale, const void* shift, float eps, void* stream);
 
+/* fp8 producers for rf_gemm_w8a8 (cfg5).  Both write OCP e4m3fn rows (1 byte per element, ldo in elements) and the
+ * per-row dequantisation scale  row_scale[m] = max_k |y[m,k]| / 448  (1 for an all-zero row):
+ *   rf_layernorm_modulate_fp8: y = LayerNorm(x)*(1+scale)+shift as rf_layernorm_modulate, quantised from fp32;
+ *   rf_quant_rows_fp8: y = [x0 | x1] (x1 optional: the single block's cat([attn, mlp]) input, block.py:320) with ONE
+ *                      scale per row across both segments; K0 + K1 <= 16384. */
+int rf_layernorm_modulate_fp8(const void* x, int64_t ldx, void* out8, int64_t ldo, float* row_scale, int32_t rows,
+                              int32_t D, const void* scale, const void* shift, float eps, void* stream);
+int rf_quant_rows_fp8(const void* x0, int64_t ld0, int32_t K0, const void* x1, int64_t ld1, int32_t K1, void* out8,
+                      int64_t ldo, float* row_scale, int32_t rows, void* stream);
+
 /* Euler step of FlowMatchEulerDiscreteScheduler.step (generate.py:276):
  *   x <- bf16( float(x) + dt * float(v) ),  dt = sigma_next - sigma */
 int rf_euler_step(void* x, const void* v, int64_t n, float dt, void* stream);
@@ -172,6 +197,11 @@ typedef struct rf_lora_seg {          /* second K-segment for one fused linear (
   int32_t _pad;
 } rf_lora_seg;
 
+typedef struct rf_w8 {                 /* fp8 copy of one (fused) nn.Linear weight for rf_gemm_w8a8; w == NULL: none */
+  const void* w;                       /* [N x K] OCP e4m3fn bytes, same row order as the bf16 weight */
+  const float* scale;                  /* [N] per-output-channel dequantisation scale */
+} rf_w8;
+
 typedef struct rf_double_block_weights {   /* FluxTransformerBlock, SURVEY Appendix A.2 */
   const void *w_qkv, *b_qkv;           /* cat(to_q,to_k,to_v)             [3D x D], [3D] */
   const void *w_add_qkv, *b_add_qkv;   /* cat(add_q,add_k,add_v)_proj     [3D x D], [3D] */
@@ -186,6 +216,8 @@ typedef struct rf_double_block_weights {   /* FluxTransformerBlock, SURVEY Appen
   float qk_bound;                      /* proven bound on |score * log2 e| from the four norm weights (see
                                           rf_attention_fwd score_bound); 0 = none */
   int32_t _pad;
+  /* cfg5: fp8 copies of the eight big weights (base weights only; used when rf_flux_dims.fp8 != 0) */
+  rf_w8 q_qkv, q_add_qkv, q_out, q_add_out, q_ff1, q_ff2, q_ffc1, q_ffc2;
 } rf_double_block_weights;
 
 typedef struct rf_single_block_weights {   /* FluxSingleTransformerBlock, Appendix A.3 */
@@ -195,6 +227,7 @@ typedef struct rf_single_block_weights {   /* FluxSingleTransformerBlock, Append
   rf_lora_seg lora_qkv_mlp, lora_out;
   float qk_bound;                      /* as in rf_double_block_weights */
   int32_t _pad;
+  rf_w8 q_qkv_mlp, q_out;              /* cfg5: fp8 copies (q_out columns [attn | mlp] like w_out) */
 } rf_single_block_weights;
 
 typedef struct rf_flux_dims {
@@ -204,6 +237,11 @@ typedef struct rf_flux_dims {
   float cross_bias;                    /* log(c_factor) */
   int32_t lora_on_main;                /* model_config["latent_lora"] */
   int32_t add_cond_attn;               /* model_config["add_cond_attn"] (needs S_cond == S_img) */
+  int32_t fp8;                         /* cfg5: run the block GEMMs of every token stream that carries no LoRA on the
+                                          fp8 weight copies (rf_gemm_w8a8): activations are quantised per token by
+                                          the LayerNorm+modulate kernel (its fp8 form) or by rf_quant_rows_fp8.  Streams
+                                          with LoRA (condition rows; image rows under latent_lora) stay bf16. */
+  int32_t _pad;
 } rf_flux_dims;
 
 typedef struct rf_workspace {
@@ -269,6 +307,7 @@ int rf_flux_denoise(const rf_flux_dims* dims, const rf_flux_model* m,
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
  * shape with hipEvents on `stream`; returns average microseconds in *us. */
 int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
+int rf_time_gemm_w8a8(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
 
 /* In-sequence timing hook (bench.py's `roofline`): between rf_profile_begin and rf_profile_end every kernel the
  * library launches is bracketed by a hipEvent pair on ITS launch stream, so the durations are those of the

@@ -28,7 +28,8 @@ class rf_kseg(C.Structure):
 class rf_gemm_group(C.Structure):
     _fields_ = [("seg", rf_kseg * 3), ("bias", C.c_void_p), ("M", C.c_int32), ("tok_offset", C.c_int32),
                 ("out", C.c_void_p), ("ldo", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
-                ("gate", C.c_void_p), ("norm_q", C.c_void_p), ("norm_k", C.c_void_p)]
+                ("gate", C.c_void_p), ("norm_q", C.c_void_p), ("norm_k", C.c_void_p),
+                ("a_scale", C.c_void_p), ("w_scale", C.c_void_p)]
 
 
 class rf_gemm_desc(C.Structure):
@@ -36,6 +37,10 @@ class rf_gemm_desc(C.Structure):
                 ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("heads", C.c_int32), ("s_pad", C.c_int32),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("norm_eps", C.c_float), ("q_scale", C.c_float),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("g", rf_gemm_group * 4)]
+
+
+class rf_w8(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("scale", C.c_void_p)]
 
 
 class rf_lora_seg(C.Structure):
@@ -51,18 +56,20 @@ class rf_double_block_weights(C.Structure):
         "w_out", "b_out", "w_add_out", "b_add_out", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
         "w_ffc1", "b_ffc1", "w_ffc2", "b_ffc2")] + [
         ("lora_qkv", rf_lora_seg), ("lora_out", rf_lora_seg), ("lora_ff2", rf_lora_seg),
-        ("qk_bound", C.c_float), ("_pad", C.c_int32)]
+        ("qk_bound", C.c_float), ("_pad", C.c_int32)] + [
+        (n, rf_w8) for n in ("q_qkv", "q_add_qkv", "q_out", "q_add_out", "q_ff1", "q_ff2", "q_ffc1", "q_ffc2")]
 
 
 class rf_single_block_weights(C.Structure):
     _fields_ = [(n, _P) for n in ("w_qkv_mlp", "b_qkv_mlp", "norm_q", "norm_k", "w_out", "b_out")] + [
-        ("lora_qkv_mlp", rf_lora_seg), ("lora_out", rf_lora_seg), ("qk_bound", C.c_float), ("_pad", C.c_int32)]
+        ("lora_qkv_mlp", rf_lora_seg), ("lora_out", rf_lora_seg), ("qk_bound", C.c_float), ("_pad", C.c_int32),
+        ("q_qkv_mlp", rf_w8), ("q_out", rf_w8)]
 
 
 class rf_flux_dims(C.Structure):
     _fields_ = [("D", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32), ("S_txt", C.c_int32),
                 ("S_img", C.c_int32), ("S_cond", C.c_int32), ("attn_mode", C.c_int32), ("cross_bias", C.c_float),
-                ("lora_on_main", C.c_int32), ("add_cond_attn", C.c_int32)]
+                ("lora_on_main", C.c_int32), ("add_cond_attn", C.c_int32), ("fp8", C.c_int32), ("_pad", C.c_int32)]
 
 
 class rf_workspace(C.Structure):
@@ -83,6 +90,10 @@ _SIGS = {
     "rf_abi_version": (C.c_int, []),
     "rf_target_arch": (C.c_int, []),
     "rf_gemm_bf16": (C.c_int, [C.POINTER(rf_gemm_desc), _P]),
+    "rf_gemm_w8a8": (C.c_int, [C.POINTER(rf_gemm_desc), _P]),
+    "rf_layernorm_modulate_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_float, _P]),
+    "rf_quant_rows_fp8": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
+    "rf_time_gemm_w8a8": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
     "rf_qk_rmsnorm_rope": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
                                      C.c_float, _P]),
     "rf_attention_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,

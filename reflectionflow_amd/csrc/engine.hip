@@ -12,6 +12,7 @@
 //   LT  [S][256]      LoRA low-rank intermediates (x . lora_A^T)
 //   SK  fp32          GEMM scratch: stream-K flags + per-CU partial tiles, LoRA split-K partials (64 MiB)
 //   X   [S][D]        residual stream (rf_flux_forward only; rows = txt | img | cond)
+//   XN8 [S][D] fp8, A8 [S][D+mlp] fp8, sXN / sA [S] fp32   cfg5 (dims.fp8): quantised GEMM inputs + their row scales
 //
 // Token order everywhere is [text | image | condition] -- the order the reference concatenates
 // them in (block.py:70-72,101-104).
@@ -22,6 +23,7 @@ namespace rf {
 struct WsLayout {
   int S, s_pad;
   int64_t xn, q, k, vt, att, hid, lt, x, sk, sk_bytes, total;  // byte offsets
+  int64_t xn8, a8, s_xn, s_a;  // cfg5 (dims.fp8): fp8 LN-mod output [S][D], fp8 GEMM input [S][D+mlp], row scales [S] fp32 x2
 };
 
 static WsLayout ws_layout(const rf_flux_dims& d) {
@@ -48,6 +50,13 @@ static WsLayout ws_layout(const rf_flux_dims& d) {
   // then fp32 partial tiles: one 256x256 slot per CU for stream-K (64 MiB at 256 CUs), reused by the LoRA split-K
   L.sk_bytes = 4096 + (64ll << 20);
   L.sk = take(L.sk_bytes / 2);
+  L.xn8 = L.a8 = L.s_xn = L.s_a = 0;
+  if (d.fp8) {
+    L.xn8 = take(cdiv64(SD, 2));                                   // 1 byte per element
+    L.a8 = take(cdiv64((int64_t)L.S * (d.D + d.mlp), 2));
+    L.s_xn = take((int64_t)L.S * 2);                               // fp32 per row
+    L.s_a = take((int64_t)L.S * 2);
+  }
   L.total = off;
   return L;
 }
@@ -136,37 +145,91 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
                   {(bf16_t*)x_img, mi, Si, o_img, dims->lora_on_main != 0},
                   {(bf16_t*)x_cond, mc, Sc, o_cond, true}};
 
+  // cfg5 (dims.fp8): a stream WITHOUT LoRA runs its GEMMs on the fp8 weight copies; its LayerNorm+modulate output and its
+  // attention / FF-hidden rows are quantised per token on the way in.  LoRA'd streams (condition; image under
+  // latent_lora) keep the bf16 kernels: their low-rank K-segment is bf16 (rf_gemm_w8a8 header note).
+  const bool have8 = dims->fp8 && w->q_qkv.w && w->q_add_qkv.w && w->q_out.w && w->q_add_out.w && w->q_ff1.w && w->q_ff2.w &&
+                     w->q_ffc1.w && w->q_ffc2.w;
+  RF_REQUIRE(!dims->fp8 || have8, RF_ERR_NULL, "rf_double_block_fwd: dims.fp8 set but the block has no fp8 weight copies");
+  const bool any_lora = w->lora_qkv.B || w->lora_out.B || w->lora_ff2.B;
+  const bool use8[3] = {have8, have8 && !(sx[1].lora && any_lora), false};
+  uint8_t* XN8 = (uint8_t*)ws->base + L.xn8;
+  uint8_t* A8 = (uint8_t*)ws->base + L.a8;
+  float* sXN = (float*)((char*)ws->base + L.s_xn);
+  float* sA = (float*)((char*)ws->base + L.s_a);
+
+  // one GEMM stage = ONE grouped launch: fp8 streams as fp8 groups (a_scale set), the others as bf16 groups of the same
+  // mixed-precision launch (rf_gemm_w8a8); with no fp8 stream it is the plain rf_gemm_bf16 launch of rounds 1
+  auto run_stage = [&](const rf_gemm_desc& base, auto&& fill) -> int {
+    rf_gemm_desc d = base;
+    int n = 0;
+    bool any8 = false;
+    for (int i = 0; i < 3; ++i) {
+      if (sx[i].rows <= 0) continue;
+      RF_TRY(fill(i, d.g[n], use8[i]));
+      any8 = any8 || use8[i];
+      ++n;
+    }
+    if (n == 0) return RF_OK;
+    d.num_groups = n;
+    attach_scratch(d, ws, L);
+    return any8 ? rf_gemm_w8a8(&d, st) : rf_gemm_bf16(&d, st);
+  };
+  // LayerNorm + modulate of every stream with (scale, shift) = mod rows (r_scale, r_shift)
+  auto ln_mod = [&](int r_scale, int r_shift) -> int {
+    for (int i = 0; i < 3; ++i) {
+      const Stream& s = sx[i];
+      if (s.rows <= 0) continue;
+      if (use8[i])
+        RF_TRY(rf_layernorm_modulate_fp8(s.x, ldx, XN8 + (int64_t)s.off * D, D, sXN + s.off, s.rows, D, s.mod + r_scale * D,
+                                         s.mod + r_shift * D, 1e-6f, st));
+      else
+        RF_TRY(rf_layernorm_modulate(s.x, ldx, XN + (int64_t)s.off * D, D, s.rows, D, s.mod + r_scale * D, s.mod + r_shift * D,
+                                     1e-6f, st));
+    }
+    return RF_OK;
+  };
+  // per-token fp8 copy of the rows [off, off+rows) of a bf16 [S][K] buffer into A8 (leading dimension K)
+  auto quant_rows = [&](const bf16_t* src, int K) -> int {
+    for (int i = 0; i < 3; ++i)
+      if (use8[i] && sx[i].rows > 0)
+        RF_TRY(rf_quant_rows_fp8(src + (int64_t)sx[i].off * K, K, K, nullptr, 0, 0, A8 + (int64_t)sx[i].off * K, K, sA + sx[i].off,
+                                 sx[i].rows, st));
+    return RF_OK;
+  };
+
   // 1. AdaLN-Zero: XN = LN(x)*(1+scale_msa)+shift_msa  (mod rows: 0 shift_msa, 1 scale_msa, 2 gate_msa,
   //    3 shift_mlp, 4 scale_mlp, 5 gate_mlp)
-  for (auto& s : sx)
-    if (s.rows > 0)
-      RF_TRY(rf_layernorm_modulate(s.x, ldx, XN + (int64_t)s.off * D, D, s.rows, D, s.mod + 1 * D, s.mod + 0 * D, 1e-6f, st));
+  RF_TRY(ln_mod(1, 0));
 
   // 2. QKV projections, written head-major into the joint [txt|img|cond] attention operands
   {
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.N = 3 * D; d.epilogue = RF_EPI_QKV; d.num_groups = 3; d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
+    d.N = 3 * D; d.epilogue = RF_EPI_QKV; d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
     d.rope_cos = cos_tab; d.rope_sin = sin_tab; d.norm_eps = 1e-6f;   // per-head RMSNorm + RoPE fused into the epilogue
     d.q_scale = QK_PRESCALE;                                          // ... and the softmax scale folded into q
-    for (int i = 0; i < 3; ++i) {
+    RF_TRY(run_stage(d, [&](int i, rf_gemm_group& g, bool f8) -> int {
       const Stream& s = sx[i];
-      rf_gemm_group& g = d.g[i];
-      g.M = s.rows; g.tok_offset = s.off;
-      if (s.rows <= 0) continue;
       const bool txt = (i == 0);
+      g.M = s.rows; g.tok_offset = s.off;
       g.norm_q = txt ? w->norm_added_q : w->norm_q;
       g.norm_k = txt ? w->norm_added_k : w->norm_k;
-      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, txt ? w->w_add_qkv : w->w_qkv, D, D);
       g.bias = txt ? w->b_add_qkv : w->b_qkv;
+      if (f8) {
+        const rf_w8& q8 = txt ? w->q_add_qkv : w->q_qkv;
+        set_seg(g.seg[0], XN8 + (int64_t)s.off * D, D, q8.w, D, D);
+        g.a_scale = sXN + s.off; g.w_scale = q8.scale;
+        return RF_OK;
+      }
+      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, txt ? w->w_add_qkv : w->w_qkv, D, D);
       if (!txt && s.lora && w->lora_qkv.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_qkv, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_qkv.B, w->lora_qkv.r_pad, w->lora_qkv.r_pad);
       }
-    }
-    attach_scratch(d, ws, L);
-    RF_TRY(rf_gemm_bf16(&d, st));
+      return RF_OK;
+    }));
   }
   // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE: fused into the QKV epilogue above
   // 4. joint attention
@@ -174,31 +237,35 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
                           0.08838834764831845f /* 1/sqrt(128) */, /*q_prescaled=*/1, w->qk_bound, st));
   // 5. output projections + gated residual: x += gate_msa * proj(attn)
   {
+    RF_TRY(quant_rows(ATT, D));
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.N = D; d.epilogue = RF_EPI_GATE_RES; d.num_groups = 3;
+    d.N = D; d.epilogue = RF_EPI_GATE_RES;
     const bool add_cond = dims->add_cond_attn && Sc > 0;
-    for (int i = 0; i < 3; ++i) {
+    RF_TRY(run_stage(d, [&](int i, rf_gemm_group& g, bool f8) -> int {
       const Stream& s = sx[i];
-      rf_gemm_group& g = d.g[i];
-      g.M = s.rows;
-      if (s.rows <= 0) continue;
       const bool txt = (i == 0);
-      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, txt ? w->w_add_out : w->w_out, D, D);
+      g.M = s.rows;
       g.bias = txt ? w->b_add_out : w->b_out;
       g.gate = s.mod + 2 * D;
       g.out = s.x; g.ldo = ldx; g.residual = s.x; g.ldr = ldx;
       if (i == 2 && add_cond) {  // keep cond_attn_output = gate*proj on its own (block.py:224-228)
         g.out = HID; g.ldo = D; g.residual = nullptr; g.ldr = 0;
       }
+      if (f8) {
+        const rf_w8& q8 = txt ? w->q_add_out : w->q_out;
+        set_seg(g.seg[0], A8 + (int64_t)s.off * D, D, q8.w, D, D);
+        g.a_scale = sA + s.off; g.w_scale = q8.scale;
+        return RF_OK;
+      }
+      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, txt ? w->w_add_out : w->w_out, D, D);
       if (!txt && s.lora && w->lora_out.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
       }
-    }
-    attach_scratch(d, ws, L);
-    RF_TRY(rf_gemm_bf16(&d, st));
+      return RF_OK;
+    }));
     if (add_cond) {
       for (int r = 0; r < Sc; ++r) {  // rows may be strided (ldx != D): add row by row only then
         if (ldx == D) {
@@ -212,50 +279,55 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
     }
   }
   // 6. norm2 + modulate with (scale_mlp, shift_mlp)
-  for (auto& s : sx)
-    if (s.rows > 0)
-      RF_TRY(rf_layernorm_modulate(s.x, ldx, XN + (int64_t)s.off * D, D, s.rows, D, s.mod + 4 * D, s.mod + 3 * D, 1e-6f, st));
+  RF_TRY(ln_mod(4, 3));
   // 7. FF up + GELU(tanh)
   {
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.N = MLP; d.epilogue = RF_EPI_GELU; d.num_groups = 3;
-    for (int i = 0; i < 3; ++i) {
+    d.N = MLP; d.epilogue = RF_EPI_GELU;
+    RF_TRY(run_stage(d, [&](int i, rf_gemm_group& g, bool f8) -> int {
       const Stream& s = sx[i];
-      rf_gemm_group& g = d.g[i];
-      g.M = s.rows;
-      if (s.rows <= 0) continue;
       const bool txt = (i == 0);
-      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, txt ? w->w_ffc1 : w->w_ff1, D, D);
+      g.M = s.rows;
       g.bias = txt ? w->b_ffc1 : w->b_ff1;
       g.out = HID + (int64_t)s.off * MLP; g.ldo = MLP;
-    }
-    attach_scratch(d, ws, L);
-    RF_TRY(rf_gemm_bf16(&d, st));
+      if (f8) {
+        const rf_w8& q8 = txt ? w->q_ffc1 : w->q_ff1;
+        set_seg(g.seg[0], XN8 + (int64_t)s.off * D, D, q8.w, D, D);
+        g.a_scale = sXN + s.off; g.w_scale = q8.scale;
+      } else {
+        set_seg(g.seg[0], XN + (int64_t)s.off * D, D, txt ? w->w_ffc1 : w->w_ff1, D, D);
+      }
+      return RF_OK;
+    }));
   }
   // 8. FF down + gated residual: x += gate_mlp * ff(x)
   {
+    RF_TRY(quant_rows(HID, MLP));
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.N = D; d.epilogue = RF_EPI_GATE_RES; d.num_groups = 3;
-    for (int i = 0; i < 3; ++i) {
+    d.N = D; d.epilogue = RF_EPI_GATE_RES;
+    RF_TRY(run_stage(d, [&](int i, rf_gemm_group& g, bool f8) -> int {
       const Stream& s = sx[i];
-      rf_gemm_group& g = d.g[i];
-      g.M = s.rows;
-      if (s.rows <= 0) continue;
       const bool txt = (i == 0);
-      set_seg(g.seg[0], HID + (int64_t)s.off * MLP, MLP, txt ? w->w_ffc2 : w->w_ff2, MLP, MLP);
+      g.M = s.rows;
       g.bias = txt ? w->b_ffc2 : w->b_ff2;
       g.gate = s.mod + 5 * D;
       g.out = s.x; g.ldo = ldx; g.residual = s.x; g.ldr = ldx;
+      if (f8) {
+        const rf_w8& q8 = txt ? w->q_ffc2 : w->q_ff2;
+        set_seg(g.seg[0], A8 + (int64_t)s.off * MLP, MLP, q8.w, MLP, MLP);
+        g.a_scale = sA + s.off; g.w_scale = q8.scale;
+        return RF_OK;
+      }
+      set_seg(g.seg[0], HID + (int64_t)s.off * MLP, MLP, txt ? w->w_ffc2 : w->w_ff2, MLP, MLP);
       if (!txt && s.lora && w->lora_ff2.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_ff2, HID + (int64_t)s.off * MLP, MLP, MLP, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_ff2.B, w->lora_ff2.r_pad, w->lora_ff2.r_pad);
       }
-    }
-    attach_scratch(d, ws, L);
-    RF_TRY(rf_gemm_bf16(&d, st));
+      return RF_OK;
+    }));
   }
   return RF_OK;
 }
@@ -279,64 +351,103 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
   Stream sx[2] = {{(bf16_t*)x_main, (const bf16_t*)mod_main, Sm, 0, dims->lora_on_main != 0},
                   {(bf16_t*)x_cond, (const bf16_t*)mod_cond, Sc, Sm, true}};
 
+  const bool have8 = dims->fp8 && w->q_qkv_mlp.w && w->q_out.w;
+  RF_REQUIRE(!dims->fp8 || have8, RF_ERR_NULL, "rf_single_block_fwd: dims.fp8 set but the block has no fp8 weight copies");
+  const bool any_lora = w->lora_qkv_mlp.B || w->lora_out.B;
+  const bool use8[2] = {have8 && !(sx[0].lora && any_lora), false};   // see rf_double_block_fwd
+  uint8_t* XN8 = (uint8_t*)ws->base + L.xn8;
+  uint8_t* A8 = (uint8_t*)ws->base + L.a8;
+  float* sXN = (float*)((char*)ws->base + L.s_xn);
+  float* sA = (float*)((char*)ws->base + L.s_a);
+  auto run_stage = [&](const rf_gemm_desc& base, auto&& fill) -> int {
+    rf_gemm_desc d = base;
+    int n = 0;
+    bool any8 = false;
+    for (int i = 0; i < 2; ++i) {
+      if (sx[i].rows <= 0) continue;
+      RF_TRY(fill(i, d.g[n], use8[i]));
+      any8 = any8 || use8[i];
+      ++n;
+    }
+    if (n == 0) return RF_OK;
+    d.num_groups = n;
+    attach_scratch(d, ws, L);
+    return any8 ? rf_gemm_w8a8(&d, st) : rf_gemm_bf16(&d, st);
+  };
+
   // 1. AdaLN-Zero-Single: mod rows 0 shift, 1 scale, 2 gate
-  for (auto& s : sx)
-    if (s.rows > 0)
+  for (int i = 0; i < 2; ++i) {
+    const Stream& s = sx[i];
+    if (s.rows <= 0) continue;
+    if (use8[i])
+      RF_TRY(rf_layernorm_modulate_fp8(s.x, ldx, XN8 + (int64_t)s.off * D, D, sXN + s.off, s.rows, D, s.mod + 1 * D, s.mod + 0 * D,
+                                       1e-6f, st));
+    else
       RF_TRY(rf_layernorm_modulate(s.x, ldx, XN + (int64_t)s.off * D, D, s.rows, D, s.mod + 1 * D, s.mod + 0 * D, 1e-6f, st));
+  }
   // 2. fused [to_q|to_k|to_v|proj_mlp]: QKV head-major, MLP branch through GELU(tanh) into HID
   {
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.N = 3 * D + MLP; d.epilogue = RF_EPI_QKV_GELU; d.n_split = 3 * D; d.num_groups = 2;
+    d.N = 3 * D + MLP; d.epilogue = RF_EPI_QKV_GELU; d.n_split = 3 * D;
     d.q = Q; d.k = K; d.vt = VT; d.heads = H; d.s_pad = L.s_pad;
     d.rope_cos = cos_tab; d.rope_sin = sin_tab; d.norm_eps = 1e-6f;
     d.q_scale = QK_PRESCALE;
-    for (int i = 0; i < 2; ++i) {
+    RF_TRY(run_stage(d, [&](int i, rf_gemm_group& g, bool f8) -> int {
       const Stream& s = sx[i];
-      rf_gemm_group& g = d.g[i];
       g.M = s.rows; g.tok_offset = s.off;
-      if (s.rows <= 0) continue;
       g.norm_q = w->norm_q; g.norm_k = w->norm_k;
-      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, w->w_qkv_mlp, D, D);
       g.bias = w->b_qkv_mlp;
       g.out = HID + (int64_t)s.off * MLP; g.ldo = MLP;
+      if (f8) {
+        set_seg(g.seg[0], XN8 + (int64_t)s.off * D, D, w->q_qkv_mlp.w, D, D);
+        g.a_scale = sXN + s.off; g.w_scale = w->q_qkv_mlp.scale;
+        return RF_OK;
+      }
+      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, w->w_qkv_mlp, D, D);
       if (s.lora && w->lora_qkv_mlp.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_qkv_mlp, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_qkv_mlp.B, w->lora_qkv_mlp.r_pad, w->lora_qkv_mlp.r_pad);
       }
-    }
-    attach_scratch(d, ws, L);
-    RF_TRY(rf_gemm_bf16(&d, st));
+      return RF_OK;
+    }));
   }
   // 3. RMSNorm(q,k) + RoPE: fused into the epilogue above (no added-norm rows in single blocks)
   // 4. attention
   RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, Sm, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
                           0.08838834764831845f, /*q_prescaled=*/1, w->qk_bound, st));
-  // 5. proj_out over cat([attn, mlp]) as two K segments + gated residual
+  // 5. proj_out over cat([attn, mlp]) + gated residual.  bf16: two K segments, no concat.  fp8: the per-token
+  //    quantisation writes [attn | mlp] side by side with ONE row scale, so it is a single K = D + mlp segment.
   {
+    const int64_t ldw = (int64_t)D + MLP;
+    for (int i = 0; i < 2; ++i)
+      if (use8[i] && sx[i].rows > 0)
+        RF_TRY(rf_quant_rows_fp8(ATT + (int64_t)sx[i].off * D, D, D, HID + (int64_t)sx[i].off * MLP, MLP, MLP,
+                                 A8 + (int64_t)sx[i].off * ldw, ldw, sA + sx[i].off, sx[i].rows, st));
     rf_gemm_desc d;
     memset(&d, 0, sizeof(d));
-    d.N = D; d.epilogue = RF_EPI_GATE_RES; d.num_groups = 2;
-    const int64_t ldw = (int64_t)D + MLP;
-    for (int i = 0; i < 2; ++i) {
+    d.N = D; d.epilogue = RF_EPI_GATE_RES;
+    RF_TRY(run_stage(d, [&](int i, rf_gemm_group& g, bool f8) -> int {
       const Stream& s = sx[i];
-      rf_gemm_group& g = d.g[i];
       g.M = s.rows;
-      if (s.rows <= 0) continue;
-      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, w->w_out, ldw, D);
-      set_seg(g.seg[1], HID + (int64_t)s.off * MLP, MLP, (const bf16_t*)w->w_out + D, ldw, MLP);
       g.bias = w->b_out;
       g.gate = s.mod + 2 * D;
       g.out = s.x; g.ldo = ldx; g.residual = s.x; g.ldr = ldx;
+      if (f8) {
+        set_seg(g.seg[0], A8 + (int64_t)s.off * ldw, ldw, w->q_out.w, ldw, (int)ldw);
+        g.a_scale = sA + s.off; g.w_scale = w->q_out.scale;
+        return RF_OK;
+      }
+      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, w->w_out, ldw, D);
+      set_seg(g.seg[1], HID + (int64_t)s.off * MLP, MLP, (const bf16_t*)w->w_out + D, ldw, MLP);
       if (s.lora && w->lora_out.B) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, HID + (int64_t)s.off * MLP, MLP, MLP, s.rows, T, ws, L, st));
         set_seg(g.seg[2], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
       }
-    }
-    attach_scratch(d, ws, L);
-    RF_TRY(rf_gemm_bf16(&d, st));
+      return RF_OK;
+    }));
   }
   return RF_OK;
 }

@@ -33,6 +33,9 @@ struct KSegDev {
 
 struct GemmGroupDev {
   KSegDev seg[3];
+  int w8, _pad8;          // this token group's operands are fp8 e4m3 (rf_gemm_w8a8 group with a_scale); else bf16
+  const float* a_scale;   // W8A8: per-row (token) dequantisation scale of this group's activations [M]
+  const float* w_scale;   // W8A8: per-output-channel dequantisation scale of this group's weights [N]
   const bf16_t* bias;
   bf16_t* out; int64_t ldo;
   const bf16_t* residual; int64_t ldr;
@@ -43,6 +46,8 @@ struct GemmGroupDev {
 
 struct GemmParams {
   int N, epi, ngroups, n_split, heads, s_pad, tiles_n, total_tiles;
+  int w8;      // 1: at least one token group has fp8 e4m3 operands (1 byte / element; a K-tile is 128 elements = the same
+               //    128 bytes): the launch uses the mixed-precision kernels, which pick the multiply per group
   int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
   bf16_t* q; bf16_t* k; bf16_t* vt;
   const float* rope_cos; const float* rope_sin; float norm_eps; float q_scale;
@@ -165,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGro
 constexpr int EPI_ROW = 528;                 // padded fp32 row: 128 cols * 4 B + 16 B
 constexpr int EPI_REGION = 32 * EPI_ROW;     // one wave's staging region
 
-template <int FM>
+template <int FM, bool W8 = false>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const GemmGroupDev& G, f32x16 (&acc)[FM][4],
                                                   const int m0, const int n0, const int wrow0, const int wcol0,
                                                   const int lane, char* region) {
@@ -201,6 +206,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int mrow0 = m0 + wrow0 + i * 32 + 4 * h;
+        if constexpr (W8) {  // dequantise in place: acc * s_act[row] * s_w[col]
+          const float swn = G.w_scale[n];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
+            acc[i][j][r] *= swn * (m < M ? G.a_scale[m] : 0.f);
+          }
+        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int m = mrow0 + 8 * rg;
@@ -231,9 +244,15 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
   const int q8 = (lane & 15) * 8;
   const int n = ncol0 + q8;
   const bool nok = n < N;  // N % 8 == 0 on this path
-  float bias8[8], gate8[8];
+  float bias8[8], gate8[8], sw8[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f, gate8[e] = 0.f;
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f, gate8[e] = 0.f, sw8[e] = 1.f;
+  constexpr bool w8 = W8;
+  if (w8 && nok) {
+    const f32x4 s0 = *(const f32x4*)(G.w_scale + n), s1 = *(const f32x4*)(G.w_scale + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sw8[e] = s0[e], sw8[e + 4] = s1[e];
+  }
   if (nok && G.bias != nullptr && epi != EPI_PARTIAL) unpack8(*(const u32x4*)(G.bias + n), bias8);
   if (nok && epi == RF_EPI_GATE_RES) unpack8(*(const u32x4*)(G.gate + n), gate8);
   const int rsub = lane >> 4;            // row within a 4-row read group
@@ -284,6 +303,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
         }
         if (m < M && nok) {
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          if constexpr (W8) {  // dequantise: fp8 products were accumulated unscaled; y = acc * s_act[m] * s_w[n]
+            const float sa = G.a_scale[m];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= sa * sw8[e];
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bias8[e];
           if (epi == RF_EPI_GELU) {
@@ -567,8 +591,55 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
 // first read a tile later); a half-tile is re-staged >= 2 phases after its last read.  vmcnt never drains to 0 in
 // steady state.  (A first build of this schedule with global_load_lds + 64-bit per-lane addresses lost 8 %: its
 // load phases were longer than the 256-cycle MFMA phases; buffer_load ... lds makes them fit.)
+// W8 = true: the operands are fp8 e4m3 (rf_gemm_w8a8).  A K-tile is then 128 ELEMENTS but the same 128 BYTES per row,
+// so staging, LDS image, swizzle, barriers and phases are byte-identical; only the multiply changes: per 128-byte row
+// two v_mfma_scale_f32_32x32x64_f8f6f4 (64 fp8 per lane pair, unit E8M0 block scales; 64 cycles each at twice the
+// bf16 FLOP rate) instead of four v_mfma_f32_32x32x16_bf16.  A lane's 32 operand bytes of a k-step are the two adjacent
+// 16-byte chunks (4*j + 2*h, +1); A and W use the same (lane, byte) -> k map, which is all a dot product needs
+// (tools/ubench/mx_probe.py: rows = lane % 32, results identical under every consistent k permutation).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+__device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
+  const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+  i32x8 r;
+  r[0] = (int)a[0]; r[1] = (int)a[1]; r[2] = (int)a[2]; r[3] = (int)a[3];
+  r[4] = (int)b[0]; r[5] = (int)b[1]; r[6] = (int)b[2]; r[7] = (int)b[3];
+  return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_MFMA_FP8(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127)
+#else
+#define RF_MFMA_FP8(a, b, c) (c)
+#endif
+
+// one phase's multiply: the 32 x 64 quadrant (a x {b0, b1}) over the whole K-tile
+template <bool W8>
+__device__ __forceinline__ void mma_quadrant(f32x16& c0, f32x16& c1, const bf16x8 (&a)[4], const bf16x8 (&b0)[4], const bf16x8 (&b1)[4]) {
+  if constexpr (!W8) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b0[ks], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b1[ks], c1, 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const i32x8 av = cat_frag(a[2 * j], a[2 * j + 1]);
+      c0 = RF_MFMA_FP8(av, cat_frag(b0[2 * j], b0[2 * j + 1]), c0);
+      c1 = RF_MFMA_FP8(av, cat_frag(b1[2 * j], b1[2 * j + 1]), c1);
+    }
+    // pin the results to this phase: hipcc's IR passes otherwise SINK all 16 scaled MFMAs of a K-tile below the last
+    // phase's barrier (seen in the ISA: eight empty barrier pairs, then 16 MFMAs back to back) -- sched_barrier only
+    // binds the machine scheduler inside a basic block, and the conditional DMA issue splits the K-tile into several
+    asm volatile("" : "+v"(c0), "+v"(c1));
+  }
+}
+
+template <bool W8 = false>
 __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                  const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
+  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
   constexpr int HT = 128 * 128;  // half-tile bytes
   constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
   const int wm = w >> 1, wn = w & 1, grp = w >> 2;
@@ -595,7 +666,7 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
   struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t lda2, ldw2; };
   auto load_seg = [&](Cur& c) {
     const KSegDev& S = G.seg[c.seg];
-    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W); c.lda2 = (uint32_t)(S.lda * 2); c.ldw2 = (uint32_t)(S.ldw * 2);
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W); c.lda2 = (uint32_t)(S.lda * ESZ); c.ldw2 = (uint32_t)(S.ldw * ESZ);
   };
   auto next = [&](Cur& c) {
     ++c.kk;
@@ -626,6 +697,8 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
   const int swz = (l31 >> 1) & 7;
   const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
   const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
+  // logical 16-byte chunk of fragment ks: bf16 k-step ks = chunks 2ks + h; fp8 k-step ks/2 = chunks 4(ks/2) + 2h + (ks&1)
+  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
 
   Cur c1;
   c1.seg = 0; c1.kk = kt_begin;
@@ -658,7 +731,7 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int coff = ((ks * 2 + h) ^ swz) << 4;
+      const int coff = frag_coff(ks);
       a0[ks] = *(const bf16x8*)(base + a_off + coff);
       bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
       bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
@@ -666,11 +739,7 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[0][ks], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[1][ks], acc[0][1], 0, 0, 0);
-    }
+    mma_quadrant<W8>(acc[0][0], acc[0][1], a0, bq[0], bq[1]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -678,15 +747,11 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     if (more1) stage(3, c1, (t + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a1[ks] = *(const bf16x8*)(base + HT + a_off + (((ks * 2 + h) ^ swz) << 4));
+    for (int ks = 0; ks < 4; ++ks) a1[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[0][ks], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[1][ks], acc[1][1], 0, 0, 0);
-    }
+    mma_quadrant<W8>(acc[1][0], acc[1][1], a1, bq[0], bq[1]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -695,18 +760,14 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int coff = ((ks * 2 + h) ^ swz) << 4;
+      const int coff = frag_coff(ks);
       bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
       bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[0][ks], acc[1][2], 0, 0, 0);
-      acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks], bq[1][ks], acc[1][3], 0, 0, 0);
-    }
+    mma_quadrant<W8>(acc[1][2], acc[1][3], a1, bq[0], bq[1]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -720,11 +781,7 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[0][ks], acc[0][2], 0, 0, 0);
-      acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[ks], bq[1][ks], acc[0][3], 0, 0, 0);
-    }
+    mma_quadrant<W8>(acc[0][2], acc[0][3], a0, bq[0], bq[1]);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -735,7 +792,8 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
 }
 
 // one 256x256 tile per block, ping-pong main loop, LDS-staged epilogue (vec_ok launches only)
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
+template <bool W8>
+__device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -751,10 +809,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x16 acc[2][4];
-  gemm_mainloop_pp(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-  __syncthreads();  // every wave is done reading the staged operands: the LDS is free
-  gemm_epilogue_lds<2>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+  if constexpr (W8) {
+    // mixed-precision launch: the multiply is chosen per token group (wave-uniform): fp8 groups next to bf16 groups
+    // (the LoRA'd condition rows of cfg5) in one grid, so the small group fills the tail instead of its own launch
+    if (G.w8) {
+      gemm_mainloop_pp<true>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+      __syncthreads();
+      gemm_epilogue_lds<2, true>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+    } else {
+      gemm_mainloop_pp<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+      __syncthreads();
+      gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+    }
+  } else {
+    gemm_mainloop_pp<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+    __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+    gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+  }
 }
+__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) { gemm_pp_body<false>(p); }
+__global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
 // One persistent block per CU.  The launch's MAC work is measured in K-tile iterations (tile-major) and cut into
@@ -781,7 +855,7 @@ struct SkParams {
   int* flags;           // [gridDim.x], zero outside a launch
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool W8>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmParams p, const SkParams sk) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -847,7 +921,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
     int lane_i = lane, tid_i = tid;
     asm volatile("" : "+v"(lane_i), "+v"(tid_i));
     f32x16 acc[FM][FN];
-    gemm_mainloop_pp(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
+    const bool g8 = W8 && G.w8;   // mixed-precision launch: multiply chosen per token group
+    if (g8) gemm_mainloop_pp<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    else gemm_mainloop_pp<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
 
     if (!is_tail) {
       // head or middle piece: raw accumulators -> this block's slot, [quad k][thread] x 16 B, as agent-coherent
@@ -912,7 +988,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
         }
       }
       __syncthreads();  // every wave is done reading the staged operands: the LDS is free
-      gemm_epilogue_lds<FM>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      else gemm_epilogue_lds<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
     }
   }
 }
@@ -952,11 +1029,13 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
-  hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
@@ -1025,7 +1104,7 @@ static int sk_make_plan(const GemmParams& p, const int P, SkParams& sk) {
 }
 
 // stream-K launch of the 256x256 kernel; returns 1 if it launched, 0 if the shape does not qualify, < 0 on error
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool W8>
 static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStream_t stream) {
   static int num_cus = 0;
   if (num_cus == 0) {
@@ -1056,7 +1135,7 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
-  auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN>;
+  auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -1094,13 +1173,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 = forced (used by tests and the tuner)
 
-static int build_params(const rf_gemm_desc* d, GemmParams& p) {
+static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = false) {
   RF_REQUIRE(d != nullptr, RF_ERR_NULL, "rf_gemm_bf16: desc is NULL");
   RF_REQUIRE(d->N > 0, RF_ERR_SHAPE, "rf_gemm_bf16: N=%d", d->N);
   RF_REQUIRE(d->num_groups >= 1 && d->num_groups <= 4, RF_ERR_SHAPE, "rf_gemm_bf16: num_groups=%d", d->num_groups);
   RF_REQUIRE(d->epilogue >= RF_EPI_STORE && d->epilogue <= RF_EPI_QKV_GELU, RF_ERR_SHAPE, "rf_gemm_bf16: bad epilogue %d",
              d->epilogue);
   memset(&p, 0, sizeof(p));
+  p.w8 = w8 ? 1 : 0;
   p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
@@ -1121,23 +1201,32 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
     if (s.M <= 0) continue;  // empty token group (e.g. no condition): skip
     GemmGroupDev& t = p.g[ng++];
     RF_REQUIRE(s.seg[0].K > 0, RF_ERR_SHAPE, "rf_gemm_bf16: group %d segment 0 is empty", g);
+    // rf_gemm_w8a8: a group WITH a_scale has fp8 operands, a group without one is bf16 (mixed-precision launch)
+    const bool g8 = w8 && s.a_scale != nullptr;
+    const int ktile = g8 ? 128 : 64, esz = g8 ? 1 : 2;   // elements per 128-byte K-tile row, bytes per element
     int ns = 0;
     for (int k = 0; k < 3; ++k) {
       const rf_kseg& ks = s.seg[k];
       if (ks.K <= 0) continue;
-      RF_REQUIRE(ks.K % 64 == 0, RF_ERR_SHAPE, "rf_gemm_bf16: group %d segment %d K=%d not a multiple of 64", g, k, ks.K);
+      RF_REQUIRE(ks.K % ktile == 0, RF_ERR_SHAPE, "rf_gemm: group %d segment %d K=%d not a multiple of %d", g, k, ks.K, ktile);
       RF_REQUIRE(ks.A && ks.W, RF_ERR_NULL, "rf_gemm_bf16: group %d segment %d A/W NULL", g, k);
-      RF_REQUIRE(aligned16(ks.A) && aligned16(ks.W) && ks.lda % 8 == 0 && ks.ldw % 8 == 0, RF_ERR_ALIGN,
-                 "rf_gemm_bf16: group %d segment %d operands must be 16-byte aligned", g, k);
+      RF_REQUIRE(aligned16(ks.A) && aligned16(ks.W) && ks.lda % (16 / esz) == 0 && ks.ldw % (16 / esz) == 0, RF_ERR_ALIGN,
+                 "rf_gemm: group %d segment %d operands must be 16-byte aligned", g, k);
       // the LDS-DMA addresses operands as buffer resource (num_records 2^31-1) + 32-bit byte offset: the last byte any
       // lane can touch must stay inside that window, or the hardware range check silently returns zeros
-      RF_REQUIRE(((int64_t)s.M - 1) * ks.lda * 2 + (int64_t)ks.K * 2 < 0x7fffffffll &&
-                     ((int64_t)d->N - 1) * ks.ldw * 2 + (int64_t)ks.K * 2 < 0x7fffffffll,
+      RF_REQUIRE(((int64_t)s.M - 1) * ks.lda * esz + (int64_t)ks.K * esz < 0x7fffffffll &&
+                     ((int64_t)d->N - 1) * ks.ldw * esz + (int64_t)ks.K * esz < 0x7fffffffll,
                  RF_ERR_SHAPE, "rf_gemm_bf16: group %d segment %d operand spans >= 2 GiB (32-bit buffer offsets)", g, k);
       KSegDev& kd = t.seg[ns++];  // compact: empty segments are dropped
-      kd.A = (const bf16_t*)ks.A; kd.lda = ks.lda; kd.W = (const bf16_t*)ks.W; kd.ldw = ks.ldw; kd.nk = ks.K / 64;
+      kd.A = (const bf16_t*)ks.A; kd.lda = ks.lda; kd.W = (const bf16_t*)ks.W; kd.ldw = ks.ldw; kd.nk = ks.K / ktile;
     }
     t.bias = (const bf16_t*)s.bias;
+    t.w8 = g8 ? 1 : 0;
+    t.a_scale = g8 ? s.a_scale : nullptr; t.w_scale = g8 ? s.w_scale : nullptr;
+    if (g8)
+      RF_REQUIRE(s.w_scale != nullptr && aligned16(s.w_scale), RF_ERR_NULL,
+                 "rf_gemm_w8a8: group %d has a_scale [M] but no 16-byte aligned w_scale [N]", g);
+    if (!w8) RF_REQUIRE(s.a_scale == nullptr, RF_ERR_UNSUPPORTED, "rf_gemm_bf16: group %d carries a_scale -- fp8 groups need rf_gemm_w8a8", g);
     t.M = s.M; t.tok_offset = s.tok_offset;
     t.out = (bf16_t*)s.out; t.ldo = s.ldo;
     t.residual = (const bf16_t*)s.residual; t.ldr = s.ldr; t.gate = (const bf16_t*)s.gate;
@@ -1159,6 +1248,12 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p) {
           (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
   }
   p.vec_ok = vec ? 1 : 0;
+  if (w8) {
+    RF_REQUIRE(vec, RF_ERR_ALIGN, "rf_gemm_w8a8: needs N %% 8 == 0 and 16-byte aligned outputs / bias / gate / residual");
+    bool any8 = false;
+    for (int g = 0; g < ng; ++g) any8 = any8 || p.g[g].w8;
+    if (!any8) p.w8 = 0;   // all groups bf16: the plain bf16 kernels
+  }
   p.ksplit = 1;
   if (d->splitk_ws != nullptr) {
     RF_REQUIRE(aligned16(d->splitk_ws) && d->splitk_ws_bytes >= 0, RF_ERR_ALIGN, "rf_gemm_bf16: splitk_ws must be 16-byte aligned");
@@ -1185,8 +1280,8 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   }
   double flops = 0.0;  // algorithmic: 2 M N K over groups and K-segments
   for (int g = 0; g < p.ngroups; ++g)
-    flops += 2.0 * p.g[g].M * (double)p.N * 64.0 * (p.g[g].seg[0].nk + p.g[g].seg[1].nk + p.g[g].seg[2].nk);
-  ProfScope prof(tile >= 256 ? RF_KC_GEMM_MAIN : RF_KC_GEMM_SMALL, flops, stream);
+    flops += 2.0 * p.g[g].M * (double)p.N * (p.g[g].w8 ? 128.0 : 64.0) * (p.g[g].seg[0].nk + p.g[g].seg[1].nk + p.g[g].seg[2].nk);
+  ProfScope prof(p.w8 ? RF_KC_GEMM_W8 : (tile >= 256 ? RF_KC_GEMM_MAIN : RF_KC_GEMM_SMALL), flops, stream);
   // split-K: a plain-store, single-group GEMM with a handful of tiles and a long K (LoRA down-projection:
   // [S_cond x K] . [r_pad x K]^T = 8 tiles x up to 240 K-tiles) would run on 8 of 256 CUs.  Slice K over
   // blockIdx.y, >= 4 K-tiles per slice, ~256 blocks in flight, fp32 partials in caller-owned scratch.
@@ -1196,8 +1291,10 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
   if (tile == 257 && !p.vec_ok) tile = 256;
+  if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
   if (tile == 256 && p.vec_ok && g_force_sk != 0) {
-    const int rc = try_launch_gemm_sk<256, 256, 4, 2>(p, ws_base, ws_total, stream);
+    const int rc = p.w8 ? try_launch_gemm_sk<256, 256, 4, 2, true>(p, ws_base, ws_total, stream)
+                        : try_launch_gemm_sk<256, 256, 4, 2, false>(p, ws_base, ws_total, stream);
     if (rc != 0) return rc < 0 ? rc : RF_OK;
   }
   if (ws_bytes > 0 && tile == 128 && p.ngroups == 1 && p.epi == RF_EPI_STORE && p.vec_ok) {
@@ -1234,6 +1331,13 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
 extern "C" int rf_gemm_bf16(const rf_gemm_desc* d, void* stream) {
   rf::GemmParams p;
   int rc = rf::build_params(d, p);
+  if (rc != RF_OK) return rc;
+  return rf::dispatch(p, (hipStream_t)stream);
+}
+
+extern "C" int rf_gemm_w8a8(const rf_gemm_desc* d, void* stream) {
+  rf::GemmParams p;
+  int rc = rf::build_params(d, p, /*w8=*/true);
   if (rc != RF_OK) return rc;
   return rf::dispatch(p, (hipStream_t)stream);
 }
@@ -1288,9 +1392,12 @@ extern "C" int rf_debug_force_gemm_sk(int mode) {
   return RF_OK;
 }
 
-extern "C" int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream) {
+static int time_gemm_impl(const rf_gemm_desc* d, int32_t iters, float* us, void* stream, bool w8);
+extern "C" int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream) { return time_gemm_impl(d, iters, us, stream, false); }
+extern "C" int rf_time_gemm_w8a8(const rf_gemm_desc* d, int32_t iters, float* us, void* stream) { return time_gemm_impl(d, iters, us, stream, true); }
+static int time_gemm_impl(const rf_gemm_desc* d, int32_t iters, float* us, void* stream, bool w8) {
   rf::GemmParams p;
-  int rc = rf::build_params(d, p);
+  int rc = rf::build_params(d, p, w8);
   if (rc != RF_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;

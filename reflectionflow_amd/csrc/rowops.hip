@@ -159,6 +159,140 @@ __global__ __launch_bounds__(256) void add_kernel(bf16_t* __restrict__ out, cons
   }
 }
 
+
+// ---- fp8 activation quantisation (rf_gemm_w8a8's A operand) --------------------------------------------------
+// Symmetric per-row absmax: scale = amax / 448 (1 for an all-zero row), q = e4m3fn(x / scale).  v_cvt_pk_fp8_f32 on
+// gfx950 converts to OCP e4m3fn with round-to-nearest-even; inputs are clamped to +-448 so the result never
+// depends on the instruction's overflow behaviour.
+constexpr float FP8_MAX = 448.0f;
+
+__device__ __forceinline__ uint32_t f32x4_to_fp8(float a, float b, float c, float d) {
+  int v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+#endif
+  return (uint32_t)v;
+}
+
+__device__ __forceinline__ u32x2 quant8(const float (&f)[8], float inv) {
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = fminf(fmaxf(f[j] * inv, -FP8_MAX), FP8_MAX);
+  u32x2 r;
+  r[0] = f32x4_to_fp8(t[0], t[1], t[2], t[3]);
+  r[1] = f32x4_to_fp8(t[4], t[5], t[6], t[7]);
+  return r;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// LayerNorm(no affine) + (1+scale) x + shift -> fp8 row + its dequantisation scale.  One wave per row (as ln_mod_kernel).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_mod_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ out,
+                                                         int64_t ldo, float* __restrict__ row_scale, int rows, int D,
+                                                         const bf16_t* __restrict__ scale, const bf16_t* __restrict__ shift,
+                                                         float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      unpack8(*(const u32x4*)(xr + col), v[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dlt = v[c][j] - mean;
+        q += dlt * dlt;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      float sc[8], sh[8];
+      unpack8(*(const u32x4*)(scale + col), sc);
+      unpack8(*(const u32x4*)(shift + col), sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[c][j] = (v[c][j] - mean) * rstd * (1.0f + sc[j]) + sh[j];
+        amax = fmaxf(amax, fabsf(v[c][j]));
+      }
+    }
+  }
+  amax = wave_max(amax);
+  const float sc_row = amax > 0.f ? amax * (1.0f / FP8_MAX) : 1.0f;
+  const float inv = 1.0f / sc_row;
+  if (lane == 0) row_scale[row] = sc_row;
+  uint8_t* orow = out + (int64_t)row * ldo;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) *(u32x2*)(orow + col) = quant8(v[c], inv);
+  }
+}
+
+// bf16 rows (one or two column segments, e.g. the single block's [attn | mlp] input) -> fp8 rows with ONE common scale
+// per row.  One 256-thread block per row, the row stays in registers (<= NCH x 2048 columns).
+template <int NCH>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x0, int64_t ld0, int K0,
+                                                             const bf16_t* __restrict__ x1, int64_t ld1, int K1,
+                                                             uint8_t* __restrict__ out, int64_t ldo, float* __restrict__ row_scale) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t row = blockIdx.x;
+  const int K = K0 + K1;
+  float v[NCH][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 256 + tid) * 8;
+    if (col < K) {
+      const bf16_t* src = col < K0 ? x0 + row * ld0 + col : x1 + row * ld1 + (col - K0);
+      unpack8(*(const u32x4*)src, v[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[c][j]));
+    }
+  }
+  amax = wave_max(amax);
+  if (lane == 0) red[w] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc_row = amax > 0.f ? amax * (1.0f / FP8_MAX) : 1.0f;
+  const float inv = 1.0f / sc_row;
+  if (tid == 0) row_scale[row] = sc_row;
+  uint8_t* orow = out + row * ldo;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 256 + tid) * 8;
+    if (col < K) *(u32x2*)(orow + col) = quant8(v[c], inv);
+  }
+}
+
 }  // namespace rf
 
 extern "C" int rf_layernorm_modulate(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows, int32_t D,
@@ -239,6 +373,60 @@ extern "C" int rf_add_inplace(void* out, const void* x, int64_t n, void* stream)
   ProfScope prof(RF_KC_ROWOP, 6.0 * (double)n, (hipStream_t)stream);
   hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out,
                      (const bf16_t*)x, n);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+
+extern "C" int rf_layernorm_modulate_fp8(const void* x, int64_t ldx, void* out8, int64_t ldo, float* row_scale, int32_t rows,
+                                         int32_t D, const void* scale, const void* shift, float eps, void* stream) {
+  using namespace rf;
+  if (rows <= 0) return RF_OK;
+  RF_REQUIRE(x && out8 && row_scale && scale && shift, RF_ERR_NULL, "rf_layernorm_modulate_fp8: NULL pointer");
+  RF_REQUIRE(D > 0 && D % 8 == 0 && D <= 8 * 512, RF_ERR_SHAPE, "rf_layernorm_modulate_fp8: D=%d (need D%%8==0, D<=4096)", D);
+  RF_REQUIRE(aligned16(x) && aligned16(scale) && aligned16(shift) && ldx % 8 == 0 && ((uintptr_t)out8 & 7u) == 0 && ldo % 8 == 0,
+             RF_ERR_ALIGN, "rf_layernorm_modulate_fp8: operands must be 16-byte (fp8 output: 8-byte) aligned");
+  const dim3 grid(cdiv(rows, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(RF_KC_QUANT, 3.0 * rows * (double)D, s);  // bytes: bf16 row in, fp8 row out
+  const int nch = cdiv(D, 512);
+#define RF_LN8_CASE(N)                                                                                              \
+  case N:                                                                                                           \
+    hipLaunchKernelGGL(ln_mod_fp8_kernel<N>, grid, block, 0, s, (const bf16_t*)x, ldx, (uint8_t*)out8, ldo, row_scale, \
+                       rows, D, (const bf16_t*)scale, (const bf16_t*)shift, eps);                                  \
+    break;
+  switch (nch) {
+    RF_LN8_CASE(1) RF_LN8_CASE(2) RF_LN8_CASE(3) RF_LN8_CASE(4) RF_LN8_CASE(5) RF_LN8_CASE(6) RF_LN8_CASE(7) RF_LN8_CASE(8)
+    default: RF_REQUIRE(false, RF_ERR_SHAPE, "rf_layernorm_modulate_fp8: D too large");
+  }
+#undef RF_LN8_CASE
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int rf_quant_rows_fp8(const void* x0, int64_t ld0, int32_t K0, const void* x1, int64_t ld1, int32_t K1, void* out8,
+                                 int64_t ldo, float* row_scale, int32_t rows, void* stream) {
+  using namespace rf;
+  if (rows <= 0) return RF_OK;
+  RF_REQUIRE(x0 && out8 && row_scale && K0 > 0 && K1 >= 0 && (K1 == 0 || x1), RF_ERR_NULL, "rf_quant_rows_fp8: NULL pointer / bad K");
+  const int K = K0 + K1;
+  RF_REQUIRE(K0 % 8 == 0 && K1 % 8 == 0 && K <= 8 * 2048, RF_ERR_SHAPE, "rf_quant_rows_fp8: K0=%d K1=%d (multiples of 8, sum <= 16384)", K0, K1);
+  RF_REQUIRE(aligned16(x0) && ld0 % 8 == 0 && (K1 == 0 || (aligned16(x1) && ld1 % 8 == 0)) && ((uintptr_t)out8 & 7u) == 0 && ldo % 8 == 0,
+             RF_ERR_ALIGN, "rf_quant_rows_fp8: inputs must be 16-byte, the fp8 output 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope prof(RF_KC_QUANT, 3.0 * rows * (double)K, s);
+  const dim3 grid(rows), block(256);
+  const int nch = cdiv(K, 2048);
+#define RF_Q8_CASE(N)                                                                                                   \
+  case N:                                                                                                               \
+    hipLaunchKernelGGL(quant_rows_fp8_kernel<N>, grid, block, 0, s, (const bf16_t*)x0, ld0, K0, (const bf16_t*)x1, ld1, K1, \
+                       (uint8_t*)out8, ldo, row_scale);                                                                 \
+    break;
+  switch (nch) {
+    RF_Q8_CASE(1) RF_Q8_CASE(2) RF_Q8_CASE(3) RF_Q8_CASE(4) RF_Q8_CASE(5) RF_Q8_CASE(6) RF_Q8_CASE(7) RF_Q8_CASE(8)
+    default: RF_REQUIRE(false, RF_ERR_SHAPE, "rf_quant_rows_fp8: row too long");
+  }
+#undef RF_Q8_CASE
   RF_LAUNCH_CHECK();
   return RF_OK;
 }

@@ -93,11 +93,19 @@ class _Packed:
     def __init__(self, struct):
         self.struct = struct
         self.keep: List[torch.Tensor] = []
+        self.by_ptr: Dict[int, torch.Tensor] = {}
+        self.fp8 = False
 
     def k(self, t: torch.Tensor) -> int:
         t = t.detach().contiguous()
         self.keep.append(t)
+        self.by_ptr[t.data_ptr()] = t
         return t.data_ptr()
+
+    def w8(self, dst: L.rf_w8, weight: torch.Tensor):
+        """fp8 copy (e4m3fn bytes + per-output-channel scale) of a fused bf16 weight for rf_gemm_w8a8."""
+        q, sc = ops.quantize_weight_fp8(weight)
+        dst.w, dst.scale = self.k(q), self.k(sc)
 
     def lora(self, seg: L.rf_lora_seg, linears):
         f = _fused_lora(linears)
@@ -112,10 +120,11 @@ def _require_device_bf16(p: torch.Tensor, what: str):
                           "the HIP path has no CPU fallback")
 
 
-def pack_double_block(b, refresh: bool = False) -> _Packed:
-    """rf_double_block_weights for a FluxTransformerBlock (cached on the module)."""
+def pack_double_block(b, refresh: bool = False, fp8: bool = False) -> _Packed:
+    """rf_double_block_weights for a FluxTransformerBlock (cached on the module).  fp8: also pack e4m3fn copies of
+    the eight big weights (BASELINE cfg5)."""
     pk = getattr(b, "_rf_packed", None)
-    if pk is not None and not refresh:
+    if pk is not None and not refresh and (pk.fp8 or not fp8):
         return pk
     a = b.attn
     _require_device_bf16(_base(a.to_q).weight, "pack_double_block")
@@ -140,15 +149,20 @@ def pack_double_block(b, refresh: bool = False) -> _Packed:
     pk.lora(w.lora_ff2, [b.ff.net[2]])
     # |score| bound from the norm weights alone: lets attention skip the online softmax (rf_attention_fwd score_bound)
     w.qk_bound = ops.qk_score_bound((a.norm_q.weight, a.norm_added_q.weight), (a.norm_k.weight, a.norm_added_k.weight))
+    pk.fp8 = fp8
+    if fp8:
+        for dst, src in ((w.q_qkv, w.w_qkv), (w.q_add_qkv, w.w_add_qkv), (w.q_out, w.w_out), (w.q_add_out, w.w_add_out),
+                         (w.q_ff1, w.w_ff1), (w.q_ff2, w.w_ff2), (w.q_ffc1, w.w_ffc1), (w.q_ffc2, w.w_ffc2)):
+            pk.w8(dst, pk.by_ptr[src])
     pk.D, pk.heads, pk.mlp = a.to_q.in_features, a.heads, b.ff.net[0].proj.out_features
     object.__setattr__(b, "_rf_packed", pk)
     return pk
 
 
-def pack_single_block(b, refresh: bool = False) -> _Packed:
+def pack_single_block(b, refresh: bool = False, fp8: bool = False) -> _Packed:
     """rf_single_block_weights for a FluxSingleTransformerBlock (cached on the module)."""
     pk = getattr(b, "_rf_packed", None)
-    if pk is not None and not refresh:
+    if pk is not None and not refresh and (pk.fp8 or not fp8):
         return pk
     a = b.attn
     _require_device_bf16(_base(a.to_q).weight, "pack_single_block")
@@ -162,13 +176,17 @@ def pack_single_block(b, refresh: bool = False) -> _Packed:
     pk.lora(w.lora_qkv_mlp, fused)
     pk.lora(w.lora_out, [b.proj_out])
     w.qk_bound = ops.qk_score_bound((a.norm_q.weight,), (a.norm_k.weight,))
+    pk.fp8 = fp8
+    if fp8:
+        pk.w8(w.q_qkv_mlp, pk.by_ptr[w.w_qkv_mlp])
+        pk.w8(w.q_out, pk.by_ptr[w.w_out])
     pk.D, pk.heads, pk.mlp = a.to_q.in_features, a.heads, b.proj_mlp.out_features
     object.__setattr__(b, "_rf_packed", pk)
     return pk
 
 
 def make_dims(D: int, heads: int, mlp: int, S_txt: int, S_img: int, S_cond: int = 0,
-              model_config: Optional[dict] = None, c_factor: Optional[float] = None) -> L.rf_flux_dims:
+              model_config: Optional[dict] = None, c_factor: Optional[float] = None, fp8: bool = False) -> L.rf_flux_dims:
     mc = model_config or {}
     d = L.rf_flux_dims()
     d.D, d.heads, d.mlp = D, heads, mlp
@@ -181,6 +199,7 @@ def make_dims(D: int, heads: int, mlp: int, S_txt: int, S_img: int, S_cond: int 
             d.attn_mode = 2
     d.lora_on_main = 1 if mc.get("latent_lora", False) else 0
     d.add_cond_attn = 1 if mc.get("add_cond_attn", False) else 0
+    d.fp8 = 1 if fp8 else 0
     return d
 
 
@@ -193,7 +212,7 @@ def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
     """Caller-owned scratch for one (D, heads, mlp, S_txt, S_img, S_cond) geometry, allocated once per
     stream (calls on different streams may overlap on the device, so they must not share scratch)."""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, d.D, d.heads, d.mlp, d.S_txt, d.S_img, d.S_cond,
-           d.lora_on_main)
+           d.lora_on_main, d.fp8)
     buf = _WS_CACHE.pop(key, None)
     if buf is None:
         n = int(L.load().rf_workspace_bytes(C.byref(d)))
@@ -213,6 +232,7 @@ class FluxEngine:
     def __init__(self, transformer: M.FluxTransformer2DModel):
         self.lib = L.load()
         self.tr = transformer
+        self.fp8 = bool(getattr(transformer, "_rf_fp8", False))     # BASELINE cfg5: fp8 weights + activations (W8A8)
         p = _base(transformer.x_embedder).weight
         _require_device_bf16(p, "FluxEngine")
         self.device = p.device
@@ -234,11 +254,11 @@ class FluxEngine:
         self._sgl = (L.rf_single_block_weights * max(ns, 1))()
         self._packs = []
         for i, b in enumerate(tr.transformer_blocks):
-            pk = pack_double_block(b, refresh=True)
+            pk = pack_double_block(b, refresh=True, fp8=self.fp8)
             self._packs.append(pk)
             self._dbl[i] = pk.struct
         for i, b in enumerate(tr.single_transformer_blocks):
-            pk = pack_single_block(b, refresh=True)
+            pk = pack_single_block(b, refresh=True, fp8=self.fp8)
             self._packs.append(pk)
             self._sgl[i] = pk.struct
         top = _Packed(L.rf_flux_model())
@@ -270,7 +290,7 @@ class FluxEngine:
     # ------------------------------------------------------------------ small helpers
     def dims(self, S_txt: int, S_img: int, S_cond: int = 0, model_config: Optional[dict] = None,
              c_factor: Optional[float] = None) -> L.rf_flux_dims:
-        return make_dims(self.D, self.heads, self.mlp, S_txt, S_img, S_cond, model_config, c_factor)
+        return make_dims(self.D, self.heads, self.mlp, S_txt, S_img, S_cond, model_config, c_factor, fp8=self.fp8)
 
     def workspace(self, d: L.rf_flux_dims) -> L.rf_workspace:
         return get_workspace(self.device, d)

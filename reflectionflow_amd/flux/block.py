@@ -152,12 +152,13 @@ def block_forward(self, hidden_states, encoder_hidden_states, condition_latents,
     lib = L.load()
     use_cond = condition_latents is not None
     latent_lora = model_config.get("latent_lora", False)
-    pk = E.pack_double_block(self)
+    fp8 = bool(model_config.get("fp8_weights", False))    # build-defined key (cfg5): fp8 copies of the big weights
+    pk = E.pack_double_block(self, fp8=fp8)
     B, Si, D = hidden_states.shape
     St = encoder_hidden_states.shape[1]
     Sc = condition_latents.shape[1] if use_cond else 0
     dev = hidden_states.device
-    d = E.make_dims(pk.D, pk.heads, pk.mlp, St, Si, Sc, model_config, _c_factor(self.attn))
+    d = E.make_dims(pk.D, pk.heads, pk.mlp, St, Si, Sc, model_config, _c_factor(self.attn), fp8=fp8)
     ws = E.get_workspace(dev, d)
     cos, sin = _rope_tables(image_rotary_emb, cond_rotary_emb if use_cond else None, dev)
     mod_img = _mod(self.norm1.linear, temb, latent_lora)                 # [B, 6D]
@@ -184,12 +185,13 @@ def single_block_forward(self, hidden_states, temb, image_rotary_emb=None, condi
     lib = L.load()
     using_cond = condition_latents is not None
     latent_lora = model_config.get("latent_lora", False)
-    pk = E.pack_single_block(self)
+    fp8 = bool(model_config.get("fp8_weights", False))
+    pk = E.pack_single_block(self, fp8=fp8)
     B, Sm, D = hidden_states.shape
     Sc = condition_latents.shape[1] if using_cond else 0
     dev = hidden_states.device
     # the C entry point only needs S_txt + S_img; pass the whole main sequence as "image" rows
-    d = E.make_dims(pk.D, pk.heads, pk.mlp, 0, Sm, Sc, model_config, _c_factor(self.attn))
+    d = E.make_dims(pk.D, pk.heads, pk.mlp, 0, Sm, Sc, model_config, _c_factor(self.attn), fp8=fp8)
     ws = E.get_workspace(dev, d)
     cos, sin = _rope_tables(image_rotary_emb, cond_rotary_emb if using_cond else None, dev)
     mod_main = _mod(self.norm.linear, temb, latent_lora)                 # [B, 3D]

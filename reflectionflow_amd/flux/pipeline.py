@@ -171,6 +171,16 @@ class FluxPipeline:
     def set_adapters(self, *a, **k):
         pass
 
+    # ---- BASELINE cfg5: fp8 weights ------------------------------------------------------------------------------
+    def enable_fp8_weights(self, enabled: bool = True):
+        """Run the 57 blocks' big GEMMs in fp8 (OCP e4m3fn): weights quantised once per output channel, activations
+        per token on the fly (include/rf_flux.h: rf_gemm_w8a8, rf_flux_dims.fp8).  Token streams that carry a LoRA
+        (the condition rows; the image rows under latent_lora) keep the bf16 kernels.  Not a reference feature
+        (the reference is bf16/fp32 only): accuracy cost and tolerance are stated in DESIGN.md / tests/test_w8_gpu.py."""
+        object.__setattr__(self.transformer, "_rf_fp8", bool(enabled))
+        E.invalidate(self.transformer)
+        return self
+
     # ---- diffusers FluxPipeline helpers (Appendix A.10) ------------------------------------------
     def check_inputs(self, prompt, prompt_2, height, width, prompt_embeds=None, pooled_prompt_embeds=None,
                      callback_on_step_end_tensor_inputs=None, max_sequence_length=None):

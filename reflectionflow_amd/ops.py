@@ -16,7 +16,8 @@ from . import _lib as L
 from ._lib import (RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, RF_EPI_STORE, RFError)
 
 __all__ = ["linear", "gemm", "build_gemm_desc", "time_gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
-           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError", "QK_PRESCALE", "profile"]
+           "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError", "QK_PRESCALE", "profile",
+           "quantize_weight_fp8", "dequantize_fp8", "quant_rows_fp8", "layernorm_modulate_fp8", "gemm_w8a8", "qk_score_bound"]
 
 
 def stream_ptr() -> int:
@@ -61,18 +62,20 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _rows2d(t: torch.Tensor, name: str):
-    _chk(t, name)
+def _rows2d(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+    _chk(t, name, dtype)
     if t.dim() != 2 or t.stride(1) != 1:
         raise RFError(f"{name}: need a 2-D row-major tensor, got shape {tuple(t.shape)} strides {t.stride()}")
     return t
 
 
 class Seg:
-    """One K-segment: activations A [M,K] and weights W [N,K] (nn.Linear layout)."""
+    """One K-segment: activations A [M,K] and weights W [N,K] (nn.Linear layout); bf16, or uint8 holding
+    fp8 e4m3fn bytes for gemm_w8a8."""
 
     def __init__(self, A: torch.Tensor, W: torch.Tensor):
-        self.A, self.W = _rows2d(A, "A"), _rows2d(W, "W")
+        dt = torch.uint8 if A.dtype == torch.uint8 else torch.bfloat16
+        self.A, self.W = _rows2d(A, "A", dt), _rows2d(W, "W", dt)
         if A.shape[1] != W.shape[1]:
             raise RFError(f"segment K mismatch: A {tuple(A.shape)} vs W {tuple(W.shape)}")
 
@@ -81,10 +84,11 @@ class Group:
     """One token group of a grouped GEMM."""
 
     def __init__(self, segs: Sequence[Seg], bias=None, out=None, residual=None, gate=None, tok_offset=0,
-                 norm_q=None, norm_k=None):
+                 norm_q=None, norm_k=None, a_scale=None, w_scale=None):
         self.segs, self.bias, self.out, self.residual, self.gate, self.tok_offset = (
             list(segs), bias, out, residual, gate, tok_offset)
         self.norm_q, self.norm_k = norm_q, norm_k
+        self.a_scale, self.w_scale = a_scale, w_scale        # gemm_w8a8: fp32 [M] / fp32 [N]
 
 
 def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
@@ -128,6 +132,11 @@ def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STOR
             G.gate = _chk(g.gate, "gate").data_ptr()
         if g.norm_q is not None:
             G.norm_q, G.norm_k = _chk(g.norm_q, "norm_q").data_ptr(), _chk(g.norm_k, "norm_k").data_ptr()
+        if g.a_scale is not None:
+            if g.a_scale.numel() != G.M or g.w_scale.numel() != N or not (g.a_scale.is_contiguous() and g.w_scale.is_contiguous()):
+                raise RFError("a_scale must be contiguous fp32 [M], w_scale contiguous fp32 [N]")
+            G.a_scale = _chk(g.a_scale, "a_scale", torch.float32).data_ptr()
+            G.w_scale = _chk(g.w_scale, "w_scale", torch.float32).data_ptr()
     return d
 
 
@@ -150,8 +159,66 @@ def time_gemm(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, ite
         kw["splitk_ws"] = None
     d = build_gemm_desc(groups, N, epilogue, **kw)
     us = C.c_float(0.0)
-    L.check(L.load().rf_time_gemm(C.byref(d), iters, C.byref(us), stream_ptr()), "rf_time_gemm")
+    w8 = groups[0].segs[0].A.dtype == torch.uint8
+    fn = L.load().rf_time_gemm_w8a8 if w8 else L.load().rf_time_gemm
+    L.check(fn(C.byref(d), iters, C.byref(us), stream_ptr()), "rf_time_gemm")
     return us.value * 1e-6
+
+
+# ---- fp8 (W8A8) path: BASELINE cfg5 ------------------------------------------------------------------------------
+FP8_MAX = 448.0
+
+
+def quantize_weight_fp8(W: torch.Tensor):
+    """nn.Linear weight [N, K] -> (uint8 [N, K] holding e4m3fn bytes, fp32 [N] per-output-channel scale):
+    scale[n] = max_k |W[n,k]| / 448,  W8 = e4m3fn(W / scale) (round to nearest even, saturating)."""
+    Wf = W.detach().float()
+    amax = Wf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / FP8_MAX, torch.ones_like(amax))
+    q = (Wf / scale[:, None]).clamp_(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def dequantize_fp8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """fp32 values of (uint8 e4m3fn bytes [R, K], fp32 [R] row scales)."""
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+def quant_rows_fp8(x0: torch.Tensor, x1: Optional[torch.Tensor] = None):
+    """bf16 rows [M, K0] (| [M, K1]) -> (uint8 [M, K0+K1] e4m3fn bytes, fp32 [M] scale), one scale per row."""
+    x0 = _rows2d(x0, "x0")
+    K1 = 0
+    if x1 is not None:
+        x1 = _rows2d(x1, "x1")
+        K1 = x1.shape[1]
+    M, K0 = x0.shape
+    out = torch.empty(M, K0 + K1, dtype=torch.uint8, device=x0.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x0.device)
+    L.check(L.load().rf_quant_rows_fp8(x0.data_ptr(), x0.stride(0), K0, ptr(x1), x1.stride(0) if x1 is not None else 0, K1,
+                                       out.data_ptr(), out.stride(0), sc.data_ptr(), M, stream_ptr()), "rf_quant_rows_fp8")
+    return out, sc
+
+
+def layernorm_modulate_fp8(x, scale, shift, eps: float = 1e-6):
+    """LayerNorm(x)*(1+scale)+shift -> (uint8 [M, D] e4m3fn bytes, fp32 [M] row scale)."""
+    x = _rows2d(x, "x")
+    _chk(scale, "scale"), _chk(shift, "shift")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    L.check(L.load().rf_layernorm_modulate_fp8(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), sc.data_ptr(),
+                                               x.shape[0], x.shape[1], scale.data_ptr(), shift.data_ptr(), eps, stream_ptr()),
+            "rf_layernorm_modulate_fp8")
+    return out, sc
+
+
+def gemm_w8a8(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, **kw):
+    """rf_gemm_w8a8: like gemm(), operands uint8 (e4m3fn bytes), every group carries a_scale / w_scale."""
+    if kw.get("splitk_ws", None) is None:
+        kw["splitk_ws"] = splitk_scratch(groups[0].segs[0].A.device)
+    elif kw["splitk_ws"] is False:
+        kw["splitk_ws"] = None
+    d = build_gemm_desc(groups, N, epilogue, **kw)
+    L.check(L.load().rf_gemm_w8a8(C.byref(d), stream_ptr()), "rf_gemm_w8a8")
 
 
 def linear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, *, epilogue: int = RF_EPI_STORE,

@@ -156,3 +156,44 @@ def test_cfg5_generate_two_steps_2048(full):
                     conditioning_dtype=BF, **okw)
     tb = O.denoise(ob, lat, pe, pooled, 2, condition_latents=cond, **okw)
     check_deep(hp, ref, tb, "cfg5 2-step generate (S=17920)")
+
+
+@torch.no_grad()
+def test_cfg5_generate_two_steps_2048_fp8_weights(full):
+    """BASELINE cfg5 as named: 2048 x 2048 + condition with fp8 (e4m3) weights AND activations on the text / image
+    streams' big GEMMs (rf_gemm_w8a8; the LoRA'd condition rows stay bf16), 2 Euler steps through generate().
+    The reference has no fp8 semantics: the plumbing is checked against the fp32 oracle under the fp8 EMULATION of
+    tests/w8_emulation.py (same quantisation points, fp32 arithmetic) with the statistical bounds explained in
+    tests/test_w8_gpu.py; the kernels' arithmetic itself is pinned there on identical quantised operands."""
+    from reflectionflow_amd.flux.condition import Condition
+    from reflectionflow_amd.flux.generate import generate
+    from tests import w8_emulation as EM
+    dev, pipe, om, ob = full
+    St, Si, Sc = 512, 16384, 1024
+    pe, pooled, lat, cond, _, _ = _inputs(dev, St, Si, Sc, seed=3)
+    cond_ids = O.condition_ids_for(512)
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    gkw = dict(model_config=cfg, default_lora=True, height=2048, width=2048, num_inference_steps=2, guidance_scale=3.5,
+               latents=lat, prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent")
+    pipe.enable_fp8_weights(True)
+    try:
+        hp = generate(pipe, conditions=[Condition("cot", tokens=cond, ids=cond_ids.to(dev))], **gkw).images
+    finally:
+        pipe.enable_fp8_weights(False)
+    hp16 = generate(pipe, conditions=[Condition("cot", tokens=cond, ids=cond_ids.to(dev))], **gkw).images
+    okw = dict(guidance_scale=3.5, condition_ids=cond_ids, model_config=cfg, image_hw=(128, 128))
+    ref = O.denoise(om, lat.float(), pe.float(), pooled.float(), 2, condition_latents=cond.float(), conditioning_dtype=BF, **okw)
+    tb = O.denoise(ob, lat, pe, pooled, 2, condition_latents=cond, **okw)
+    EM.emulate_fp8(om, St, Si)
+    try:
+        emu = O.denoise(om, lat.float(), pe.float(), pooled.float(), 2, condition_latents=cond.float(), conditioning_dtype=BF, **okw)
+    finally:
+        EM.remove_emulation(om)
+    e_impl, e_t, e_cost, e16, cost_emu = rel_l2(hp, emu), rel_l2(tb, ref), rel_l2(hp, ref), rel_l2(hp16, ref), rel_l2(emu, ref)
+    print(f"  cfg5 fp8 2-step generate: product vs emulated-fp8 oracle {e_impl:.3e}, product vs fp32 {e_cost:.3e}, emulation vs fp32 "
+          f"{cost_emu:.3e}, eager-bf16 vs fp32 {e_t:.3e} (bf16 product vs fp32: {e16:.3e})")
+    assert torch.isfinite(hp.float()).all()
+    # bounds: tests/test_w8_gpu.py "What can be asserted here"
+    assert e_impl <= 1.0 * cost_emu + 2.0 * e_t, f"product vs emulated fp8 oracle {e_impl:.3e} (cost_emu {cost_emu:.3e})"
+    assert e_cost <= 1.5 * cost_emu + 2.0 * e_t, f"product deviates {e_cost:.3e} from fp32 (cost_emu {cost_emu:.3e})"
+    assert not torch.equal(hp, hp16)

@@ -1,0 +1,23 @@
+"""rf_gemm_w8a8 vs rf_gemm_bf16 on the FLUX block shapes (isolated launches, random data): time and TFLOP/s.
+M = 4608 (cfg2), 16896 (cfg5 text+image rows)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib, ops
+from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_STORE, Group, Seg
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+_lib.load()
+r = lambda *s, sc=1.0: (torch.randn(*s, device=dev) * sc).to(BF)
+for M in (4608, 16896):
+    for name, N, K, epi in (("qkv-like", 9216, 3072, RF_EPI_STORE), ("out", 3072, 3072, RF_EPI_GATE_RES), ("ff1", 12288, 3072, RF_EPI_GELU),
+                            ("ff2", 3072, 12288, RF_EPI_GATE_RES), ("sgl_in-like", 21504, 3072, RF_EPI_GELU), ("sgl_out", 3072, 15360, RF_EPI_GATE_RES)):
+        x, W, b, gate = r(M, K), r(N, K, sc=0.02), r(N), r(N)
+        out = torch.empty(M, N, device=dev, dtype=BF)
+        kw = dict(bias=b, out=out)
+        if epi == RF_EPI_GATE_RES:
+            kw.update(residual=out, gate=gate)
+        t16 = ops.time_gemm([Group([Seg(x, W)], **kw)], N, epi, iters=8)
+        A8, sa = ops.quant_rows_fp8(x)
+        W8, sw = ops.quantize_weight_fp8(W)
+        t8 = ops.time_gemm([Group([Seg(A8, W8)], a_scale=sa, w_scale=sw, **kw)], N, epi, iters=8)
+        fl = 2.0 * M * N * K
+        print(f"M={M:6d} {name:12s} N={N:6d} K={K:6d}: bf16 {t16*1e6:8.1f} us {fl/t16/1e12:7.1f} TF | fp8 {t8*1e6:8.1f} us {fl/t8/1e12:7.1f} TF | x{t16/t8:.2f}", flush=True)
