@@ -309,13 +309,15 @@ int rf_flux_denoise(const rf_flux_dims* dims, const rf_flux_model* m,
 int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
 int rf_time_gemm_w8a8(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
 
-/* In-sequence timing hook (bench.py's `roofline`): between rf_profile_begin and rf_profile_end every kernel the
- * library launches is bracketed by a hipEvent pair on ITS launch stream, so the durations are those of the
- * kernels inside the real 57-block sequence (cold operands, real neighbours), not of isolated re-launches.
+/* In-sequence timing hook (bench.py's `roofline`): between rf_profile_begin and rf_profile_end every launch site of
+ * the library records ONE hipEvent on ITS launch stream in front of its kernel(s); rf_profile_end records a closing
+ * event.  A launch's duration is the distance to the next event (kernel + the gap behind it), so the durations are
+ * those of the kernels inside the real 57-block sequence (cold operands, real neighbours), not of isolated
+ * re-launches, and the per-class sums add up exactly to the wall time between the first and the closing event.
  * rf_profile_end synchronises, then fills, per rf_kernel_class: summed duration (us), launch count and summed
  * algorithmic work (FLOPs: 2MNK per GEMM over all groups and K-segments, 4*S^2*128*heads per attention launch;
  * BYTES read+written for the row kernels).  `dropped` = launches beyond max_launches (not timed).
- * Not thread-safe, not for use during hipGraph capture; costs two event records per launch while open. */
+ * Not thread-safe, single stream, not for use during hipGraph capture; costs one event record per launch while open. */
 typedef enum rf_kernel_class {
   RF_KC_GEMM_MAIN = 0,   /* 256x256-tile MFMA GEMM launches (tile-per-block ping-pong loop and stream-K) */
   RF_KC_GEMM_SMALL = 1,  /* 128x128-tile launches (embedders, LoRA down-projections incl. split-K + reduce) */

@@ -663,10 +663,20 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
 
   // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
   // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
-  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t lda2, ldw2; };
+  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
+  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
   auto load_seg = [&](Cur& c) {
     const KSegDev& S = G.seg[c.seg];
-    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W); c.lda2 = (uint32_t)(S.lda * ESZ); c.ldw2 = (uint32_t)(S.ldw * ESZ);
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
+    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        c.offA[sb][i] = rowA[sb][i] * lda2 + chunk_b;
+        c.offB[sb][i] = rowB[sb][i] * ldw2 + chunk_b;
+      }
   };
   auto next = [&](Cur& c) {
     ++c.kk;
@@ -681,8 +691,8 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     char* dst = smem + buf * BUF + kind * HT + w * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), rowA[kind & 1][i] * c.lda2 + chunk_b, c.kk * 128);
-      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), rowB[kind & 1][i] * c.ldw2 + chunk_b, c.kk * 128);
+      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
+      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
     }
   };
 

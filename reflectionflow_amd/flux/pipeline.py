@@ -52,8 +52,11 @@ class FluxPipeline:
         self.vae = vae
         self.text_encoder = text_encoder or SyntheticTextEncoder(
             transformer.config.joint_attention_dim, transformer.config.pooled_projection_dim)
-        self.image_processor = image_processor
         self.vae_scale_factor = 8
+        if image_processor is None and vae is not None:
+            from .vae import VaeImageProcessor
+            image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor * 2)   # as diffusers' FluxPipeline
+        self.image_processor = image_processor
         self.default_sample_size = 128
         self.interrupt = False
         self._joint_attention_kwargs = None
@@ -62,11 +65,17 @@ class FluxPipeline:
 
     # ---- construction --------------------------------------------------------------------------
     @classmethod
-    def synthetic(cls, config: Optional[dict] = None, seed: int = 0, torch_dtype=torch.bfloat16, device=None):
-        """Random-init FLUX-shaped transformer (there are no checkpoints offline)."""
+    def synthetic(cls, config: Optional[dict] = None, seed: int = 0, torch_dtype=torch.bfloat16, device=None,
+                  with_vae: bool = False, vae_config: Optional[dict] = None):
+        """Random-init FLUX-shaped transformer (there are no checkpoints offline); with_vae: also a random-init
+        AutoencoderKL (FLUX.1-dev VAE shape unless vae_config says otherwise) so PIL in / PIL out works."""
         tr = M.FluxTransformer2DModel(**(config or {})).to(torch_dtype)
         M.init_synthetic_(tr, seed=seed)
-        pipe = cls(tr)
+        vae = None
+        if with_vae:
+            from .vae import AutoencoderKL, init_synthetic_vae_
+            vae = init_synthetic_vae_(AutoencoderKL(**(vae_config or {})), seed=seed + 1).to(torch_dtype)
+        pipe = cls(tr, vae=vae)
         return pipe.to(device) if device is not None else pipe
 
     @classmethod
@@ -96,7 +105,24 @@ class FluxPipeline:
         missing, unexpected = tr.load_state_dict(sd, strict=False)
         if missing or unexpected:
             raise RuntimeError(f"FLUX checkpoint mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
-        return cls(tr)
+        # optional diffusers `vae/` sub-directory (AutoencoderKL; stays a PyTorch-ROCm module)
+        vae, vdir = None, os.path.join(root, "vae")
+        if os.path.isdir(vdir):
+            from .vae import FLUX_VAE_CONFIG, AutoencoderKL
+            vcfg, vcfg_path = {}, os.path.join(vdir, "config.json")
+            if os.path.exists(vcfg_path):
+                import json
+                raw = json.load(open(vcfg_path))
+                vcfg = {k: raw[k] for k in FLUX_VAE_CONFIG if k in raw}
+            vae = AutoencoderKL(**vcfg).to(torch_dtype)
+            vsd = {}
+            for f in sorted(os.listdir(vdir)):
+                if f.endswith(".safetensors"):
+                    vsd.update(load_file(os.path.join(vdir, f)))
+            missing, unexpected = vae.load_state_dict(vsd, strict=False)
+            if missing or unexpected:
+                raise RuntimeError(f"VAE checkpoint mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+        return cls(tr, vae=vae)
 
     def to(self, device=None, dtype=None):
         self.transformer.to(device=device, dtype=dtype)

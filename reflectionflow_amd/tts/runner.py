@@ -52,9 +52,26 @@ def build_pipeline(config: dict, device, synthetic: bool = False, small: bool = 
     return pipe
 
 
+def candidate_condition(pipe: FluxPipeline, latents: torch.Tensor, height: int, width: int, condition_size: int) -> Condition:
+    """The condition a selected candidate becomes for the next round.  With a VAE on the pipeline this is the
+    REFERENCE computation (tts_reflectionflow.py:273-279): decode the candidate (generate.py:302-307), take the 8-bit
+    image the reference would have written to PNG and re-opened, `resize((condition_size, condition_size))` with PIL's
+    default filter, and hand it over as `Condition(condition=img, "cot", position_delta=[0, -condition_size // 16])` --
+    `Condition.encode` then runs `image_processor.preprocess` + `vae.encode(x).latent_dist.sample()` + shift/scale +
+    pack (pipeline_tools.py:7-30).  Only the PNG file round trip itself is skipped (lossless).
+    Without a VAE (no weights offline) it falls back to `latent_to_condition`, a declared stand-in."""
+    if pipe.vae is None or pipe.image_processor is None:
+        return latent_to_condition(latents, height, width, condition_size)
+    z = pipe._unpack_latents(latents, height, width, pipe.vae_scale_factor)
+    z = z / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor
+    img = pipe.image_processor.postprocess(pipe.vae.decode(z.to(pipe.vae.dtype), return_dict=False)[0], output_type="pil")[0]
+    img = img.resize((condition_size, condition_size))
+    return Condition(condition=img, condition_type="cot", position_delta=[0, -(condition_size // 16)])
+
+
 def latent_to_condition(latents: torch.Tensor, height: int, width: int, condition_size: int) -> Condition:
-    """Stand-in for `resize(decoded image, condition_size) -> VAE encode` (tts_reflectionflow.py:273-279 +
-    condition.py:96-132) when no VAE is loaded: area-downsample the candidate's latent grid to the
+    """STAND-IN (used only when the pipeline has no VAE) for `resize(decoded image, condition_size) -> VAE encode`
+    (tts_reflectionflow.py:273-279 + condition.py:96-132): area-downsample the candidate's latent grid to the
     condition resolution in latent space.  Position ids follow the reference: delta = [0, -size//16]."""
     from ..flux.pipeline import FluxPipeline as P
     z = P._unpack_latents(latents, height, width, 8).float()                   # [1,16,h,w]
@@ -120,7 +137,9 @@ def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pip
                 noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seed])[seed]
                 conds = None
                 if rnd > 0:                                                     # round 0 = plain t2i (noise scaling)
-                    conds = [latent_to_condition(kept[i % len(kept)], pa["height"], pa["width"], pa["condition_size"])]
+                    conds = [candidate_condition(pipe, kept[i % len(kept)], pa["height"], pa["width"], pa["condition_size"])]
+                    torch.manual_seed(seed)     # Condition.encode samples the VAE posterior from the global RNG
+                                                # (pipeline_tools.py:10): seed it per candidate -> world-size independent
                 lat = generate(pipe, prompt=[prompt], conditions=conds, height=pa["height"], width=pa["width"],
                                num_inference_steps=pa["num_inference_steps"], guidance_scale=pa["guidance_scale"],
                                latents=noise, model_config=model_cfg, default_lora=True, output_type="latent").images

@@ -163,7 +163,7 @@ def test_profile_hook_counts_and_times_every_launch(dev):
     assert c["attention"]["work"] == pytest.approx(4.0 * 512 * 512 * 128 * 2)
     assert c["rowop"]["work"] == pytest.approx(4.0 * M_ * K)
     tot = sum(v["us"] for v in c.values())
-    assert all(v["us"] > 0 for v in c.values()) and tot <= wall_us
+    assert all(v["us"] > 0 for v in c.values()) and tot <= wall_us      # event-to-event durations tile the region
     # a second profile can be opened after the first closed; nesting is refused loudly
     with ops.profile(4):
         with pytest.raises(ops.RFError):
@@ -269,3 +269,47 @@ def test_engine_passes_a_valid_score_bound(dev):
         worst = max(worst, float(s.abs().max()))
     print(f"  engine bound {bound:.2f}, largest |score| seen {worst:.2f}")
     assert worst <= bound and bound < 100
+
+
+@torch.no_grad()
+def test_pil_output_and_reference_round_handoff_with_vae(dev, tmp_path):
+    """With a VAE on the pipeline (PyTorch-ROCm modules, random-init) the calls either side of the loop are the
+    reference's: generate(output_type="pil") decodes (generate.py:302-307), and the reflection rounds condition on
+    decode -> 8-bit image -> resize(condition_size) -> VAE-encode (tts_reflectionflow.py:273-279, condition.py:96-132)
+    instead of the latent-space stand-in."""
+    import json
+    from PIL import Image
+    from reflectionflow_amd.flux.condition import Condition
+    from reflectionflow_amd.flux.generate import generate
+    from reflectionflow_amd.flux.pipeline import FluxPipeline, synthetic_lora_state_dict
+    from reflectionflow_amd.tts import runner, search
+    small = dict(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64)
+    vcfg = dict(block_out_channels=(32, 64, 64, 64), norm_num_groups=8)
+    pipe = FluxPipeline.synthetic(small, seed=0, device=dev, with_vae=True, vae_config=vcfg)
+    pipe.set_progress_bar_config(disable=True)
+    pipe.load_lora_weights(synthetic_lora_state_dict(pipe.transformer, r=8, seed=3), adapter_name="reflection")
+    kw = dict(model_config={}, height=256, width=192, num_inference_steps=3, guidance_scale=3.5, prompt=["a red cube"])
+    lat = generate(pipe, output_type="latent", generator=torch.Generator().manual_seed(4), **kw).images
+    img = generate(pipe, output_type="pil", generator=torch.Generator().manual_seed(4), **kw).images[0]
+    assert isinstance(img, Image.Image) and img.size == (192, 256)
+    z = pipe._unpack_latents(lat, 256, 192, 8) / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor
+    ref = pipe.image_processor.postprocess(pipe.vae.decode(z, return_dict=False)[0], output_type="pil")[0]
+    assert img.tobytes() == ref.tobytes()
+    # the round hand-off is the reference computation: a PIL condition of condition_size, delta [0, -size/16]
+    c = runner.candidate_condition(pipe, lat, 256, 192, 128)
+    assert isinstance(c, Condition) and c.tokens is None and c.condition.size == (128, 128) and list(c.position_delta) == [0, -8]
+    torch.manual_seed(1)
+    tok, ids, _ = c.encode(pipe)
+    assert tok.shape == (1, 64, 64) and ids.shape == (64, 3) and float(ids[:, 2].min()) == -8.0
+    # whole search with the VAE in the loop: PNGs like the reference, deterministic
+    cfg = json.load(open(os.path.join(os.path.dirname(runner.__file__), "configs", "flux1_dev_mi355x.json")))
+    cfg["pipeline_args"].update(height=256, width=256, condition_size=128, num_inference_steps=2)
+    cfg["search_args"].update(search_branch=2, search_rounds=1)
+    logs = []
+    for rep in range(2):
+        out = str(tmp_path / f"run{rep}")
+        logs.append(runner.run_reflection_search(cfg, ["a red cube left of a blue ball"], out, pipe, search.Shard(0, 1)))
+        files = sorted(os.listdir(os.path.join(out, "00000", "samples")))
+        assert len(files) == 4 and all(f.endswith(".png") for f in files)
+        assert Image.open(os.path.join(out, "00000", "samples", files[0])).size == (256, 256)
+    assert logs[0] == logs[1]
