@@ -861,6 +861,7 @@ struct SkParams {
   // like the one-tile-per-block launch (shared A / W panels in the private L2) -- then the stream-K region, the
   // iterations [sk_begin[x], chunk_end[x]) (one to two tiles per worker), cut evenly
   int chunk_tile[8], dp_rounds[8], sk_begin[8], chunk_end[8];
+  int chunk_tiles[8];   // tiles in chunk x (bounds the last, partial whole-tile round of the persistent-tile mode)
   float* partials;      // [gridDim.x] slots of BM*BN floats
   int* flags;           // [gridDim.x], zero outside a launch
 };
@@ -893,6 +894,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
   while (true) {
     int gi = 0, lt, ts, ub, nk_u;
     bool is_tail;
+    if (round < dp_rounds && round * PL + cl >= sk.chunk_tiles[xcd]) round = dp_rounds;  // partial last round: no tile left for this worker
     if (round < dp_rounds) {
       // whole tile of a full round
       const int tile = sk.chunk_tile[xcd] + round * PL + cl;
@@ -1053,7 +1055,11 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
 // scratch layout shared by split-K and stream-K: [0, 4096) stream-K flags (zero outside a launch), partials after
 constexpr int64_t WS_FLAG_BYTES = 4096;
 static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K (test introspection)
-static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = whenever feasible (tests)
+static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = stream-K whenever feasible (tests), 2 = persistent whole tiles only
+static int g_persistent_rounds = 1;  // heuristic: bf16 launches with >= this many tile rounds that do not qualify for stream-K run as
+                                     // ONE persistent launch of whole tiles (+1..4 % on every cfg2 / cfg5 shape: a tile's output
+                                     // stores drain under the next tile's main loop, no block dispatch between rounds;
+                                     // profiles/r02_kb_persist.log); 0 = off.  fp8 / mixed launches keep one tile per block.
 
 // The stream-K launch relies on two properties HIP does not promise: lower-indexed blocks are dispatched first and
 // block b runs on XCD b % 8 (observed on MI355X in SPX mode; a wrong guess about the XCD costs speed only, but a
@@ -1071,7 +1077,10 @@ static bool streamk_allowed(int num_cus) {
 
 // stream-K work plan (pure host arithmetic; also reachable through rf_debug_sk_plan so the CPU tests can check its
 // invariants without a GPU).  Needs layout_tiles() done.  Returns 1 if the launch qualifies, 0 otherwise.
-static int sk_make_plan(const GemmParams& p, const int P, SkParams& sk) {
+// persistent_only: no stream-K region at all -- every worker walks whole tiles cl, cl + PL, ... of its XCD chunk (the
+// one-tile-per-block schedule as ONE persistent launch: a tile's output stores drain while the next tile's main loop
+// runs, and there is no block dispatch between rounds)
+static int sk_make_plan(const GemmParams& p, const int P, SkParams& sk, const bool persistent_only = false) {
   const int T = p.total_tiles;
   memset(&sk, 0, sizeof(sk));
   int64_t I = 0;
@@ -1102,7 +1111,13 @@ static int sk_make_plan(const GemmParams& p, const int P, SkParams& sk) {
   for (int x = 0; x < 8; ++x) {
     const int Tc = chunk_tile[x + 1] - chunk_tile[x];
     sk.chunk_tile[x] = chunk_tile[x];
+    sk.chunk_tiles[x] = Tc;
     sk.chunk_end[x] = chunk_tile[x + 1] == T ? (int)I : iter_of_tile(chunk_tile[x + 1]);
+    if (persistent_only) {
+      sk.dp_rounds[x] = cdiv(Tc, PL);
+      sk.sk_begin[x] = sk.chunk_end[x];   // empty stream-K region
+      continue;
+    }
     // the stream-K region is the remainder after the full rounds (workers are out of K-phase there and share less
     // in the L2, so it is kept short); if that leaves < 8 K-tiles per worker, the last full round joins it
     sk.dp_rounds[x] = Tc / PL;
@@ -1134,10 +1149,12 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   // under this kernel), so a last round that leaves CUs idle costs less than its tile count suggests, while the
   // stream-K region loses the lock-step L2 sharing of A/W panels.  Stream-K wins below ~83 % round utilisation
   // (S=5632: 264 tiles +40..58 %, 792 tiles +9 %, 1056 tiles +5 %) and loses above it (S=4608: 0.84 -> -2..-10 %).
-  if (g_force_sk < 0 && (double)T / ((double)rounds * P) >= 0.83) return 0;
+  const bool persistent_only = g_force_sk == 2 || (g_force_sk < 0 && !W8 && g_persistent_rounds > 0 && rounds >= g_persistent_rounds &&
+                                                   (double)T / ((double)rounds * P) >= 0.83);
+  if (g_force_sk < 0 && !persistent_only && (double)T / ((double)rounds * P) >= 0.83) return 0;
   SkParams sk;
   {
-    const int ok = sk_make_plan(p, P, sk);
+    const int ok = sk_make_plan(p, P, sk, persistent_only);
     if (ok != 1) return ok;
   }
   sk.flags = (int*)ws;
@@ -1396,8 +1413,13 @@ extern "C" int rf_debug_sk_plan(const rf_gemm_desc* d, int32_t num_cus, int32_t*
 
 extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }
 
+extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds
+  rf::g_persistent_rounds = rounds < 0 ? 0 : rounds;
+  return RF_OK;
+}
+
 extern "C" int rf_debug_force_gemm_sk(int mode) {
-  if (mode < -1 || mode > 1) return RF_ERR_SHAPE;
+  if (mode < -1 || mode > 2) return RF_ERR_SHAPE;
   rf::g_force_sk = mode;
   return RF_OK;
 }

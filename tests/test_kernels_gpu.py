@@ -561,3 +561,32 @@ def test_gemm_pingpong_cold_cache_stress(dev):
         lib.rf_debug_force_gemm_tile(0)
         del flush
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("rows,N,K", [((512, 4096), 9216, 3072), ((4608,), 3072, 3072), ((300, 5000, 77), 1536, 256)])
+def test_gemm_persistent_whole_tiles_equals_tile_per_block(dev, rows, N, K):
+    """rf_debug_force_gemm_sk(2): the persistent launch that walks whole 256x256 tiles (no stream-K region) computes
+    every tile with the same loop and epilogue as the one-tile-per-block launch -> bit-identical outputs, also with
+    several token groups and a partial last round."""
+    from reflectionflow_amd import _lib, ops
+    from reflectionflow_amd.ops import RF_EPI_GATE_RES, Group, Seg
+    lib = _lib.load()
+    xs = [rnd(m, K, dev=dev, seed=50 + i) for i, m in enumerate(rows)]
+    Ws = [rnd(N, K, dev=dev, scale=0.05, seed=60 + i) for i in range(len(rows))]
+    b, gate = rnd(N, dev=dev), rnd(N, dev=dev)
+    res = [rnd(m, N, dev=dev, seed=70 + i) for i, m in enumerate(rows)]
+    outs = {}
+    for mode in (0, 2):
+        lib.rf_debug_force_gemm_sk(mode)
+        lib.rf_debug_force_gemm_tile(256)
+        try:
+            o = [r_.clone() for r_ in res]
+            ops.gemm([Group([Seg(xs[i], Ws[i])], bias=b, out=o[i], residual=o[i], gate=gate) for i in range(len(rows))], N, RF_EPI_GATE_RES)
+            assert lib.rf_debug_last_gemm_path() == mode
+            outs[mode] = o
+        finally:
+            lib.rf_debug_force_gemm_sk(-1)
+            lib.rf_debug_force_gemm_tile(0)
+    for i in range(len(rows)):
+        assert torch.equal(outs[0][i], outs[2][i]), f"group {i}: persistent != tile-per-block"
+        assert_close(outs[2][i], res[i].float() + gate.float() * (xs[i].float() @ Ws[i].float().t() + b.float()), f"persistent group {i}")

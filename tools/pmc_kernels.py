@@ -24,9 +24,13 @@ def dbl_ff1(): ops.gemm([Group([Seg(xn[t], W1b)], bias=bm, out=hid[t]), Group([S
 def dbl_ff2(): ops.gemm([Group([Seg(hid[t], W2b)], bias=b1, gate=gate, out=x[t], residual=x[t]), Group([Seg(hid[i], W2)], bias=b1, gate=gate, out=x[i], residual=x[i])], D, RF_EPI_GATE_RES)
 def sgl_in(): ops.gemm([Group([Seg(xn, Wf)], bias=bfu, out=hid, tok_offset=0, norm_q=nw[0], norm_k=nw[1])], 3 * D + mlp, RF_EPI_QKV_GELU, n_split=3 * D, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin))
 def sgl_out(): ops.gemm([Group([Seg(att, Ws[:, :D]), Seg(hid, Ws[:, D:])], bias=b1, gate=gate, out=x, residual=x)], D, RF_EPI_GATE_RES)
-def attn(): ops.attention(q, k, vt, S, out=att)
-q.normal_(); k.normal_(); vt.normal_()
-for fn in (dbl_qkv, dbl_out, dbl_ff1, dbl_ff2, sgl_in, sgl_out, attn):
+for fn in (dbl_qkv, dbl_out, dbl_ff1, dbl_ff2, sgl_in, sgl_out):
     fn(); torch.cuda.synchronize()      # warm-up (dispatch 1 of the pair)
     fn(); torch.cuda.synchronize()      # measured (dispatch 2 of the pair)
+# attention as the engine calls it: prescaled q, proven score bound -> bounded-score kernel (v4); fresh random operands
+# (the QKV launches above overwrote q / k / vt)
+q.normal_(); k.normal_(); vt.normal_(); q.mul_(ops.QK_PRESCALE)
+BOUND = float(q.float().norm(dim=-1).max() * k.float().norm(dim=-1).max()) * 1.01
+for _ in range(2):
+    ops.attention(q, k, vt, S, out=att, q_prescaled=True, score_bound=BOUND); torch.cuda.synchronize()
 print("done")

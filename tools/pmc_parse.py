@@ -9,7 +9,8 @@ Conventions (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"; calibrated on
     verified: it equals 32 * flops / (2*16384) to 4 digits for every launch below.
   * GRBM_GUI_ACTIVE is summed over the 8 XCDs -> kernel cycles = GRBM_GUI_ACTIVE / 8; clock = cycles / duration.
 """
-import collections, csv, glob, json, os
+import collections, csv, glob, json, os, sys
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"     # output prefix under profiles/
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = collections.OrderedDict()
 names = ['dbl_qkv', 'dbl_out', 'dbl_ff1', 'dbl_ff2', 'sgl_in', 'sgl_out', 'attn']
@@ -36,7 +37,7 @@ alg = {'dbl_qkv': (S*D*2 + 2*3*D*D*2 + S*3*D*2, 2.0*S*3*D*D, 19), 'dbl_out': (S*
        'sgl_in': (S*D*2 + (3*D+mlp)*D*2 + S*(3*D+mlp)*2, 2.0*S*(3*D+mlp)*D, 38),
        'sgl_out': (S*(D+mlp)*2 + D*(D+mlp)*2 + 2*S*D*2, 2.0*S*D*(D+mlp), 38), 'attn': (4*S*D*2, 4.0*S*S*D, 57)}
 out = collections.OrderedDict()
-md = ["# Round 1 -- PMC counters of the dominant kernels (MI355X, rocprofv3 --pmc, one measured launch each)", "",
+md = [f"# {ROUND} -- PMC counters of the dominant kernels (MI355X, rocprofv3 --pmc, one measured launch each)", "",
       "Command: `bash tools/pmc_collect.sh` (5 separate `rocprofv3 --kernel-trace --pmc ...` passes over `tools/pmc_kernels.py`), parsed by `tools/pmc_parse.py`.",
       "Shapes are the launches of one 1024^2 FLUX.1-dev forward (512 text + 4096 image tokens). Profiled runs are ~10-15 % slower than un-profiled ones.", "",
       "| launch (per forward) | kernel | us | fabric read MB (FETCH_SIZE x2) | write MB | algorithmic MB | traffic / algorithmic | MFMA busy % | clock GHz | LDS bank-conflict % |",
@@ -47,7 +48,7 @@ for n, e in rows.items():
     ab, fl, cnt = alg[n]
     cyc = e['GRBM_GUI_ACTIVE'] / 8
     util = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) * 100
-    assert abs(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (32 * fl / 32768) - 1) < 0.02, n
+    assert abs(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (32 * fl / 32768) - 1) < 0.03, n   # v4 attention: +1.4 % (one stale score tile, one zero PV)
     clk = cyc / e['ns_p4']
     ldsc = e['SQ_LDS_BANK_CONFLICT'] / max(e['SQ_LDS_IDX_ACTIVE'], 1) * 100
     out[n] = dict(kernel=e['kernel'], launches_per_forward=cnt, us_profiled=round(us, 1), fabric_read_bytes=fetch, write_bytes=write,
@@ -66,6 +67,6 @@ md += ["", f"GEMM kernel, forward-weighted: traffic {summary['gemm_traffic_bytes
            "at the clock the chip actually sustains (1.8-2.07 GHz, not 2.4).",
        "Reading: the >2x traffic ratio is operand panels re-read by several XCDs (private L2s) and served by the Infinity Cache -- the kernels are far from "
        "the fabric limit (<= 2 TB/s of ~6) and are bound by MFMA issue efficiency, not by memory. Zero LDS bank conflicts confirms the XOR/padded layouts."]
-json.dump(out, open(os.path.join(ROOT, 'profiles/r01_pmc_kernels.json'), 'w'), indent=1)
-open(os.path.join(ROOT, 'profiles/r01_pmc_kernels.md'), 'w').write("\n".join(md) + "\n")
+json.dump(out, open(os.path.join(ROOT, f'profiles/{ROUND}_pmc_kernels.json'), 'w'), indent=1)
+open(os.path.join(ROOT, f'profiles/{ROUND}_pmc_kernels.md'), 'w').write("\n".join(md) + "\n")
 print("\n".join(md))
