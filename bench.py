@@ -15,7 +15,7 @@
              one; rank 0 prints the line.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-    roofline     -- the dominant kernel class (the 256x256-tile bf16 MFMA GEMM): algorithmic FLOPs of its launches /
+    roofline     -- the dominant kernel class (the 256x256-tile bf16 MFMA GEMM; persistent whole-tile launches of the ping-pong loop): algorithmic FLOPs of its launches /
                     their summed durations, both taken INSIDE the real forward sequence: right after the timed
                     region one more candidate is denoised for a few steps with the library's in-sequence timing hook
                     on (a hipEvent pair around every kernel launch on its launch stream, rf_profile_begin/_end), so
@@ -173,7 +173,7 @@ def in_sequence_roofline(one_latent_steps, T_prof, ms_per_forward_timed, dims):
     per_fwd["gemm_main"]["tflops"] = round(ach, 1)
     sum_ms = sum(v["us"] for v in cl.values()) / T_prof / 1e3
     traffic, traffic_src = pmc_traffic(*dims)
-    return {"bound": "mfma", "kernel": "rf::gemm_bf16_pp_kernel (256x256x64 ping-pong; 256x256-tile launches)",
+    return {"bound": "mfma", "kernel": "256x256x64 bf16 MFMA GEMM, ping-pong loop (rf::gemm_bf16_sk_kernel<256,256,4,2,false> in persistent whole-tile mode / rf::gemm_bf16_pp_kernel)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
             "traffic_source": traffic_src,
