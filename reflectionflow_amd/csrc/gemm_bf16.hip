@@ -636,7 +636,10 @@ __device__ __forceinline__ void mma_quadrant(f32x16& c0, f32x16& c1, const bf16x
   }
 }
 
-template <bool W8 = false>
+// VAR (experiments, rf_debug_force_gemm_tile(259) + rf_debug_gemm_w4_knock(VAR)): 0 = production order;
+// 1 = a phase's fragment reads are issued BEFORE its two DMA pieces; timing-only knock-outs (wrong results):
+// 2 = no DMA in the loop, 3 = no fragment reads, 4 = neither.
+template <bool W8 = false, int VAR = 0>
 __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                  const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
   constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
@@ -737,16 +740,38 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     const char* base = smem + (t & 1) * BUF;
     const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
     // ---- p0 -------------------------------------------------------------------------------
-    if (more1) stage(1, c1, (t + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
+    constexpr bool DMA = VAR != 2 && VAR != 4, RD = VAR != 3 && VAR != 4, RD_FIRST = VAR == 1;
+    auto rd0 = [&]() {
+      if (!RD) return;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int coff = frag_coff(ks);
-      a0[ks] = *(const bf16x8*)(base + a_off + coff);
-      bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
-      bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
-    }
+      for (int ks = 0; ks < 4; ++ks) {
+        const int coff = frag_coff(ks);
+        a0[ks] = *(const bf16x8*)(base + a_off + coff);
+        bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
+        bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto rd1 = [&]() {
+      if (!RD) return;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a1[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto rd2 = [&]() {
+      if (!RD) return;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int coff = frag_coff(ks);
+        bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
+        bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (RD_FIRST) rd0();
+    if (more1 && DMA) stage(1, c1, (t + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (!RD_FIRST) rd0();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     mma_quadrant<W8>(acc[0][0], acc[0][1], a0, bq[0], bq[1]);
@@ -754,11 +779,10 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- p1 -------------------------------------------------------------------------------
-    if (more1) stage(3, c1, (t + 1) & 1);
+    if (RD_FIRST) rd1();
+    if (more1 && DMA) stage(3, c1, (t + 1) & 1);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) a1[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
-    __builtin_amdgcn_sched_barrier(0);
+    if (!RD_FIRST) rd1();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     mma_quadrant<W8>(acc[1][0], acc[1][1], a1, bq[0], bq[1]);
@@ -766,15 +790,10 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- p2 -------------------------------------------------------------------------------
-    if (more2) stage(0, c2, t & 1);
+    if (RD_FIRST) rd2();
+    if (more2 && DMA) stage(0, c2, t & 1);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int coff = frag_coff(ks);
-      bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
-      bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    if (!RD_FIRST) rd2();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     mma_quadrant<W8>(acc[1][2], acc[1][3], a1, bq[0], bq[1]);
@@ -782,7 +801,7 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- p3 -------------------------------------------------------------------------------
-    if (more2) {
+    if (more2 && DMA) {
       stage(2, c2, t & 1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but this tile's p2/p3 stages has landed
     } else {
@@ -798,6 +817,188 @@ __device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const in
     next(c1);
     next(c2);
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
+}
+
+// Balanced ping-pong schedule (experiment VAR 5; see profiles/r02_kb_ppx*.log and r02_ubench_lds_port.log).
+// The knock-outs say the production loop loses ~7 % to DMA alone, ~10 % to fragment reads alone, but 35 % to both:
+// its load phases carry 12 / 4 / 8 / 0 fragment reads and 2 DMA pieces each, and a wave group's load phase must fit under
+// the other group's 8 MFMAs (256 cycles).  Four waves' 12 reads are 384 cycles of the 128 B/clk LDS before any latency,
+// and the two DMA pieces queue behind three other waves' on the 64 B/clk DMA path (~128 cycles) -- phase 0 is twice its
+// budget while phase 3 idles.  Here the phases carry 8 / 4 / 8 / 4 reads and 0 / 4 / 0 / 4 pieces: the next tile's A0
+// fragments are read in phase 3 into the registers A1 just vacated (the two A register sets swap roles every tile, so
+// the loop is unrolled by two), and all DMA sits in the two light phases, behind that phase's reads.
+// Staging (buffer u & 1 holds tile u; a region may be overwritten two phases after the phase that reads it, which is
+// when BOTH wave groups have passed a barrier behind their reads of it):
+//   p1(t): A0(t+2) [last read p3(t-1)], B1(t+1) [B1(t-1) read p2(t-1)]      p3(t): B0(t+2) [read p0(t)], A1(t+2) [read p1(t)]
+// Every piece is issued >= 5 phases before its first read; s_waitcnt vmcnt(8) behind each issue retires the batch
+// issued two DMA phases earlier, one barrier before its first reader.
+template <bool W8>
+__device__ __forceinline__ void gemm_mainloop_pp2(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                                  const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
+  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
+  constexpr int HT = 128 * 128;  // half-tile bytes
+  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
+  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M;
+
+  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
+  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
+  const int r8 = lane >> 3;
+  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
+  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
+  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
+  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
+  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
+  auto load_seg = [&](Cur& c) {
+    const KSegDev& S = G.seg[c.seg];
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
+    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+    // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
+        const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
+        c.offA[sb][i] = (uint32_t)(gm < M ? gm : M - 1) * lda2 + chunk_b;
+        c.offB[sb][i] = (uint32_t)(gn < N ? gn : N - 1) * ldw2 + chunk_b;
+      }
+  };
+  auto next = [&](Cur& c) {
+    ++c.kk;
+    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+      c.kk = 0;
+      ++c.seg;
+      load_seg(c);
+    }
+  };
+  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](const int kind, const Cur& c, const int buf) {
+    char* dst = smem + buf * BUF + kind * HT + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
+      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a buffer
+  const int swz = (l31 >> 1) & 7;
+  const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
+  const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
+  // logical 16-byte chunk of fragment ks: bf16 k-step ks = chunks 2ks + h; fp8 k-step ks/2 = chunks 4(ks/2) + 2h + (ks&1)
+  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
+
+  Cur c1;
+  c1.seg = 0; c1.kk = kt_begin;
+  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
+    c1.kk -= G.seg[c1.seg].nk;
+    ++c1.seg;
+  }
+  load_seg(c1);
+  // prologue, in steady-state issue order: A0(0) | B0(0) A1(0) | A0(1) B1(0) | B0(1) A1(1)
+  Cur c2 = c1;
+  if (nk > 1) {
+    next(c2);                                        // c1 = tile 0, c2 = tile 1
+    stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0);
+    stage(0, c2, 1); stage(3, c1, 0);
+    stage(2, c2, 1); stage(1, c2, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 but B1 has landed
+    c1 = c2;                                         // c1 -> tile 1
+    next(c2);                                        // c2 -> tile 2
+  } else {
+    stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 X[4], Y[4], bq[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) X[ks] = *(const bf16x8*)(smem + a_off + frag_coff(ks));   // A0 of tile 0
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+#define RF_PP2_BAR()                    \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_barrier();         \
+  __builtin_amdgcn_sched_barrier(0)
+  // one K-tile: P holds its A0 fragments (read during the previous tile's phase 3), Q receives A1, then the next A0
+  auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
+    const char* base = smem + (t & 1) * BUF;
+    const char* nbase = smem + ((t + 1) & 1) * BUF;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- p0: 8 reads ---------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = frag_coff(ks);
+      bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
+      bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
+    }
+    RF_PP2_BAR();
+    mma_quadrant<W8>(acc[0][0], acc[0][1], P, bq[0], bq[1]);
+    RF_PP2_BAR();
+    // ---- p1: 4 reads, 4 pieces -----------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stage(0, c2, t & 1); stage(3, c1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (more1) {
+      stage(3, c1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP2_BAR();
+    mma_quadrant<W8>(acc[1][0], acc[1][1], Q, bq[0], bq[1]);
+    RF_PP2_BAR();
+    // ---- p2: 8 reads ---------------------------------------------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = frag_coff(ks);
+      bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
+      bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
+    }
+    RF_PP2_BAR();
+    mma_quadrant<W8>(acc[1][2], acc[1][3], Q, bq[0], bq[1]);
+    // the next tile's A0 goes into Q: keep its reads behind these MFMAs' operand fetch
+    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
+    RF_PP2_BAR();
+    // ---- p3: 4 reads (next tile's A0), 4 pieces ------------------------------------------
+    if (more1) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(nbase + a_off + frag_coff(ks));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stage(2, c2, t & 1); stage(1, c2, t & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP2_BAR();
+    mma_quadrant<W8>(acc[0][2], acc[0][3], P, bq[0], bq[1]);
+    RF_PP2_BAR();
+    next(c1);
+    next(c2);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    tile(t, X, Y);
+    if (t + 1 < nk) tile(t + 1, Y, X);
+  }
+#undef RF_PP2_BAR
   if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
 }
 
@@ -823,22 +1024,234 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
     // mixed-precision launch: the multiply is chosen per token group (wave-uniform): fp8 groups next to bf16 groups
     // (the LoRA'd condition rows of cfg5) in one grid, so the small group fills the tail instead of its own launch
     if (G.w8) {
-      gemm_mainloop_pp<true>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+      gemm_mainloop_pp2<true>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
       __syncthreads();
       gemm_epilogue_lds<2, true>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
     } else {
-      gemm_mainloop_pp<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+      gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
       __syncthreads();
       gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
     }
   } else {
-    gemm_mainloop_pp<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+    gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
     __syncthreads();  // every wave is done reading the staged operands: the LDS is free
     gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
   }
 }
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) { gemm_pp_body<false>(p); }
 __global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
+
+// experiment harness for the ping-pong main loop (one tile per block, bf16 only): rf_debug_force_gemm_tile(259)
+template <int VAR>
+__global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  int tm, tn;
+  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  f32x16 acc[2][4];
+  if constexpr (VAR == 5) gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  else gemm_mainloop_pp<false, VAR>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  __syncthreads();
+  gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+}
+
+// ---- one wave per SIMD (experimental, rf_debug_force_gemm_tile(258)) -------------------------------------------
+// 256x256x64 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 4 x 4 MFMA fragments: 256 accumulator registers per lane,
+// which only fit because a 256-thread block leaves each SIMD to ONE wave (512 unified VGPR/AGPR).  Per K-tile a wave
+// multiplies 64 MFMAs from 32 fragment reads (0.5 per MFMA vs 0.75 in the 8-wave kernels) and there is no second wave
+// to arbitrate the matrix pipe with, so the schedule is the bounded-score attention kernel's: per k-step (16 MFMAs) four
+// groups of four, each fenced by sched_barrier(0), each first issuing two of the NEXT k-step's eight fragment reads
+// into the other half of a double buffer plus one or two of the next K-tile's sixteen LDS-DMA pieces.  One barrier per
+// K-tile, in front of the last k-step's MFMAs (whose fragments are already in registers), so the first reads of the
+// next tile fly under 16 MFMAs.  Two 64 KiB LDS stages; the epilogue needs only 4 x 16.5 KiB.
+#ifndef RF_W4_NSLOT
+#define RF_W4_NSLOT 8
+#endif
+// KNOCK (timing diagnostics only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no fragment reads in the loop,
+// 4 = no per-tile wait + barrier.
+template <bool W8, int KNOCK = 0>
+__device__ __forceinline__ void gemm_mainloop_w4(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                                 const int nk, f32x16 (&acc)[4][4], char* smem, const int w, const int lane) {
+  constexpr int ESZ = W8 ? 1 : 2;
+  constexpr int STAGE = 65536, A_BYTES = 32768;
+  const int wm = w >> 1, wn = w & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M;
+  // DMA piece p = i*4 + w (i = 0..15) fills stage rows p*8 + lane/8: pieces 0..31 are A rows, 32..63 W rows
+  const int r8 = lane >> 3;
+  uint32_t rowsrc[16];   // clamped global row of piece i (A for i < 8, W for i >= 8)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = i * 4 + w;
+    if (i < 8) {
+      const int gm = m0 + p * 8 + r8;
+      rowsrc[i] = (uint32_t)(gm < M ? gm : M - 1);
+    } else {
+      const int gn = n0 + (p - 32) * 8 + r8;
+      rowsrc[i] = (uint32_t)(gn < N ? gn : N - 1);
+    }
+  }
+  // swizzled 16-byte chunk this lane fetches: stage row = p*8 + r8, (row >> 1) & 7 = ((w*8 + r8) >> 1) & 7 since p*8 = i*32 + w*8
+  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w * 8 + r8) >> 1) & 7)) * 16);
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t off[16]; };
+  auto load_seg = [&](Cur& c) {
+    const KSegDev& S = G.seg[c.seg];
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
+    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c.off[i] = rowsrc[i] * (i < 8 ? lda2 : ldw2) + chunk_b;
+  };
+  auto next = [&](Cur& c) {
+    ++c.kk;
+    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+      c.kk = 0;
+      ++c.seg;
+      load_seg(c);
+    }
+  };
+  auto dma_piece = [&](const int i, const Cur& c, const int buf) {
+    char* dst = smem + buf * STAGE + (i * 4 + w) * 1024;
+    if (i < 8) RF_BUF_LOAD_LDS(c.A, (lds_void*)dst, c.off[i], c.kk * 128);
+    else RF_BUF_LOAD_LDS(c.W, (lds_void*)dst, c.off[i], c.kk * 128);
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int swz = (l31 >> 1) & 7;
+  const char* a_rd = smem + (wm * 128 + l31) * 128;               // + i*4096 + coff(ks) + buf*STAGE
+  const char* b_rd = smem + A_BYTES + (wn * 128 + l31) * 128;     // + j*4096 + coff(ks) + buf*STAGE
+  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
+
+  Cur c1;
+  c1.seg = 0; c1.kk = kt_begin;
+  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
+    c1.kk -= G.seg[c1.seg].nk;
+    ++c1.seg;
+  }
+  load_seg(c1);
+  // DMA schedule.  A buffer_load..lds occupies the CU's one LDS-DMA path for ~16 cycles and the ISSUING wave waits for
+  // it: four waves issuing in lock step (which the per-tile barrier makes them) each wait for all four
+  // (tools/kb_w4_knock.py: 1375 cycles per K-tile).  So the 16 groups of a tile are SLOTS and wave w issues only in
+  // slots s == w (mod 4), one or two pieces behind each of the slot's MFMAs.  Tile u's pieces go out in the NSLOT slots
+  // that start right after the barrier of tile u-2 (k-step 3 of tile u-2, then the first groups of tile u-1): the
+  // stage is free from that barrier on, and the data has the rest of tile u-1 to land before ITS barrier.
+  constexpr int NSLOT = RF_W4_NSLOT;           // 8 or 12
+  constexpr int PER = NSLOT / 4;               // slots a wave owns per tile: 2 (8 + 8 pieces) or 3 (6 + 5 + 5)
+  auto slot_first = [](int k) { return PER == 2 ? k * 8 : (k == 0 ? 0 : 1 + k * 5); };
+  auto slot_cnt = [](int k) { return PER == 2 ? 8 : (k == 0 ? 6 : 5); };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dma_piece(i, c1, 0);   // tile 0, whole
+  next(c1);                                            // c1 -> tile 1
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < slot_cnt(0); ++i) dma_piece(i, c1, 1);   // tile 1, this wave's first slot
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa[2][4], fb[2][4];   // fragment double buffer by k-step parity
+  // fragments of k-step ks of the tile in stage `buf`, read e of 8: e < 4 -> A row block e, else W column block e - 4
+  auto rd = [&](const int buf, const int ks, const int e, const int par) {
+    const int coff = frag_coff(ks) + buf * STAGE;
+    if (e < 4) fa[par][e] = *(const bf16x8*)(a_rd + e * 4096 + coff);
+    else fb[par][e - 4] = *(const bf16x8*)(b_rd + (e - 4) * 4096 + coff);
+  };
+#pragma unroll
+  for (int e = 0; e < 8; ++e) rd(0, 0, e, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // four MFMAs of group g (row block g x the four column blocks); with DMA: pieces [first, first+cnt) of the tile under
+  // cursor c1 into stage dbuf, spread behind the MFMAs
+  auto mfma = [&](const int g, const int j, const int par) {
+    if constexpr (!W8) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[par][g], fb[par][j], acc[g][j], 0, 0, 0);
+  };
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    const bool more = t + 1 < nk;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int par = ks & 1;
+      if (ks == 3 && !(KNOCK & 4)) {
+        // the last k-step's fragments are in registers: retire this wave's LDS traffic on the tile, let every wave's
+        // DMA of tile t+1 land, then read tile t+1's first fragments UNDER this k-step's 16 MFMAs
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass can see
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q = ks * 4 + g;
+        if (!(KNOCK & 2)) {
+          if (ks < 3) {
+            rd(buf, ks + 1, 2 * g, par ^ 1);
+            rd(buf, ks + 1, 2 * g + 1, par ^ 1);
+          } else if (more) {
+            rd(buf ^ 1, 0, 2 * g, 0);
+            rd(buf ^ 1, 0, 2 * g + 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // slot of this group: k-step 3 opens tile t+2's slots 0..3 (stage buf, free since the barrier above);
+        // groups 0..NSLOT-5 are tile t+1's slots 4..NSLOT-1 (stage buf ^ 1)
+        const int s = q >= 12 ? q - 12 : (q < NSLOT - 4 ? q + 4 : -1);
+        const bool exists = q >= 12 ? t + 2 < nk : more;
+        const bool own = s >= 0 && !(KNOCK & 1) && exists && (s & 3) == w;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mfma(g, j, par);
+          if (s >= 0 && !(KNOCK & 1)) {       // only the DMA issue is conditional: no accumulator crosses a branch
+            __builtin_amdgcn_sched_barrier(0);
+            if (own) {
+              const int first = slot_first(s >> 2), cnt = slot_cnt(s >> 2);
+#pragma unroll
+              for (int d = (cnt * j) / 4; d < (cnt * (j + 1)) / 4; ++d) dma_piece(first + d, c1, q >= 12 ? buf : buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("" : "+a"(acc[g][0]), "+a"(acc[g][1]), "+a"(acc[g][2]), "+a"(acc[g][3]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == NSLOT - 5 && more) next(c1);   // tile t+1's last slot is out: the cursor moves to tile t+2
+      }
+    }
+  }
+}
+
+template <int KNOCK>
+__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  int tm, tn;
+  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  f32x16 acc[4][4];
+  gemm_mainloop_w4<false, KNOCK>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  __syncthreads();
+  gemm_epilogue_lds<4, false>(p, G, acc, m0, n0, (w >> 1) * 128, (w & 1) * 128, lane, smem + w * EPI_REGION);
+}
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
 // One persistent block per CU.  The launch's MAC work is measured in K-tile iterations (tile-major) and cut into
@@ -934,8 +1347,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
     asm volatile("" : "+v"(lane_i), "+v"(tid_i));
     f32x16 acc[FM][FN];
     const bool g8 = W8 && G.w8;   // mixed-precision launch: multiply chosen per token group
-    if (g8) gemm_mainloop_pp<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
-    else gemm_mainloop_pp<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
+    if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    else gemm_mainloop_pp2<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
 
     if (!is_tail) {
       // head or middle piece: raw accumulators -> this block's slot, [quad k][thread] x 16 B, as agent-coherent
@@ -1017,6 +1430,57 @@ static void layout_tiles(GemmParams& p) {
   }
   p.total_tiles = start;
 }
+
+static int g_w4_knock = 0;
+template <int KNOCK>
+static int launch_gemm_w4_k(GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 2 * 65536;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<KNOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  layout_tiles<256, 256>(p);
+  if (p.total_tiles == 0) return RF_OK;
+  hipLaunchKernelGGL(gemm_bf16_w4_kernel<KNOCK>, dim3(p.total_tiles), dim3(256), LDS, stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+template <int VAR>
+static int launch_gemm_ppx_v(GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 8 * EPI_REGION;   // > the main loop's 128 KiB
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_ppx_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  layout_tiles<256, 256>(p);
+  if (p.total_tiles == 0) return RF_OK;
+  hipLaunchKernelGGL(gemm_bf16_ppx_kernel<VAR>, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+static int launch_gemm_ppx(GemmParams& p, hipStream_t stream) {
+  switch (g_w4_knock) {
+    case 1: return launch_gemm_ppx_v<1>(p, stream);
+    case 2: return launch_gemm_ppx_v<2>(p, stream);
+    case 3: return launch_gemm_ppx_v<3>(p, stream);
+    case 4: return launch_gemm_ppx_v<4>(p, stream);
+    case 5: return launch_gemm_ppx_v<5>(p, stream);
+    default: return launch_gemm_ppx_v<0>(p, stream);
+  }
+}
+static int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
+  switch (g_w4_knock) {
+    case 1: return launch_gemm_w4_k<1>(p, stream);
+    case 2: return launch_gemm_w4_k<2>(p, stream);
+    case 3: return launch_gemm_w4_k<3>(p, stream);
+    case 4: return launch_gemm_w4_k<4>(p, stream);
+    case 7: return launch_gemm_w4_k<7>(p, stream);
+    default: return launch_gemm_w4_k<0>(p, stream);
+  }
+}
+
 
 template <int BM, int BN, int WM, int WN, bool VEC, bool TL = false>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
@@ -1317,9 +1781,9 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
-  if (tile == 257 && !p.vec_ok) tile = 256;
+  if ((tile == 257 || tile == 258 || tile == 259) && (!p.vec_ok || p.w8)) tile = 256;
   if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
-  if (tile == 256 && p.vec_ok && g_force_sk != 0) {
+  if (tile == 256 && p.vec_ok && g_force_sk != 0) {   // (forced 257 / 258 skip the stream-K / persistent paths)
     const int rc = p.w8 ? try_launch_gemm_sk<256, 256, 4, 2, true>(p, ws_base, ws_total, stream)
                         : try_launch_gemm_sk<256, 256, 4, 2, false>(p, ws_base, ws_total, stream);
     if (rc != 0) return rc < 0 ? rc : RF_OK;
@@ -1349,6 +1813,8 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   g_last_path = 0;
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
   if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (A/B reference)
+  if (tile == 258) return launch_gemm_w4(p, stream);                       // one wave per SIMD (experimental A/B)
+  if (tile == 259) return launch_gemm_ppx(p, stream);                      // ping-pong loop experiments
   if (tile == 256) return p.vec_ok ? launch_gemm_pp(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }
@@ -1371,7 +1837,7 @@ extern "C" int rf_gemm_w8a8(const rf_gemm_desc* d, void* stream) {
 
 // test / tuning hook (not part of the drop-in surface): force a tile config (0 = heuristic)
 extern "C" int rf_debug_force_gemm_tile(int tile) {
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return RF_ERR_SHAPE;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 257 && tile != 258 && tile != 259) return RF_ERR_SHAPE;
   rf::g_force_tile = tile;
   return RF_OK;
 }
@@ -1413,6 +1879,7 @@ extern "C" int rf_debug_sk_plan(const rf_gemm_desc* d, int32_t num_cus, int32_t*
 
 extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }
 
+extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
 extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds
   rf::g_persistent_rounds = rounds < 0 ? 0 : rounds;
   return RF_OK;

@@ -1,0 +1,34 @@
+"""Ping-pong main loop experiments (rf_debug_force_gemm_tile(259), variant via rf_debug_gemm_w4_knock):
+0 production order, 1 reads before DMA, 2 no DMA (timing only), 3 no reads (timing only), 4 neither (timing only)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib, ops
+lib = _lib.load()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+NAMES = {0: "production", 1: "reads first", 2: "no DMA", 3: "no reads", 4: "MFMA+barriers"}
+if len(sys.argv) > 1:
+    NAMES = {int(k): NAMES.get(int(k), f"var{k}") for k in sys.argv[1].split(",")}
+for (M, N, K) in ((4608, 3072, 12288), (4608, 9216, 3072)):
+    a = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.05
+    y = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    g = [ops.Group([ops.Seg(a, w)], out=y)]
+    ref = a.float() @ w.float().t()
+    lib.rf_debug_force_gemm_tile(259)
+    for k in NAMES:
+        if k in (2, 3, 4):
+            continue
+        lib.rf_debug_gemm_w4_knock(k)
+        ops.gemm(g, N, splitk_ws=False)
+        err = ((y.float() - ref).norm() / ref.norm()).item()
+        print(f"var {k} {M}x{N}x{K}: rel-L2 {err:.3e}", flush=True)
+        assert err < 5e-3
+    nkt = K // 64
+    for rep in range(3):
+        for k, name in NAMES.items():
+            lib.rf_debug_gemm_w4_knock(k)
+            t = ops.time_gemm(g, N, iters=20, splitk_ws=False)
+            print(f"{M}x{N}x{K} {name:16s} {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF", flush=True)
+    lib.rf_debug_gemm_w4_knock(0)
+    lib.rf_debug_force_gemm_tile(0)

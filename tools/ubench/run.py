@@ -32,3 +32,9 @@ for blocks in (1, 256):
     show("8 x ds_read_b128 + wait, 4 waves: cycles per group of 8", run(4, 4, blocks), REP, 4)
     show("8 x ds_read_b128 + wait, 8 waves: cycles per group of 8", run(4, 8, blocks), REP)
     show("ping-pong skeleton (8 MFMA, 2 barriers): cycles per phase", run(5, 8, blocks), REP)
+
+print("---- LDS port sharing (1 workgroup; 8 x 1 KiB per iteration per wave; cycles per KiB per wave) ----")
+for blocks in (1, 256):
+    for name, t in (("ds_read_b128 x4 waves alone", 6), ("LDS-DMA x4 waves alone", 7), ("ds_read x4 + LDS-DMA x4 together", 8),
+                    ("ds_write_b128 x4 waves alone", 9), ("ds_read x4 + ds_write x4 together", 10)):
+        show(f"[{blocks} wg] {name}", run(t, 8, blocks), REP * 4 * 8)

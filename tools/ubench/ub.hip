@@ -106,6 +106,41 @@ __global__ __launch_bounds__(512) void ub_kernel(int test, int nw, const char* g
     t1 = now();
     if (grp == 0) __builtin_amdgcn_s_barrier();
   }
+  else if (test >= 6 && test <= 10) {
+    // LDS port sharing: waves 0..3 stream conflict-free ds_read_b128 (tests 6, 8, 10); waves 4..7 stream LDS-DMA pieces
+    // (tests 7, 8) or ds_write_b128 (tests 9, 10).  Alone vs together tells whether DMA / ds_write and ds_read share the port.
+    const bool reader = w < 4 && (test == 6 || test == 8 || test == 10);
+    const bool dma = w >= 4 && (test == 7 || test == 8);
+    const bool writer = w >= 4 && (test == 9 || test == 10);
+    const char* rbase = smem + ((lane & 31) * 128 + (((lane >> 5) ^ ((lane >> 1) & 7)) << 4)) + (w & 3) * 4096;
+    bf16x8 f[8];
+    __syncthreads();
+    t0 = now();
+    if (reader) {
+      for (int r = 0; r < REP * 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = *(const bf16x8*)(rbase + i * 16384 + (((r & 3) * 2) << 4) * 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[0] = (__bf16)((float)a[0] + (float)f[i][0]);
+      }
+    } else if (dma) {
+      for (int r = 0; r < REP * 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(smem + 65536 + ((w - 4) * 8 + i) * 1024), 16, voff, ((r * 8 + i) & 63) * 1024 + w * 65536, 0, 0);
+        if ((r & 1) == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (writer) {
+      for (int r = 0; r < REP * 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(bf16x8*)(smem + 65536 + ((w - 4) * 8 + i) * 1024 + lane * 16) = a;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    t1 = now();
+  }
   float s = (float)a[0];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += acc[i][lane & 15];
