@@ -496,8 +496,12 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
   (f(std::integral_constant<int, I>{}), ...);
 }
 
+__device__ unsigned long long g_attn_clk_probe[4];   // see ClkProbe (common.hpp)
+
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -667,6 +671,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
     tile(t + 3, std::integral_constant<int, 3>{});
   }
 
+  clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
   RF_ATT4_WAIT_BARRIER(0);
   {
@@ -697,6 +702,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
         *(u32x2*)(orow + db * 32 + rg * 8) = v;
       }
   }
+}
+
+int read_clk_probe_attn(unsigned long long* h) {
+  return hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_clk_probe), 4 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
 }
 
 static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)

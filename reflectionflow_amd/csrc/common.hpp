@@ -120,4 +120,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + idx;
 }
 
+// Shader-clock probe: block 0 brackets its work with {s_memtime (shader clocks), s_memrealtime (100 MHz)} and stores the four
+// counters; rf_debug_clock_probe() turns them into the clock the kernel actually ran at.  MI355X is power-limited under
+// dense MFMA + LDS + L2 traffic (profiles/r02_kb_ppx_v4_clock.log): the sustained clock, not 2.4 GHz, prices a kernel.
+struct ClkProbe {
+  unsigned long long c0 = 0, r0 = 0;
+  __device__ __forceinline__ void begin() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (blockIdx.x == 0) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
+#endif
+  }
+  __device__ __forceinline__ void end(unsigned long long* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      unsigned long long c1, r1;
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+      dst[0] = c0; dst[1] = r0; dst[2] = c1; dst[3] = r1;
+    }
+#endif
+  }
+};
+int read_clk_probe_gemm(unsigned long long* h);   // gemm_bf16.hip
+int read_clk_probe_attn(unsigned long long* h);   // attention.hip
+
 }  // namespace rf

@@ -1002,10 +1002,222 @@ __device__ __forceinline__ void gemm_mainloop_pp2(const GemmGroupDev& G, const i
   if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
 }
 
+// Evenly loaded ping-pong schedule (experiment VAR 6): 6 fragment reads and 2 DMA pieces in EVERY phase.  On top of
+// gemm_mainloop_pp2's early A0 read, the k-step-0 pair of each B half is read one phase early into two spare fragment
+// pairs (e0 for B0, e1 for B1); the other six fragments of a half share one register set m.  18 fragments live (+2).
+//   reads   p0: B0 ks1..3 (6)      p1: A1 (4) + B1 ks0 (2)      p2: B1 ks1..3 (6)      p3: next A0 (4) + next B0 ks0 (2)
+//   DMA     p0: B1(t+1)            p1: A0(t+2)                  p2: B0(t+2)            p3: A1(t+2)
+// (each region is overwritten >= 2 phases after its last reader phase and >= 5 phases before its first; vmcnt(8) behind
+// the issue of p0 / p2 retires what p1 / p3 of the same tile read, one barrier ahead)
+template <bool W8>
+__device__ __forceinline__ void mma_split(f32x16& c0, f32x16& c1, const bf16x8 (&a)[4], const bf16x8 (&e)[2], const bf16x8 (&m)[6]) {
+  if constexpr (!W8) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e[0], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e[1], c1, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], m[ks - 1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], m[ks + 2], c1, 0, 0, 0);
+    }
+  } else {
+    const i32x8 a01 = cat_frag(a[0], a[1]), a23 = cat_frag(a[2], a[3]);
+    c0 = RF_MFMA_FP8(a01, cat_frag(e[0], m[0]), c0);
+    c1 = RF_MFMA_FP8(a01, cat_frag(e[1], m[3]), c1);
+    c0 = RF_MFMA_FP8(a23, cat_frag(m[1], m[2]), c0);
+    c1 = RF_MFMA_FP8(a23, cat_frag(m[4], m[5]), c1);
+    asm volatile("" : "+v"(c0), "+v"(c1));   // see mma_quadrant
+  }
+}
+
+template <bool W8>
+__device__ __forceinline__ void gemm_mainloop_pp3(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                                  const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
+  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
+  constexpr int HT = 128 * 128;  // half-tile bytes
+  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
+  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M;
+
+  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
+  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
+  const int r8 = lane >> 3;
+  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
+  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
+  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
+  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
+  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
+  auto load_seg = [&](Cur& c) {
+    const KSegDev& S = G.seg[c.seg];
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
+    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+    // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
+        const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
+        c.offA[sb][i] = (uint32_t)(gm < M ? gm : M - 1) * lda2 + chunk_b;
+        c.offB[sb][i] = (uint32_t)(gn < N ? gn : N - 1) * ldw2 + chunk_b;
+      }
+  };
+  auto next = [&](Cur& c) {
+    ++c.kk;
+    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+      c.kk = 0;
+      ++c.seg;
+      load_seg(c);
+    }
+  };
+  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](const int kind, const Cur& c, const int buf) {
+    char* dst = smem + buf * BUF + kind * HT + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
+      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a buffer
+  const int swz = (l31 >> 1) & 7;
+  const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
+  const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
+  // logical 16-byte chunk of fragment ks: bf16 k-step ks = chunks 2ks + h; fp8 k-step ks/2 = chunks 4(ks/2) + 2h + (ks&1)
+  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
+
+  Cur c1;
+  c1.seg = 0; c1.kk = kt_begin;
+  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
+    c1.kk -= G.seg[c1.seg].nk;
+    ++c1.seg;
+  }
+  load_seg(c1);
+  // prologue, in steady-state issue order: A0(0) B0(0) A1(0) B1(0) | A0(1) B0(1) A1(1)      (B1(1) goes out in p0 of tile 0)
+  Cur c2 = c1;
+  stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
+  if (nk > 1) {
+    next(c2);                                        // c2 = tile 1
+    stage(0, c2, 1); stage(2, c2, 1); stage(1, c2, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) have landed
+    c1 = c2;                                         // c1 -> tile 1
+    next(c2);                                        // c2 -> tile 2
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 X[4], Y[4], e0[2], e1[2], m[6];
+  {
+    const int c0 = frag_coff(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) X[ks] = *(const bf16x8*)(smem + a_off + frag_coff(ks));   // A0 of tile 0
+    e0[0] = *(const bf16x8*)(smem + b_off + c0);
+    e0[1] = *(const bf16x8*)(smem + b_off + 32 * 128 + c0);
+  }
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+#define RF_PP3_BAR()                    \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_barrier();         \
+  __builtin_amdgcn_sched_barrier(0)
+  auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
+    const char* base = smem + (t & 1) * BUF;
+    const char* nbase = smem + ((t + 1) & 1) * BUF;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- p0: B0 ks 1..3; DMA B1(t+1) ---------------------------------------------------------
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      const int coff = frag_coff(ks);
+      m[ks - 1] = *(const bf16x8*)(base + b_off + coff);
+      m[ks + 2] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1) {
+      stage(3, c1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP3_BAR();
+    mma_split<W8>(acc[0][0], acc[0][1], P, e0, m);
+    RF_PP3_BAR();
+    // ---- p1: A1, B1 ks 0; DMA A0(t+2) --------------------------------------------------------
+    {
+      const int c0 = frag_coff(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
+      e1[0] = *(const bf16x8*)(base + HT + b_off + c0);
+      e1[1] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + c0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) stage(0, c2, t & 1);
+    RF_PP3_BAR();
+    mma_split<W8>(acc[1][0], acc[1][1], Q, e0, m);
+    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+    RF_PP3_BAR();
+    // ---- p2: B1 ks 1..3; DMA B0(t+2) ---------------------------------------------------------
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) {
+      const int coff = frag_coff(ks);
+      m[ks - 1] = *(const bf16x8*)(base + HT + b_off + coff);
+      m[ks + 2] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stage(2, c2, t & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP3_BAR();
+    mma_split<W8>(acc[1][2], acc[1][3], Q, e1, m);
+    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
+    RF_PP3_BAR();
+    // ---- p3: next tile's A0 and B0 ks 0; DMA A1(t+2) -----------------------------------------
+    if (more1) {
+      const int c0 = frag_coff(0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(nbase + a_off + frag_coff(ks));
+      e0[0] = *(const bf16x8*)(nbase + b_off + c0);
+      e0[1] = *(const bf16x8*)(nbase + b_off + 32 * 128 + c0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) stage(1, c2, t & 1);
+    RF_PP3_BAR();
+    mma_split<W8>(acc[0][2], acc[0][3], P, e1, m);
+    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+    RF_PP3_BAR();
+    next(c1);
+    next(c2);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    tile(t, X, Y);
+    if (t + 1 < nk) tile(t + 1, Y, X);
+  }
+#undef RF_PP3_BAR
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
+}
+
+__device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
+
 // one 256x256 tile per block, ping-pong main loop, LDS-staged epilogue (vec_ok launches only)
 template <bool W8>
 __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1025,15 +1237,18 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
     // (the LoRA'd condition rows of cfg5) in one grid, so the small group fills the tail instead of its own launch
     if (G.w8) {
       gemm_mainloop_pp2<true>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+      clk.end(g_clk_probe);
       __syncthreads();
       gemm_epilogue_lds<2, true>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
     } else {
       gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+      clk.end(g_clk_probe);
       __syncthreads();
       gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
     }
   } else {
     gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+    clk.end(g_clk_probe);
     __syncthreads();  // every wave is done reading the staged operands: the LDS is free
     gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
   }
@@ -1042,10 +1257,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) {
 __global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
 
 // experiment harness for the ping-pong main loop (one tile per block, bf16 only): rf_debug_force_gemm_tile(259)
+// clock probe: block 0 stores {s_memtime, s_memrealtime} (shader clocks, 100 MHz reference) around its tile, so
+// rf_debug_gemm_clock_mhz() can report the shader clock the kernel actually ran at
 template <int VAR>
 __global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
+  ClkProbe clk;
+  clk.begin();
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = xcd_remap(blockIdx.x, p.total_tiles);
@@ -1060,7 +1279,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) 
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x16 acc[2][4];
   if constexpr (VAR == 5) gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  else if constexpr (VAR == 6) gemm_mainloop_pp3<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
   else gemm_mainloop_pp<false, VAR>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  clk.end(g_clk_probe);
   __syncthreads();
   gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
 }
@@ -1467,6 +1688,7 @@ static int launch_gemm_ppx(GemmParams& p, hipStream_t stream) {
     case 3: return launch_gemm_ppx_v<3>(p, stream);
     case 4: return launch_gemm_ppx_v<4>(p, stream);
     case 5: return launch_gemm_ppx_v<5>(p, stream);
+    case 6: return launch_gemm_ppx_v<6>(p, stream);
     default: return launch_gemm_ppx_v<0>(p, stream);
   }
 }
@@ -1520,10 +1742,11 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
 constexpr int64_t WS_FLAG_BYTES = 4096;
 static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K (test introspection)
 static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = stream-K whenever feasible (tests), 2 = persistent whole tiles only
-static int g_persistent_rounds = 1;  // heuristic: bf16 launches with >= this many tile rounds that do not qualify for stream-K run as
-                                     // ONE persistent launch of whole tiles (+1..4 % on every cfg2 / cfg5 shape: a tile's output
-                                     // stores drain under the next tile's main loop, no block dispatch between rounds;
-                                     // profiles/r02_kb_persist.log); 0 = off.  fp8 / mixed launches keep one tile per block.
+static int g_persistent_rounds = 0;  // > 0: bf16 launches with >= this many tile rounds that do not qualify for stream-K run as ONE
+                                     // persistent launch of whole tiles.  Worth +1..4 % with the round-1 main loop (a tile's stores
+                                     // drain under the next tile's loop; profiles/r02_kb_persist.log); with the balanced loop it is
+                                     // neutral at cfg2 and -1..3 % at cfg5 sizes (profiles/r02_kb_persist_pp2.log), so it is OFF.
+                                     // rf_debug_gemm_persistent_rounds() / rf_debug_force_gemm_sk(2) still exercise it.
 
 // The stream-K launch relies on two properties HIP does not promise: lower-indexed blocks are dispatched first and
 // block b runs on XCD b % 8 (observed on MI355X in SPX mode; a wrong guess about the XCD costs speed only, but a
@@ -1879,6 +2102,22 @@ extern "C" int rf_debug_sk_plan(const rf_gemm_desc* d, int32_t num_cus, int32_t*
 
 extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }
 
+namespace rf {
+int read_clk_probe_gemm(unsigned long long* h) {
+  return hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), 4 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
+}
+}  // namespace rf
+// which: 0 = the last completed 256x256 ping-pong GEMM launch (one tile per block), 1 = the last bounded-score attention
+// launch.  mhz = shader clocks per microsecond over block 0's main loop, us = that loop's duration.  The caller
+// synchronises the stream first.
+extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
+  unsigned long long h[4];
+  const int rc = which == 0 ? rf::read_clk_probe_gemm(h) : rf::read_clk_probe_attn(h);
+  if (rc != RF_OK) return rc;
+  *us = (double)(h[3] - h[1]) / 100.0;
+  *mhz = *us > 0 ? (double)(h[2] - h[0]) / *us : 0.0;
+  return RF_OK;
+}
 extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
 extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds
   rf::g_persistent_rounds = rounds < 0 ? 0 : rounds;

@@ -1,6 +1,6 @@
 """Ping-pong main loop experiments (rf_debug_force_gemm_tile(259), variant via rf_debug_gemm_w4_knock):
 0 production order, 1 reads before DMA, 2 no DMA (timing only), 3 no reads (timing only), 4 neither (timing only)."""
-import os, sys, torch
+import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reflectionflow_amd import _lib, ops
 lib = _lib.load()
@@ -29,6 +29,10 @@ for (M, N, K) in ((4608, 3072, 12288), (4608, 9216, 3072)):
         for k, name in NAMES.items():
             lib.rf_debug_gemm_w4_knock(k)
             t = ops.time_gemm(g, N, iters=20, splitk_ws=False)
-            print(f"{M}x{N}x{K} {name:16s} {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF", flush=True)
+            torch.cuda.synchronize()
+            mhz, us = C.c_double(0), C.c_double(0)
+            lib.rf_debug_clock_probe(0, C.byref(mhz), C.byref(us))
+            print(f"{M}x{N}x{K} {name:16s} {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF   shader clock {mhz.value:6.0f} MHz over block 0's main loop ({us.value:.1f} us)"
+                  f"  -> {2*M*N*K/t/1e12 / (2516.6 * mhz.value / 2400.0) * 100:5.1f} % of the MFMA rate at that clock", flush=True)
     lib.rf_debug_gemm_w4_knock(0)
     lib.rf_debug_force_gemm_tile(0)
