@@ -20,6 +20,7 @@
 //     W = scaling*lora_B) without materialising a concat or a merged weight;
 //   * blockIdx is remapped so that every XCD works on a contiguous chunk of tiles (private L2).
 #include "common.hpp"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace rf {
@@ -59,6 +60,7 @@ struct GemmParams {
   GemmGroupDev g[4];
 };
 
+__device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
 
@@ -170,11 +172,69 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGro
 constexpr int EPI_ROW = 528;                 // padded fp32 row: 128 cols * 4 B + 16 B
 constexpr int EPI_REGION = 32 * EPI_ROW;     // one wave's staging region
 
-template <int FM, bool W8 = false>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const GemmGroupDev& G, f32x16 (&acc)[FM][4],
-                                                  const int m0, const int n0, const int wrow0, const int wcol0,
-                                                  const int lane, char* region) {
-  const int l31 = lane & 31, h = lane >> 5;
+// Accumulator views: the epilogue touches a wave's accumulators in two ways only -- 4-token runs of one column (V^T,
+// straight from registers) and "stage the 32-row block i into the wave's LDS region" -- so the two MFMA shapes differ
+// only here.  32x32x16: acc[i][j] covers rows i*32.., cols j*32..; col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// 16x16x32: acc[it][jt] covers rows it*16.., cols jt*16..; col = lane&15, row = 4*(lane>>4) + r.
+template <int FM>
+struct Acc32 {
+  f32x16 (&a)[FM][4];
+  // f(row in the wave tile of the run's first token, column in the 128-column strip, float (&v)[4])
+  template <class F>
+  __device__ __forceinline__ void for_each_run4(const int lane, F f) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float v[4] = {a[i][j][rg * 4 + 0], a[i][j][rg * 4 + 1], a[i][j][rg * 4 + 2], a[i][j][rg * 4 + 3]};
+          f(i * 32 + 4 * h + 8 * rg, j * 32 + l31, v);
+        }
+  }
+  __device__ __forceinline__ void stage(const int i, char* region, const int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        *(float*)(region + row * EPI_ROW + (j * 32 + l31) * 4) = a[i][j][r];
+      }
+  }
+};
+template <int FM>
+struct Acc16 {
+  f32x4 (&a)[2 * FM][8];
+  template <class F>
+  __device__ __forceinline__ void for_each_run4(const int lane, F f) {
+    const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+      for (int it = 0; it < 2 * FM; ++it) {
+        float v[4] = {a[it][jt][0], a[it][jt][1], a[it][jt][2], a[it][jt][3]};
+        f(it * 16 + 4 * g, jt * 16 + l15, v);
+      }
+  }
+  __device__ __forceinline__ void stage(const int i, char* region, const int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    // padded row = 132 dwords: lanes (g, l15) of one register hit banks 16g + l15 + const -- conflict-free
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *(float*)(region + (t * 16 + 4 * g + r) * EPI_ROW + (jt * 16 + l15) * 4) = a[2 * i + t][jt][r];
+  }
+};
+
+template <int FM, bool W8, class ACC>
+__device__ __forceinline__ void gemm_epilogue_lds_v(const GemmParams& p, const GemmGroupDev& G, ACC acc,
+                                                    const int m0, const int n0, const int wrow0, const int wcol0,
+                                                    const int lane, char* region) {
   const int M = G.M, N = p.N;
   int epi = p.epi;
   int ncol_base = 0;
@@ -197,46 +257,35 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
   }
 
   if (epi == RF_EPI_QKV && which == 2) {
-    // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped; lane = one d, 4-key runs
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = ncol0 + j * 32 + l31;
+    // V^T tiles: [head][tok/64][d][64], key position has bits 2,3 swapped; a lane holds 4-key runs of one d
+    acc.for_each_run4(lane, [&](const int row, const int col, float (&v)[4]) {
+      const int n = ncol0 + col;
       const float bias_v = G.bias != nullptr ? bf2f(G.bias[n]) : 0.f;
-      bf16_t* dst = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64) + (j * 32 + l31) * 64;
+      bf16_t* dst = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64) + col * 64;
+      const int m = m0 + wrow0 + row;
+      if constexpr (W8) {  // dequantise: acc * s_act[row] * s_w[col]
+        const float swn = G.w_scale[n];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int mrow0 = m0 + wrow0 + i * 32 + 4 * h;
-        if constexpr (W8) {  // dequantise in place: acc * s_act[row] * s_w[col]
-          const float swn = G.w_scale[n];
+        for (int e = 0; e < 4; ++e) v[e] *= swn * (m + e < M ? G.a_scale[m + e] : 0.f);
+      }
+      const int tok = G.tok_offset + m;
+      if (((tok & 3) == 0) && (m + 3 < M)) {
+        const int pos = (tok & 51) | ((tok & 4) << 1) | ((tok & 8) >> 1);
+        u32x2 o;
+        o[0] = pack2(v[0] + bias_v, v[1] + bias_v);
+        o[1] = pack2(v[2] + bias_v, v[3] + bias_v);
+        *(u32x2*)(dst + (int64_t)(tok >> 6) * (128 * 64) + pos) = o;
+      } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mrow0 + (r & 3) + 8 * (r >> 2);
-            acc[i][j][r] *= swn * (m < M ? G.a_scale[m] : 0.f);
-          }
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int m = mrow0 + 8 * rg;
-          const int tok = G.tok_offset + m;
-          if (((tok & 3) == 0) && (m + 3 < M)) {
-            const int pos = (tok & 51) | ((tok & 4) << 1) | ((tok & 8) >> 1);
-            u32x2 v;
-            v[0] = pack2(acc[i][j][rg * 4 + 0] + bias_v, acc[i][j][rg * 4 + 1] + bias_v);
-            v[1] = pack2(acc[i][j][rg * 4 + 2] + bias_v, acc[i][j][rg * 4 + 3] + bias_v);
-            *(u32x2*)(dst + (int64_t)(tok >> 6) * (128 * 64) + pos) = v;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int t2 = tok + e;
-              if (m + e < M) {
-                const int pos = (t2 & 51) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
-                dst[(int64_t)(t2 >> 6) * (128 * 64) + pos] = f2bf(acc[i][j][rg * 4 + e] + bias_v);
-              }
-            }
+        for (int e = 0; e < 4; ++e) {
+          const int t2 = tok + e;
+          if (m + e < M) {
+            const int pos = (t2 & 51) | ((t2 & 4) << 1) | ((t2 & 8) >> 1);
+            dst[(int64_t)(t2 >> 6) * (128 * 64) + pos] = f2bf(v[e] + bias_v);
           }
         }
       }
-    }
+    });
     return;
   }
 
@@ -267,15 +316,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
 
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    // registers -> LDS (row-major fp32 with swizzled chunks)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int col = j * 32 + l31;
-        *(float*)(region + row * EPI_ROW + col * 4) = acc[i][j][r];
-      }
+    // registers -> LDS (row-major fp32, padded rows)
+    acc.stage(i, region, lane);
     const int mbase = m0 + wrow0 + i * 32;
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {  // two batches of 4 row groups: bounds the prefetch registers
@@ -355,6 +397,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
       }
     }
   }
+}
+
+template <int FM, bool W8 = false>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const GemmGroupDev& G, f32x16 (&acc)[FM][4],
+                                                  const int m0, const int n0, const int wrow0, const int wcol0,
+                                                  const int lane, char* region) {
+  gemm_epilogue_lds_v<FM, W8>(p, G, Acc32<FM>{acc}, m0, n0, wrow0, wcol0, lane, region);
+}
+template <int FM>
+__device__ __forceinline__ void gemm_epilogue_lds16(const GemmParams& p, const GemmGroupDev& G, f32x4 (&acc)[2 * FM][8],
+                                                    const int m0, const int n0, const int wrow0, const int wcol0,
+                                                    const int lane, char* region) {
+  gemm_epilogue_lds_v<FM, false>(p, G, Acc16<FM>{acc}, m0, n0, wrow0, wcol0, lane, region);
 }
 
 // ---- main loop ----------------------------------------------------------------------------------------
@@ -1002,6 +1057,189 @@ __device__ __forceinline__ void gemm_mainloop_pp2(const GemmGroupDev& G, const i
   if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
 }
 
+// The same balanced schedule on v_mfma_f32_16x16x32_bf16.  Under the 1.4 kW cap the matrix pipes sustain 1.82 PFLOP/s with
+// 32x32x16 MFMAs on random bf16 operands and 2.06 PFLOP/s with 16x16x32 (tools/ubench/mfma_power.py, no memory traffic at
+// all: the chip settles at 1.89 vs 2.13 GHz) -- the small shape reads and writes half the accumulator bytes per MAC.  Fragment
+// counts per phase, LDS image, staging and barriers are unchanged (a 32-row A half = 2 row tiles x 2 k-steps = 4 fragments,
+// a 64-column W half = 4 x 2 = 8); only the lane -> (row, chunk) map of a fragment read and the accumulator layout differ.
+__device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                                  const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
+  constexpr int ESZ = 2;  // bytes per element
+  constexpr int HT = 128 * 128;  // half-tile bytes
+  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
+  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M;
+
+  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
+  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
+  const int r8 = lane >> 3;
+  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
+  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
+  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
+  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
+  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
+  auto load_seg = [&](Cur& c) {
+    const KSegDev& S = G.seg[c.seg];
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
+    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+    // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
+        const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
+        c.offA[sb][i] = (uint32_t)(gm < M ? gm : M - 1) * lda2 + chunk_b;
+        c.offB[sb][i] = (uint32_t)(gn < N ? gn : N - 1) * ldw2 + chunk_b;
+      }
+  };
+  auto next = [&](Cur& c) {
+    ++c.kk;
+    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+      c.kk = 0;
+      ++c.seg;
+      load_seg(c);
+    }
+  };
+  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](const int kind, const Cur& c, const int buf) {
+    char* dst = smem + buf * BUF + kind * HT + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
+      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a buffer (16x16x32 fragments: lane -> row lane&15, 16-byte chunk 4*ks + lane>>4)
+  const int l15 = lane & 15;
+  const int swz = (l15 >> 1) & 7;
+  const int a_off = (wm * 32 + l15) * 128;                 // + sb*HT + rt*16*128
+  const int b_off = 2 * HT + (wn * 64 + l15) * 128;        // + sb*HT + ct*16*128
+  auto frag_coff = [&](int ks) { return ((ks * 4 + (lane >> 4)) ^ swz) << 4; };
+  // A half: fragments [rt*2 + ks] (2 row tiles x 2 k-steps); W half: [ct*2 + ks] (4 column tiles x 2 k-steps)
+  auto rdA = [&](bf16x8 (&dst)[4], const char* half) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) dst[rt * 2 + ks] = *(const bf16x8*)(half + a_off + rt * 2048 + frag_coff(ks));
+  };
+  auto rdB = [&](bf16x8 (&dst)[8], const char* half) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)      // k-step 0 of all four column tiles first: the phase's first MFMAs need those
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) dst[ct * 2 + ks] = *(const bf16x8*)(half + b_off + ct * 2048 + frag_coff(ks));
+  };
+  // one phase: the 32 x 64 quadrant (row tiles rb, rb+1) x (column tiles cb .. cb+3) over the whole K-tile, 16 MFMAs;
+  // the two updates of an accumulator are 8 MFMAs apart
+  auto mma16 = [&](const int rb, const int cb, const bf16x8 (&A)[4], const bf16x8 (&B)[8]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rb + rt][cb + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt * 2 + ks], B[ct * 2 + ks], acc[rb + rt][cb + ct], 0, 0, 0);
+  };
+
+  Cur c1;
+  c1.seg = 0; c1.kk = kt_begin;
+  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
+    c1.kk -= G.seg[c1.seg].nk;
+    ++c1.seg;
+  }
+  load_seg(c1);
+  // prologue, in steady-state issue order: A0(0) | B0(0) A1(0) | A0(1) B1(0) | B0(1) A1(1)
+  Cur c2 = c1;
+  if (nk > 1) {
+    next(c2);                                        // c1 = tile 0, c2 = tile 1
+    stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0);
+    stage(0, c2, 1); stage(3, c1, 0);
+    stage(2, c2, 1); stage(1, c2, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 but B1 has landed
+    c1 = c2;                                         // c1 -> tile 1
+    next(c2);                                        // c2 -> tile 2
+  } else {
+    stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 X[4], Y[4], bq[8];
+  rdA(X, smem);   // A0 of tile 0
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+#define RF_PP2_BAR()                    \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_barrier();         \
+  __builtin_amdgcn_sched_barrier(0)
+  // one K-tile: P holds its A0 fragments (read during the previous tile's phase 3), Q receives A1, then the next A0
+  auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
+    const char* base = smem + (t & 1) * BUF;
+    const char* nbase = smem + ((t + 1) & 1) * BUF;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- p0: 8 reads ---------------------------------------------------------------------
+    rdB(bq, base);
+    RF_PP2_BAR();
+    mma16(0, 0, P, bq);
+    RF_PP2_BAR();
+    // ---- p1: 4 reads, 4 pieces -----------------------------------------------------------
+    rdA(Q, base + HT);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stage(0, c2, t & 1); stage(3, c1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (more1) {
+      stage(3, c1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP2_BAR();
+    mma16(2, 0, Q, bq);
+    RF_PP2_BAR();
+    // ---- p2: 8 reads ---------------------------------------------------------------------
+    rdB(bq, base + HT);
+    RF_PP2_BAR();
+    mma16(2, 4, Q, bq);
+    // the next tile's A0 goes into Q: keep its reads behind these MFMAs' operand fetch
+    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
+    RF_PP2_BAR();
+    // ---- p3: 4 reads (next tile's A0), 4 pieces ------------------------------------------
+    if (more1) rdA(Q, nbase);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stage(2, c2, t & 1); stage(1, c2, t & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP2_BAR();
+    mma16(0, 4, P, bq);
+    RF_PP2_BAR();
+    next(c1);
+    next(c2);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    tile(t, X, Y);
+    if (t + 1 < nk) tile(t + 1, Y, X);
+  }
+#undef RF_PP2_BAR
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
+}
+
+
 // Evenly loaded ping-pong schedule (experiment VAR 6): 6 fragment reads and 2 DMA pieces in EVERY phase.  On top of
 // gemm_mainloop_pp2's early A0 read, the k-step-0 pair of each B half is read one phase early into two spare fragment
 // pairs (e0 for B0, e1 for B1); the other six fragments of a half share one register set m.  18 fragments live (+2).
@@ -1210,8 +1448,6 @@ __device__ __forceinline__ void gemm_mainloop_pp3(const GemmGroupDev& G, const i
   if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
 }
 
-__device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
-
 // one 256x256 tile per block, ping-pong main loop, LDS-staged epilogue (vec_ok launches only)
 template <bool W8>
 __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
@@ -1254,6 +1490,30 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
   }
 }
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) { gemm_pp_body<false>(p); }
+// bf16 launches on 16x16x32 MFMAs (gemm_mainloop_pp2_m16)
+__global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  int tm, tn;
+  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  f32x4 acc[4][8];
+  gemm_mainloop_pp2_m16(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  clk.end(g_clk_probe);
+  __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+  gemm_epilogue_lds16<2>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+}
 __global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
 
 // experiment harness for the ping-pong main loop (one tile per block, bf16 only): rf_debug_force_gemm_tile(259)
@@ -1286,64 +1546,80 @@ __global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) 
   gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
 }
 
-// ---- one wave per SIMD (experimental, rf_debug_force_gemm_tile(258)) -------------------------------------------
+// ---- one wave per SIMD (rf_debug_force_gemm_tile(258)) -----------------------------------------------------------
 // 256x256x64 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 4 x 4 MFMA fragments: 256 accumulator registers per lane,
 // which only fit because a 256-thread block leaves each SIMD to ONE wave (512 unified VGPR/AGPR).  Per K-tile a wave
-// multiplies 64 MFMAs from 32 fragment reads (0.5 per MFMA vs 0.75 in the 8-wave kernels) and there is no second wave
-// to arbitrate the matrix pipe with, so the schedule is the bounded-score attention kernel's: per k-step (16 MFMAs) four
-// groups of four, each fenced by sched_barrier(0), each first issuing two of the NEXT k-step's eight fragment reads
-// into the other half of a double buffer plus one or two of the next K-tile's sixteen LDS-DMA pieces.  One barrier per
-// K-tile, in front of the last k-step's MFMAs (whose fragments are already in registers), so the first reads of the
-// next tile fly under 16 MFMAs.  Two 64 KiB LDS stages; the epilogue needs only 4 x 16.5 KiB.
-#ifndef RF_W4_NSLOT
-#define RF_W4_NSLOT 8
-#endif
+// multiplies 64 MFMAs from 32 fragment reads (0.5 per MFMA against 0.75 in the 8-wave kernels: a third less LDS energy
+// on a power-limited part) -- but a single wave per SIMD hides nothing, so every stall source had to go
+// (tools/kb_w4_knock.py, profiles/r02_kb_w4_knock_*.log; shader clocks per K-tile, 64 MFMAs = 2048 + issue = 2105):
+//   * fragment reads: per k-step (16 MFMAs) four groups of four MFMAs fenced by sched_barrier(0); each group first
+//     issues two of the NEXT k-step's eight reads into the other half of a register double buffer        -> 2250
+//   * LDS-DMA issue: a burst of pieces stalls the issuing wave ~55 cycles per piece and four waves issuing in lock step
+//     queue behind each other; ONE piece per group per wave, wave w behind the group's MFMA w, costs ~14.  A taken
+//     scalar branch around the piece costs a single-wave SIMD an instruction-fetch bubble, so the loop is specialised
+//     per wave (template WV) and the piece is straight-line code                                            -> 2480
+//   * landing: with two 64 KiB stages the pieces issued late in a tile have no time to land before the barrier that
+//     publishes them (3350 with the wait).  The 160 KiB LDS is therefore a RING of ten 16 KiB sub-blocks -- A rows
+//     0..127, A rows 128..255, W rows 0..127, W rows 128..255 of a K-tile, four per tile, ring position (4u + kind) % 10 --
+//     so 2.5 tiles are resident and every piece is issued >= 32 MFMA slots (~1050 cycles) before its barrier:
+//        k-step 3 of tile t-1 and k-step 0 of tile t : W(t+1), into the positions A(t-1) left at barrier(t-1)
+//        k-steps 1, 2 of tile t                      : A(t+2), into the positions W(t-1) left
+//     barrier(t) sits in front of k-step 3 (whose fragments are in registers): it publishes tile t+1 (s_waitcnt vmcnt(8):
+//     only A(t+2) may be in flight) and retires tile t, and tile t+1's first fragments are read under k-step 3's MFMAs.
 // KNOCK (timing diagnostics only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no fragment reads in the loop,
-// 4 = no per-tile wait + barrier.
-template <bool W8, int KNOCK = 0>
+// 4 = no per-tile wait + barrier, 8 = DMA from a hot (two K-tile) source.
+template <bool W8, int KNOCK, int WV>
 __device__ __forceinline__ void gemm_mainloop_w4(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
-                                                 const int nk, f32x16 (&acc)[4][4], char* smem, const int w, const int lane) {
+                                                 const int nk, f32x16 (&acc)[4][4], char* smem, const int lane) {
   constexpr int ESZ = W8 ? 1 : 2;
-  constexpr int STAGE = 65536, A_BYTES = 32768;
-  const int wm = w >> 1, wn = w & 1;
+  constexpr int SUB = 16384;                 // one sub-block: 128 rows x 128 B
+  constexpr int w = WV, wm = WV >> 1, wn = WV & 1;
   const int l31 = lane & 31, h = lane >> 5;
   const int M = G.M;
-  // DMA piece p = i*4 + w (i = 0..15) fills stage rows p*8 + lane/8: pieces 0..31 are A rows, 32..63 W rows
   const int r8 = lane >> 3;
-  uint32_t rowsrc[16];   // clamped global row of piece i (A for i < 8, W for i >= 8)
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int p = i * 4 + w;
-    if (i < 8) {
-      const int gm = m0 + p * 8 + r8;
-      rowsrc[i] = (uint32_t)(gm < M ? gm : M - 1);
-    } else {
-      const int gn = n0 + (p - 32) * 8 + r8;
-      rowsrc[i] = (uint32_t)(gn < N ? gn : N - 1);
-    }
-  }
-  // swizzled 16-byte chunk this lane fetches: stage row = p*8 + r8, (row >> 1) & 7 = ((w*8 + r8) >> 1) & 7 since p*8 = i*32 + w*8
+  // piece j (0..3) of a sub-block, as loaded by this wave: rows (4j + w)*8 + lane/8, 1 KiB at sub-block offset (4j + w) KiB;
+  // swizzled 16-byte chunk: (row >> 1) & 7 = ((w*8 + r8) >> 1) & 7 since 32j rows do not reach those bits
   const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w * 8 + r8) >> 1) & 7)) * 16);
-  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t off[16]; };
-  auto load_seg = [&](Cur& c) {
+  // cursor over K-tiles for one operand: segment, tile in segment, resource, the wave's 8 per-lane byte offsets
+  // (pieces 0..3 of the low sub-block, 4..7 of the high one)
+  struct Cur { int seg, kk, nk; rsrc_t R; uint32_t off[8]; };   // nk: K-tiles until the next segment starts (INT_MAX in the last)
+  auto load_seg = [&](Cur& c, const bool isA) {
     const KSegDev& S = G.seg[c.seg];
-    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
-    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+    c.nk = (c.seg < 2 && G.seg[c.seg + 1].nk > 0) ? S.nk : 0x7fffffff;
+    c.R = isA ? RF_MAKE_RSRC(S.A) : RF_MAKE_RSRC(S.W);
+    const uint32_t pitch = (uint32_t)((isA ? S.lda : S.ldw) * ESZ);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c.off[i] = rowsrc[i] * (i < 8 ? lda2 : ldw2) + chunk_b;
+    for (int i = 0; i < 8; ++i) {
+      const int row = (i >> 2) * 128 + ((i & 3) * 4 + w) * 8 + r8;
+      const int g = isA ? m0 + row : n0 + row;
+      const int lim = isA ? M : N;
+      c.off[i] = (uint32_t)(g < lim ? g : lim - 1) * pitch + chunk_b;
+    }
   };
-  auto next = [&](Cur& c) {
+  auto seek = [&](Cur& c, const bool isA) {
+    c.seg = 0; c.kk = kt_begin;
+    while (c.seg < 2 && c.kk >= G.seg[c.seg].nk && G.seg[c.seg + 1].nk > 0) {
+      c.kk -= G.seg[c.seg].nk;
+      ++c.seg;
+    }
+    load_seg(c, isA);
+  };
+  auto next = [&](Cur& c, const bool isA) {
     ++c.kk;
-    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+    // (a TAKEN branch costs this kernel's lone wave per SIMD a fetch bubble: the rare paths are laid out of line)
+    if (__builtin_expect(c.kk >= c.nk, 0)) {
       c.kk = 0;
       ++c.seg;
-      load_seg(c);
+      load_seg(c, isA);
     }
   };
-  auto dma_piece = [&](const int i, const Cur& c, const int buf) {
-    char* dst = smem + buf * STAGE + (i * 4 + w) * 1024;
-    if (i < 8) RF_BUF_LOAD_LDS(c.A, (lds_void*)dst, c.off[i], c.kk * 128);
-    else RF_BUF_LOAD_LDS(c.W, (lds_void*)dst, c.off[i], c.kk * 128);
+  // piece i (0..7) of the operand under cursor c into ring positions pos (low sub-block) / pos + 1 (high), pos in 0..9
+  auto mod10 = [](const int x) { return x >= 10 ? x - 10 : x; };
+  auto dma_piece = [&](const int i, const Cur& c, const int pos_lo) {
+    const int pos = mod10(pos_lo + (i >> 2));
+    char* dst = smem + pos * SUB + ((i & 3) * 4 + w) * 1024;
+    const int koff = (KNOCK & 64) ? 0 : (KNOCK & 8) ? (c.kk & 1) * 128 : c.kk * 128;
+    RF_BUF_LOAD_LDS(c.R, (lds_void*)dst, c.off[(KNOCK & 64) ? 0 : i], koff);   // 64: one 1 KiB piece over and over (TCP hits)
   };
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1353,108 +1629,102 @@ __device__ __forceinline__ void gemm_mainloop_w4(const GemmGroupDev& G, const in
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int swz = (l31 >> 1) & 7;
-  const char* a_rd = smem + (wm * 128 + l31) * 128;               // + i*4096 + coff(ks) + buf*STAGE
-  const char* b_rd = smem + A_BYTES + (wn * 128 + l31) * 128;     // + j*4096 + coff(ks) + buf*STAGE
   auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
+  const char* lane_rd = smem + l31 * 128;     // + ring position * SUB + row block * 4096 + frag_coff(ks)
 
-  Cur c1;
-  c1.seg = 0; c1.kk = kt_begin;
-  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
-    c1.kk -= G.seg[c1.seg].nk;
-    ++c1.seg;
-  }
-  load_seg(c1);
-  // DMA schedule.  A buffer_load..lds occupies the CU's one LDS-DMA path for ~16 cycles and the ISSUING wave waits for
-  // it: four waves issuing in lock step (which the per-tile barrier makes them) each wait for all four
-  // (tools/kb_w4_knock.py: 1375 cycles per K-tile).  So the 16 groups of a tile are SLOTS and wave w issues only in
-  // slots s == w (mod 4), one or two pieces behind each of the slot's MFMAs.  Tile u's pieces go out in the NSLOT slots
-  // that start right after the barrier of tile u-2 (k-step 3 of tile u-2, then the first groups of tile u-1): the
-  // stage is free from that barrier on, and the data has the rest of tile u-1 to land before ITS barrier.
-  constexpr int NSLOT = RF_W4_NSLOT;           // 8 or 12
-  constexpr int PER = NSLOT / 4;               // slots a wave owns per tile: 2 (8 + 8 pieces) or 3 (6 + 5 + 5)
-  auto slot_first = [](int k) { return PER == 2 ? k * 8 : (k == 0 ? 0 : 1 + k * 5); };
-  auto slot_cnt = [](int k) { return PER == 2 ? 8 : (k == 0 ? 6 : 5); };
+  Cur cA, cB;
+  seek(cA, true);
+  seek(cB, false);
+  // prologue, in steady-state issue order: A(0) W(0) | A(1) | W(1) pieces 0..3      (ring positions 0 1 | 2 3 | 4 5 | 6 7)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) dma_piece(i, c1, 0);   // tile 0, whole
-  next(c1);                                            // c1 -> tile 1
+  for (int i = 0; i < 8; ++i) dma_piece(i, cA, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(i, cB, 2);
+  next(cA, true);
+  next(cB, false);                            // both -> tile 1
   if (nk > 1) {
 #pragma unroll
-    for (int i = 0; i < slot_cnt(0); ++i) dma_piece(i, c1, 1);   // tile 1, this wave's first slot
+    for (int i = 0; i < 8; ++i) dma_piece(i, cA, 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(i, cB, 6);
+    next(cA, true);                           // cA -> tile 2; cB stays on tile 1 (pieces 4..7 go out in k-step 0)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   bf16x8 fa[2][4], fb[2][4];   // fragment double buffer by k-step parity
-  // fragments of k-step ks of the tile in stage `buf`, read e of 8: e < 4 -> A row block e, else W column block e - 4
-  auto rd = [&](const int buf, const int ks, const int e, const int par) {
-    const int coff = frag_coff(ks) + buf * STAGE;
-    if (e < 4) fa[par][e] = *(const bf16x8*)(a_rd + e * 4096 + coff);
-    else fb[par][e - 4] = *(const bf16x8*)(b_rd + (e - 4) * 4096 + coff);
+  // read e of 8 of k-step ks of the tile whose A sub-blocks start at ring position pa: e < 4 -> A row block e of this
+  // wave's half, else W column block e - 4
+  auto rd = [&](const int pa, const int ks, const int e, const int par) {
+    const int coff = frag_coff(ks);
+    if (e < 4) fa[par][e] = *(const bf16x8*)(lane_rd + mod10(pa + wm) * SUB + e * 4096 + coff);
+    else fb[par][e - 4] = *(const bf16x8*)(lane_rd + mod10(pa + 2 + wn) * SUB + (e - 4) * 4096 + coff);
   };
 #pragma unroll
   for (int e = 0; e < 8; ++e) rd(0, 0, e, 0);
   __builtin_amdgcn_sched_barrier(0);
 
-  // four MFMAs of group g (row block g x the four column blocks); with DMA: pieces [first, first+cnt) of the tile under
-  // cursor c1 into stage dbuf, spread behind the MFMAs
-  auto mfma = [&](const int g, const int j, const int par) {
-    if constexpr (!W8) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[par][g], fb[par][j], acc[g][j], 0, 0, 0);
-  };
-  for (int t = 0; t < nk; ++t) {
-    const int buf = t & 1;
-    const bool more = t + 1 < nk;
+  int pa = 0;                                  // ring position of A(t), = (4t) % 10
+  // one K-tile; TAIL = false is the steady state (tiles t+1 and t+2 exist: no conditions, hence no branches, in it)
+  auto tile = [&](const int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const bool more1 = !TAIL || t + 1 < nk, more2 = !TAIL || t + 2 < nk;
+    const int pa1 = mod10(pa + 4);             // A(t+1)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int par = ks & 1;
       if (ks == 3 && !(KNOCK & 4)) {
-        // the last k-step's fragments are in registers: retire this wave's LDS traffic on the tile, let every wave's
-        // DMA of tile t+1 land, then read tile t+1's first fragments UNDER this k-step's 16 MFMAs
-        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0), as an instruction the waitcnt pass can see
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (KNOCK & 16) __builtin_amdgcn_s_waitcnt(0xc07f);   // (16: lgkmcnt(0) only)
+        else if (more2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): only A(t+2) may still be in flight
+        else __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
+        if (!(KNOCK & 32)) __builtin_amdgcn_s_barrier();      // (32: waits but no barrier)
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int q = ks * 4 + g;
         if (!(KNOCK & 2)) {
           if (ks < 3) {
-            rd(buf, ks + 1, 2 * g, par ^ 1);
-            rd(buf, ks + 1, 2 * g + 1, par ^ 1);
-          } else if (more) {
-            rd(buf ^ 1, 0, 2 * g, 0);
-            rd(buf ^ 1, 0, 2 * g + 1, 0);
+            rd(pa, ks + 1, 2 * g, par ^ 1);
+            rd(pa, ks + 1, 2 * g + 1, par ^ 1);
+          } else if (more1) {
+            rd(pa1, 0, 2 * g, 0);
+            rd(pa1, 0, 2 * g + 1, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // slot of this group: k-step 3 opens tile t+2's slots 0..3 (stage buf, free since the barrier above);
-        // groups 0..NSLOT-5 are tile t+1's slots 4..NSLOT-1 (stage buf ^ 1)
-        const int s = q >= 12 ? q - 12 : (q < NSLOT - 4 ? q + 4 : -1);
-        const bool exists = q >= 12 ? t + 2 < nk : more;
-        const bool own = s >= 0 && !(KNOCK & 1) && exists && (s & 3) == w;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          mfma(g, j, par);
-          if (s >= 0 && !(KNOCK & 1)) {       // only the DMA issue is conditional: no accumulator crosses a branch
+          if constexpr (!W8) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[par][g], fb[par][j], acc[g][j], 0, 0, 0);
+          if (j == WV && !(KNOCK & 1)) {       // this wave's DMA slot of the group
             __builtin_amdgcn_sched_barrier(0);
-            if (own) {
-              const int first = slot_first(s >> 2), cnt = slot_cnt(s >> 2);
-#pragma unroll
-              for (int d = (cnt * j) / 4; d < (cnt * (j + 1)) / 4; ++d) dma_piece(first + d, c1, q >= 12 ? buf : buf ^ 1);
-            }
+            if (ks == 0) { if (more1) dma_piece(4 + g, cB, mod10(pa + 6)); }        // W(t+1) pieces 4..7
+            else if (ks == 1) { if (more2) dma_piece(g, cA, mod10(pa + 8)); }       // A(t+2) pieces 0..3
+            else if (ks == 2) { if (more2) dma_piece(4 + g, cA, mod10(pa + 8)); }   // A(t+2) pieces 4..7
+            else { if (more2) dma_piece(g, cB, pa); }                               // W(t+2) pieces 0..3 (pa + 10)
             __builtin_amdgcn_sched_barrier(0);
           }
         }
         asm volatile("" : "+a"(acc[g][0]), "+a"(acc[g][1]), "+a"(acc[g][2]), "+a"(acc[g][3]));
         __builtin_amdgcn_sched_barrier(0);
-        if (q == NSLOT - 5 && more) next(c1);   // tile t+1's last slot is out: the cursor moves to tile t+2
       }
+      if (ks == 0 && more1) next(cB, false);   // W(t+1) is out: cB -> tile t+2
+      if (ks == 2 && more2) next(cA, true);    // A(t+2) is out: cA -> tile t+3
     }
-  }
+    pa = pa1;
+  };
+  int t = 0;
+  for (; t + 2 < nk; ++t) tile(t, std::false_type{});
+  for (; t < nk; ++t) tile(t, std::true_type{});
 }
 
 template <int KNOCK>
 __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1469,7 +1739,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x16 acc[4][4];
-  gemm_mainloop_w4<false, KNOCK>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  switch (w) {
+    case 0: gemm_mainloop_w4<false, KNOCK, 0>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
+    case 1: gemm_mainloop_w4<false, KNOCK, 1>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
+    case 2: gemm_mainloop_w4<false, KNOCK, 2>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
+    default: gemm_mainloop_w4<false, KNOCK, 3>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
+  }
+  clk.end(g_clk_probe);
   __syncthreads();
   gemm_epilogue_lds<4, false>(p, G, acc, m0, n0, (w >> 1) * 128, (w & 1) * 128, lane, smem + w * EPI_REGION);
 }
@@ -1655,7 +1931,7 @@ static void layout_tiles(GemmParams& p) {
 static int g_w4_knock = 0;
 template <int KNOCK>
 static int launch_gemm_w4_k(GemmParams& p, hipStream_t stream) {
-  constexpr int LDS = 2 * 65536;
+  constexpr int LDS = 10 * 16384;   // the whole 160 KiB: a ring of ten sub-blocks
   static bool attr_set = false;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<KNOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1699,6 +1975,12 @@ static int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
     case 3: return launch_gemm_w4_k<3>(p, stream);
     case 4: return launch_gemm_w4_k<4>(p, stream);
     case 7: return launch_gemm_w4_k<7>(p, stream);
+    case 8: return launch_gemm_w4_k<8>(p, stream);
+    case 10: return launch_gemm_w4_k<10>(p, stream);
+    case 16: return launch_gemm_w4_k<16>(p, stream);
+    case 64: return launch_gemm_w4_k<64>(p, stream);
+    case 66: return launch_gemm_w4_k<66>(p, stream);
+    case 32: return launch_gemm_w4_k<32>(p, stream);
     default: return launch_gemm_w4_k<0>(p, stream);
   }
 }
@@ -1721,6 +2003,7 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   return RF_OK;
 }
 
+static int g_mi16 = 1;   // bf16 tile-per-block launches use 16x16x32 MFMAs (rf_debug_gemm_mi16)
 static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * 4 * 128 * 128, LDS_EPI = 8 * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
@@ -1728,11 +2011,13 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
   if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  else if (g_mi16) hipLaunchKernelGGL(gemm_bf16_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
@@ -2118,6 +2403,7 @@ extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
   *mhz = *us > 0 ? (double)(h[2] - h[0]) / *us : 0.0;
   return RF_OK;
 }
+extern "C" int rf_debug_gemm_mi16(int on) { rf::g_mi16 = on ? 1 : 0; return RF_OK; }   // A/B hook: MFMA shape of the bf16 256x256 kernel
 extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
 extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds
   rf::g_persistent_rounds = rounds < 0 ? 0 : rounds;

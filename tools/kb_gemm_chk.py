@@ -7,8 +7,9 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 VAR = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+TILE = int(sys.argv[2]) if len(sys.argv) > 2 else 259   # 258 = one-wave-per-SIMD ring kernel
 def run(groups_fn, N, ref, tag):
-    for tile, var in ((256, 0), (259, VAR)):
+    for tile, var in ((256, 0), (TILE, VAR)):
         lib.rf_debug_force_gemm_tile(tile); lib.rf_debug_force_gemm_sk(0); lib.rf_debug_gemm_w4_knock(var)
         y = groups_fn()
         torch.cuda.synchronize()

@@ -20,10 +20,10 @@ for (M, N, K) in ((512, 512, 256), (4608, 3072, 3072), (777, 1000, 192)):
     print(f"w4 {M}x{N}x{K}: rel-L2 {err:.3e}", flush=True)
     assert err < 5e-3
 rows = []
-for rep in range(2):
-    for mode in ("old", "pp", "default"):
+for rep in range(3):
+    for mode in ("pp", "w4", "default"):
         lib.rf_debug_gemm_w4_knock(0)
-        lib.rf_debug_force_gemm_tile(259 if mode == "old" else 0)
+        lib.rf_debug_force_gemm_tile(258 if mode == "w4" else 0)
         lib.rf_debug_force_gemm_sk(0 if mode == "pp" else -1)
         rows.append((mode, bench.isolated_shapes(dev, 512, 4096, 3072, 12288, 24, 19, 38)))
 lib.rf_debug_force_gemm_tile(0); lib.rf_debug_force_gemm_sk(-1)
