@@ -61,6 +61,7 @@ struct GemmParams {
 };
 
 __device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
+static int g_mi16 = 1;   // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs (rf_debug_gemm_mi16)
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
 
@@ -1776,8 +1777,9 @@ struct SkParams {
   int* flags;           // [gridDim.x], zero outside a launch
 };
 
-template <int BM, int BN, int WM, int WN, bool W8>
+template <int BM, int BN, int WM, int WN, bool W8, bool MI16 = false>   // MI16: bf16 launch on 16x16x32 MFMAs (gemm_mainloop_pp2_m16)
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmParams p, const SkParams sk) {
+  static_assert(!(W8 && MI16), "the fp8 loop stays on 32x32x64");
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
@@ -1842,9 +1844,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
     // loop (LICM would hoist ~100 VGPRs of it across the whole kernel and spill)
     int lane_i = lane, tid_i = tid;
     asm volatile("" : "+v"(lane_i), "+v"(tid_i));
-    f32x16 acc[FM][FN];
+    // a thread's accumulators are 32 quads either way: acc[i][j][4rq..] (32x32x16) or acc16[it][jt] (16x16x32); partial
+    // sums travel quad by quad in that order, which producer and consumer (the same kernel) share
+    typename std::conditional<MI16, f32x4[4][8], f32x16[FM][FN]>::type acc;
+    auto quad = [&](const int k) -> f32x4 {
+      if constexpr (MI16) return acc[k >> 3][k & 7];
+      else return f32x4{acc[k >> 4][(k >> 2) & 3][(k & 3) * 4], acc[k >> 4][(k >> 2) & 3][(k & 3) * 4 + 1],
+                        acc[k >> 4][(k >> 2) & 3][(k & 3) * 4 + 2], acc[k >> 4][(k >> 2) & 3][(k & 3) * 4 + 3]};
+    };
+    auto quad_add = [&](const int k, const f32x4 v) {
+      if constexpr (MI16) acc[k >> 3][k & 7] += v;
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[k >> 4][(k >> 2) & 3][(k & 3) * 4 + e] += v[e];
+      }
+    };
     const bool g8 = W8 && G.w8;   // mixed-precision launch: multiply chosen per token group
-    if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    if constexpr (MI16) gemm_mainloop_pp2_m16(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     else gemm_mainloop_pp2<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
 
     if (!is_tail) {
@@ -1854,14 +1871,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
       {
         uint32_t voff = (uint32_t)tid_i * 16u;
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-              const f32x4 v = {acc[i][j][rq * 4], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-              asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\tv_add_u32 %0, 0x2000, %0" : "+v"(voff) : "v"(v), "s"(my_slot) : "memory");
-            }
+        for (int k = 0; k < 32; ++k) {
+          const f32x4 v = quad(k);
+          asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\tv_add_u32 %0, 0x2000, %0" : "+v"(voff) : "v"(v), "s"(my_slot) : "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();  // every thread's stores have been issued and acknowledged
@@ -1883,9 +1896,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
           const float* slot = sk.partials + (int64_t)b2 * (BM * BN);
           uint32_t voff = (uint32_t)tid_i * 16u;
 #pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; j += 2) {
+          for (int k8 = 0; k8 < 32; k8 += 8) {
               f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
               asm volatile(
                   "global_load_dwordx4 %0, %8, %9 sc1\n\tv_add_u32 %8, 0x2000, %8\n\t"
@@ -1902,15 +1913,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
                   : "memory");
               const f32x4 tt[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
 #pragma unroll
-              for (int q = 0; q < 8; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][j + (q >> 2)][(q & 3) * 4 + e] += tt[q][e];
+              for (int q = 0; q < 8; ++q) quad_add(k8 + q, tt[q]);
             }
           if (rb2 <= ts) break;
         }
       }
       __syncthreads();  // every wave is done reading the staged operands: the LDS is free
-      if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      if constexpr (MI16) gemm_epilogue_lds16<FM>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      else if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
       else gemm_epilogue_lds<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
     }
   }
@@ -2003,7 +2013,6 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   return RF_OK;
 }
 
-static int g_mi16 = 1;   // bf16 tile-per-block launches use 16x16x32 MFMAs (rf_debug_gemm_mi16)
 static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * 4 * 128 * 128, LDS_EPI = 8 * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
@@ -2134,12 +2143,15 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
-  auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8>;
+  auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>;
+  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, false, true>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  if (!W8 && g_mi16) hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  else hipLaunchKernelGGL(kern, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   RF_LAUNCH_CHECK();
   g_last_path = 2;
   return 1;
