@@ -406,11 +406,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const Gem
                                                   const int lane, char* region) {
   gemm_epilogue_lds_v<FM, W8>(p, G, Acc32<FM>{acc}, m0, n0, wrow0, wcol0, lane, region);
 }
-template <int FM>
+template <int FM, bool W8 = false>
 __device__ __forceinline__ void gemm_epilogue_lds16(const GemmParams& p, const GemmGroupDev& G, f32x4 (&acc)[2 * FM][8],
                                                     const int m0, const int n0, const int wrow0, const int wcol0,
                                                     const int lane, char* region) {
-  gemm_epilogue_lds_v<FM, false>(p, G, Acc16<FM>{acc}, m0, n0, wrow0, wcol0, lane, region);
+  gemm_epilogue_lds_v<FM, W8>(p, G, Acc16<FM>{acc}, m0, n0, wrow0, wcol0, lane, region);
 }
 
 // ---- main loop ----------------------------------------------------------------------------------------
@@ -665,8 +665,10 @@ __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define RF_MFMA_FP8(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127)
+#define RF_MFMA_FP8_16(a, b, c) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127)
 #else
 #define RF_MFMA_FP8(a, b, c) (c)
+#define RF_MFMA_FP8_16(a, b, c) (c)
 #endif
 
 // one phase's multiply: the 32 x 64 quadrant (a x {b0, b1}) over the whole K-tile
@@ -1063,9 +1065,10 @@ __device__ __forceinline__ void gemm_mainloop_pp2(const GemmGroupDev& G, const i
 // all: the chip settles at 1.89 vs 2.13 GHz) -- the small shape reads and writes half the accumulator bytes per MAC.  Fragment
 // counts per phase, LDS image, staging and barriers are unchanged (a 32-row A half = 2 row tiles x 2 k-steps = 4 fragments,
 // a 64-column W half = 4 x 2 = 8); only the lane -> (row, chunk) map of a fragment read and the accumulator layout differ.
+template <bool W8 = false>
 __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                   const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
-  constexpr int ESZ = 2;  // bytes per element
+  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
   constexpr int HT = 128 * 128;  // half-tile bytes
   constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
   const int wm = w >> 1, wn = w & 1, grp = w >> 2;
@@ -1143,13 +1146,30 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
   // one phase: the 32 x 64 quadrant (row tiles rb, rb+1) x (column tiles cb .. cb+3) over the whole K-tile, 16 MFMAs;
   // the two updates of an accumulator are 8 MFMAs apart
   auto mma16 = [&](const int rb, const int cb, const bf16x8 (&A)[4], const bf16x8 (&B)[8]) {
+    if constexpr (!W8) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[rb + rt][cb + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt * 2 + ks], B[ct * 2 + ks], acc[rb + rt][cb + ct], 0, 0, 0);
+    } else {
+      // fp8: a 128-byte row is the whole k-step of v_mfma_scale_f32_16x16x128_f8f6f4; a lane's 32 operand bytes are
+      // k = 16g .. 16g+15 and 64+16g .. (g = lane >> 4; measured, profiles/r02_mx_probe.md) = chunks g and 4 + g, which
+      // are exactly the two fragment reads the bf16 map makes for its k-steps 0 and 1.  Unit E8M0 scales.
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const i32x8 av = cat_frag(A[rt * 2], A[rt * 2 + 1]);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-          acc[rb + rt][cb + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt * 2 + ks], B[ct * 2 + ks], acc[rb + rt][cb + ct], 0, 0, 0);
+          acc[rb + rt][cb + ct] = RF_MFMA_FP8_16(av, cat_frag(B[ct * 2], B[ct * 2 + 1]), acc[rb + rt][cb + ct]);
+      }
+      // pin the results to this phase (see mma_quadrant: IR passes sink scaled MFMAs below the phase barriers)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        asm volatile("" : "+v"(acc[rb + rt][cb]), "+v"(acc[rb + rt][cb + 1]), "+v"(acc[rb + rt][cb + 2]), "+v"(acc[rb + rt][cb + 3]));
+    }
   };
 
   Cur c1;
@@ -1491,8 +1511,9 @@ __device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
   }
 }
 __global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) { gemm_pp_body<false>(p); }
-// bf16 launches on 16x16x32 MFMAs (gemm_mainloop_pp2_m16)
-__global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p) {
+// launches on the 16x16 MFMA shapes (gemm_mainloop_pp2_m16): bf16, or W8 = mixed precision per token group
+template <bool W8>
+__device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
   clk.begin();
@@ -1510,12 +1531,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p)
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x4 acc[4][8];
-  gemm_mainloop_pp2_m16(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-  clk.end(g_clk_probe);
-  __syncthreads();  // every wave is done reading the staged operands: the LDS is free
-  gemm_epilogue_lds16<2>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+  if (W8 && G.w8) {
+    gemm_mainloop_pp2_m16<W8>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+    clk.end(g_clk_probe);
+    __syncthreads();
+    gemm_epilogue_lds16<2, W8>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+  } else {
+    gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+    clk.end(g_clk_probe);
+    __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+    gemm_epilogue_lds16<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+  }
 }
 __global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
+__global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p) { gemm_pp16_body<false>(p); }
+__global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) { gemm_pp16_body<true>(p); }
 
 // experiment harness for the ping-pong main loop (one tile per block, bf16 only): rf_debug_force_gemm_tile(259)
 // clock probe: block 0 stores {s_memtime, s_memrealtime} (shader clocks, 100 MHz reference) around its tile, so
@@ -1777,9 +1807,8 @@ struct SkParams {
   int* flags;           // [gridDim.x], zero outside a launch
 };
 
-template <int BM, int BN, int WM, int WN, bool W8, bool MI16 = false>   // MI16: bf16 launch on 16x16x32 MFMAs (gemm_mainloop_pp2_m16)
+template <int BM, int BN, int WM, int WN, bool W8, bool MI16 = false>   // MI16: the 16x16 MFMA shapes (gemm_mainloop_pp2_m16)
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmParams p, const SkParams sk) {
-  static_assert(!(W8 && MI16), "the fp8 loop stays on 32x32x64");
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
@@ -1860,8 +1889,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
       }
     };
     const bool g8 = W8 && G.w8;   // mixed-precision launch: multiply chosen per token group
-    if constexpr (MI16) gemm_mainloop_pp2_m16(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
-    else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    if constexpr (MI16) {
+      if (g8) gemm_mainloop_pp2_m16<W8>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+      else gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    } else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     else gemm_mainloop_pp2<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
 
     if (!is_tail) {
@@ -1919,8 +1950,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
         }
       }
       __syncthreads();  // every wave is done reading the staged operands: the LDS is free
-      if constexpr (MI16) gemm_epilogue_lds16<FM>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
-      else if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      if constexpr (MI16) {
+        if (g8) gemm_epilogue_lds16<FM, W8>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+        else gemm_epilogue_lds16<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      } else if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
       else gemm_epilogue_lds<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
     }
   }
@@ -2021,11 +2054,13 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
-  if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  if (p.w8 && g_mi16) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  else if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   else if (g_mi16) hipLaunchKernelGGL(gemm_bf16_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
@@ -2144,13 +2179,13 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
   auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>;
-  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, false, true>;
+  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  if (!W8 && g_mi16) hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  if (g_mi16) hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   else hipLaunchKernelGGL(kern, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   RF_LAUNCH_CHECK();
   g_last_path = 2;

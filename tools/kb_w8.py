@@ -25,7 +25,11 @@ for M in (4608, 16896):
         c16 = clk()
         A8, sa = ops.quant_rows_fp8(x)
         W8, sw = ops.quantize_weight_fp8(W)
+        lib.rf_debug_gemm_mi16(0)
+        t8o = ops.time_gemm([Group([Seg(A8, W8)], a_scale=sa, w_scale=sw, **kw)], N, epi, iters=8)
+        c8o = clk()
+        lib.rf_debug_gemm_mi16(1)
         t8 = ops.time_gemm([Group([Seg(A8, W8)], a_scale=sa, w_scale=sw, **kw)], N, epi, iters=8)
         c8 = clk()
         fl = 2.0 * M * N * K
-        print(f"M={M:6d} {name:12s} N={N:6d} K={K:6d}: bf16 {t16*1e6:8.1f} us {fl/t16/1e12:7.1f} TF @{c16:5.0f} MHz | fp8 {t8*1e6:8.1f} us {fl/t8/1e12:7.1f} TF @{c8:5.0f} MHz | x{t16/t8:.2f}", flush=True)
+        print(f"M={M:6d} {name:12s} N={N:6d} K={K:6d}: bf16 {t16*1e6:8.1f} us {fl/t16/1e12:7.1f} TF @{c16:5.0f} MHz | fp8 32x32x64 {t8o*1e6:8.1f} us {fl/t8o/1e12:7.1f} TF @{c8o:5.0f} | fp8 16x16x128 {t8*1e6:8.1f} us {fl/t8/1e12:7.1f} TF @{c8:5.0f} MHz | x{t16/t8:.2f}", flush=True)
