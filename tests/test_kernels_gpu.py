@@ -590,3 +590,70 @@ def test_gemm_persistent_whole_tiles_equals_tile_per_block(dev, rows, N, K):
     for i in range(len(rows)):
         assert torch.equal(outs[0][i], outs[2][i]), f"group {i}: persistent != tile-per-block"
         assert_close(outs[2][i], res[i].float() + gate.float() * (xs[i].float() @ Ws[i].float().t() + b.float()), f"persistent group {i}")
+
+
+@pytest.mark.parametrize("rows,N,K", [((512, 4096), 3072, 3072), ((300, 5000, 77), 1536, 320), ((4608,), 3072, 64)])
+def test_gemm_mfma_shapes_and_experimental_loops_agree(dev, rows, N, K):
+    """The shipped 256x256 kernel multiplies with v_mfma_f32_16x16x32_bf16; rf_debug_gemm_mi16(0) selects the 32x32x16
+    loop it replaced.  Both walk the K-tiles in the same order with fp32 accumulation per output element, so the results
+    are bit-identical -- as are the experimental main loops kept in the library (rf_debug_force_gemm_tile 258: one wave
+    per SIMD over an LDS ring; 259 + variant 5 / 6: the balanced and the evenly loaded ping-pong phases on 32x32x16),
+    with grouped rows, a ragged last tile in M and N, 1 / 5 / 48 K-tiles and the gate-residual epilogue."""
+    from reflectionflow_amd import _lib, ops
+    from reflectionflow_amd.ops import RF_EPI_GATE_RES, Group, Seg
+    lib = _lib.load()
+    xs = [rnd(m, K, dev=dev, seed=150 + i) for i, m in enumerate(rows)]
+    Ws = [rnd(N, K, dev=dev, scale=0.05, seed=160 + i) for i in range(len(rows))]
+    b, gate = rnd(N, dev=dev), rnd(N, dev=dev)
+    res = [rnd(m, N, dev=dev, seed=170 + i) for i, m in enumerate(rows)]
+    outs = {}
+    try:
+        for name, tile, var, mi16 in (("16x16x32", 256, 0, 1), ("32x32x16", 256, 0, 0), ("one wave per SIMD", 258, 0, 1),
+                                      ("balanced 32x32", 259, 5, 1), ("even 32x32", 259, 6, 1)):
+            lib.rf_debug_force_gemm_sk(0)
+            lib.rf_debug_force_gemm_tile(tile)
+            lib.rf_debug_gemm_w4_knock(var)
+            lib.rf_debug_gemm_mi16(mi16)
+            o = [r_.clone() for r_ in res]
+            ops.gemm([Group([Seg(xs[i], Ws[i])], bias=b, out=o[i], residual=o[i], gate=gate) for i in range(len(rows))], N,
+                     RF_EPI_GATE_RES, splitk_ws=False)
+            outs[name] = o
+    finally:
+        lib.rf_debug_force_gemm_sk(-1)
+        lib.rf_debug_force_gemm_tile(0)
+        lib.rf_debug_gemm_w4_knock(0)
+        lib.rf_debug_gemm_mi16(1)
+    for i in range(len(rows)):
+        assert_close(outs["16x16x32"][i], res[i].float() + gate.float() * (xs[i].float() @ Ws[i].float().t() + b.float()), f"group {i}")
+        for name in outs:
+            assert torch.equal(outs[name][i], outs["16x16x32"][i]), f"group {i}: '{name}' differs from the shipped kernel"
+
+
+def test_gemm_stream_k_on_both_mfma_shapes(dev):
+    """Stream-K (partial accumulators travel through scratch quad by quad) on the 16x16x32 kernel and on the 32x32x16 one
+    (S = 5632-like rows, 264 tiles): for a given schedule the two MFMA shapes agree bit for bit; stream-K splits the K sum
+    of a tile between workers, so against one tile per block it is compared with the usual tolerance."""
+    from reflectionflow_amd import _lib, ops
+    from reflectionflow_amd.ops import Group, Seg
+    lib = _lib.load()
+    rows, N, K = (512, 4096, 1024), 3072, 3072
+    xs = [rnd(m, K, dev=dev, seed=250 + i) for i, m in enumerate(rows)]
+    Ws = [rnd(N, K, dev=dev, scale=0.05, seed=260 + i) for i in range(len(rows))]
+    outs = {}
+    try:
+        for mi16 in (1, 0):
+            for sk in (0, 1):
+                lib.rf_debug_gemm_mi16(mi16)
+                lib.rf_debug_force_gemm_sk(sk)
+                o = [torch.empty(m, N, dtype=BF, device=dev) for m in rows]
+                ops.gemm([Group([Seg(xs[i], Ws[i])], out=o[i]) for i in range(len(rows))], N)
+                assert lib.rf_debug_last_gemm_path() == (2 if sk else 0)
+                outs[(mi16, sk)] = o
+    finally:
+        lib.rf_debug_force_gemm_sk(-1)
+        lib.rf_debug_gemm_mi16(1)
+    for i in range(len(rows)):
+        for sk in (0, 1):
+            assert torch.equal(outs[(0, sk)][i], outs[(1, sk)][i]), f"group {i}, stream-K={sk}: the MFMA shapes disagree"
+        assert_close(outs[(1, 1)][i], xs[i].float() @ Ws[i].float().t(), f"stream-K group {i}")
+        assert_close(outs[(1, 1)][i], outs[(1, 0)][i].float(), f"stream-K vs tile-per-block, group {i}", rtol=4e-3)
