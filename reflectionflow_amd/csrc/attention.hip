@@ -704,17 +704,262 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
   }
 }
 
+// =================================================================================================
+// v5 -- v4's schedule on v_mfma_f32_16x16x32_bf16.  Under the 1.4 kW cap the 16x16 shape sustains ~15 % more FLOP/s than
+// 32x32x16 (half the accumulator bytes per MAC; tools/ubench/mfma_power.py) and attention runs at the cap (1.8 GHz).
+// Same workgroup, rings, DMA queue, counted waits, three independent streams per tile and 16 fenced groups -- a group is now
+// four 16-cycle MFMAs on two fragments (each fragment feeds both 16-query tiles of the wave) instead of two 32-cycle ones.
+//   * a wave's 32 queries are two q-tiles; S^T, P^T and O^T tiles have q = lane & 15 in BOTH MFMA shapes, so P still goes
+//     from the score accumulators into the PV product's B operand inside a lane;
+//   * the PV B operand of a 32-key block wants, in lane group g = lane >> 4, the keys VT stores at positions 8g .. 8g+7
+//     of the block = {0-3, 8-11}, {4-7, 12-15}, {16-19, 24-27}, {20-23, 28-31} (the permutation the QKV epilogue already
+//     writes for the 32x32 kernel).  A 16x16 score tile leaves rows 4g .. 4g+3 in lane group g, so each 32-key block is
+//     scored as TWO tiles whose MFMA rows are the keys T0 = {0-7, 16-23} and T1 = T0 + 8: lane group g then holds
+//     exactly its eight keys, four from each tile.  The row permutation costs nothing: it is the per-lane row offset of
+//     the K fragment read;
+//   * K ring swizzle: chunk ^ ((row & 7) | ((row >> 1) & 8)) -- the 16 rows of a T tile get 16 different chunk slots
+//     (for every fragment the term is just lane & 15).  VT ring: v4's (row >> 1) & 7.
+__global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int head = blockIdx.x % p.heads;
+  const int qb = blockIdx.x / p.heads;
+  const int S = p.S;
+  const int nt = S / ATT_KV;
+  const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
+  const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
+  const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
+  char* const kring = smem;
+  char* const vring = smem + ATT4_RING * 16384;
+
+  // Q B-operand fragments: [q-tile][d step of 32]: lane -> query qt*16 + l15, d = 32 ds + 8g .. +8
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q_row = qb * 256 + w * 32 + qt * 16 + l15;
+    const bf16_t* qp = p.q + ((int64_t)head * p.s_pad + (q_row < S ? q_row : S - 1)) * 128 + g * 8;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *(const bf16x8*)(qp + ds * 32);
+  }
+  // DMA pieces: 2 of the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each) per wave
+  uint32_t k_src[2], v_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 8 + w) * 4 + (lane >> 4);
+    const int ksw = (row & 7) | ((row >> 1) & 8);
+    k_src[i] = (uint32_t)(row * 256 + (((lane & 15) ^ ksw) * 16));
+    const int vrow = (i * 8 + w) * 8 + (lane >> 3);
+    v_src[i] = (uint32_t)((vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
+  }
+  auto issue_k = [&](int t, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 8 + w) * 1024), k_src[i], t * (ATT_KV * 256));
+  };
+  auto issue_v = [&](int t, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 8 + w) * 1024), v_src[i], t * (128 * 64 * 2));
+  };
+  // fragment read addresses: 4 (K, per d step) + 2 (V^T, per 32-key block) per-lane registers; ring slot, key block,
+  // T tile (+8 rows) and d tile are immediates.  K row of MFMA row l15 in tile T0: (l15 & 7) | ((l15 & 8) << 1).
+  const char* k_rd[4];
+  const char* v_rd[2];
+  const int krow = (l15 & 7) | ((l15 & 8) << 1);
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) k_rd[ds] = kring + krow * 256 + (((ds * 4 + g) ^ l15) << 4);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) v_rd[b] = vring + l15 * 128 + (((b * 4 + g) ^ ((l15 >> 1) & 7)) << 4);
+  // K fragment (32-key block b, tile T, d step ds): k_rd[ds] + slot*16384 + b*32*256 + T*8*256
+  // V fragment (d tile dt, block b):               v_rd[b] + slot*16384 + dt*16*128
+
+  f32x4 oacc[8][2];   // O^T tiles [d tile][q tile]: d = dt*16 + 4g + r, q = l15
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][qt][r] = 0.f;
+  float l_run[2] = {0.f, 0.f};
+  // score tiles, index ti = b*4 + T*2 + qt: this lane holds keys b*32 + T*8 + {0-3 | 4-7 | 16-19 | 20-23}[g] of query l15
+  f32x4 s_cur[8], s_nxt[8];
+  bf16x8 pf[4];   // P(t-1): B-operand fragments [b*2 + qt] of the pending PV product: words T*2, T*2+1 from tile (b, T, qt)
+
+  {  // V ring slot 3 stands in for V(-1): tile 0 multiplies it with P(-1) = 0, so it must be finite
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(vring + 3 * 16384 + (i * 8 + w) * 1024 + lane * 16) = z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[i][j] = (bf16_t)0.f;
+  }
+  issue_k(0, 0);
+  if (nt > 1) issue_k(1, 1);
+  if (nt > 2) issue_k(2, 2);
+  issue_v(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill above
+  RF_ATT4_WAIT_BARRIER(2 * ((nt > 1) + (nt > 2) + 1));   // K0 landed
+#pragma unroll
+  for (int bt = 0; bt < 4; ++bt) {   // (b, T) = (bt >> 1, bt & 1)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_cur[bt * 2 + qt][r] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) s_cur[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * 2 + qt], 0, 0, 0);
+    }
+  }
+
+  auto tile = [&](const int t, auto ts_tag) {
+    constexpr int TS = decltype(ts_tag)::value;
+    constexpr int KSLOT = (TS + 1) % 4, VSLOT = (TS + 3) % 4;
+    // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t)
+    RF_ATT4_WAIT_BARRIER(2 * ((t + 2 < nt) + 1));
+    if (t + 3 < nt) issue_k(t + 3, (TS + 3) % 4);
+    if (t + 1 < nt) issue_v(t + 1, KSLOT);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fr[2][2];   // fragment double buffer: group G multiplies fr[G & 1][0..1]
+    float psum[2] = {0.f, 0.f};
+    // fragment pair of group G: G < 8 -> V^T(t-1) [d tile G, key blocks 0, 1], else K(t+1) [(b, T) = (G-8)/2, d steps ((G-8)%2)*2 + 0, 1]
+    auto load_group = [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value;
+      if constexpr (G < 8) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) fr[G & 1][e] = *(const bf16x8*)(v_rd[e] + VSLOT * 16384 + G * 16 * 128);
+      } else if constexpr (G < 16) {
+        constexpr int bt = (G - 8) / 2;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          fr[G & 1][e] = *(const bf16x8*)(k_rd[((G - 8) % 2) * 2 + e] + KSLOT * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+      }
+    };
+    load_group(std::integral_constant<int, 0>{});
+    // ---- first half: pending PV product (8 groups of 4 MFMA: d tile G) | P = exp2(S) in place + row sums (tile G) ----
+    static_for(std::make_integer_sequence<int, 8>{}, [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value;
+      load_group(std::integral_constant<int, G + 1>{});
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          oacc[G][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][b], pf[b * 2 + qt], oacc[G][qt], 0, 0, 0);
+      {
+        float e4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e4[j] = __builtin_amdgcn_exp2f(s_cur[G][j]);
+        RF_PIN4(e4[0], e4[1], e4[2], e4[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s_cur[G][j] = e4[j];
+          psum[G & 1] += e4[j];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("" : "+v"(psum[0]), "+v"(psum[1]));
+    l_run[0] += psum[0];
+    l_run[1] += psum[1];
+    // ---- second half: next tile's scores (8 groups of 4 MFMA) | pack P tile G-8 into the PV operand ----------------
+    static_for(std::make_integer_sequence<int, 8>{}, [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value + 8;
+      load_group(std::integral_constant<int, G + 1>{});
+      constexpr int bt = (G - 8) / 2;
+      constexpr int dsb = ((G - 8) % 2) * 2;
+      if constexpr (dsb == 0) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_nxt[bt * 2 + qt][r] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          s_nxt[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][e], qf[qt][dsb + e], s_nxt[bt * 2 + qt], 0, 0, 0);
+      {
+        constexpr int ti = G - 8;                       // score tile (b, T, qt) = (ti >> 2, (ti >> 1) & 1, ti & 1)
+        uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
+        uint32_t w1 = pack2(s_cur[ti][2], s_cur[ti][3]);
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        constexpr int pi = (ti >> 2) * 2 + (ti & 1), wi = ((ti >> 1) & 1) * 2;
+        u32x4 t4 = __builtin_bit_cast(u32x4, pf[pi]);
+        t4[wi] = w0;
+        t4[wi + 1] = w1;
+        pf[pi] = __builtin_bit_cast(bf16x8, t4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_cur[i] = s_nxt[i];
+  };
+  for (int t = 0; t < nt; t += 4) {   // unrolled by the ring size (dispatch guarantees nt % 4 == 0): one exit
+    tile(t, std::integral_constant<int, 0>{});
+    tile(t + 1, std::integral_constant<int, 1>{});
+    tile(t + 2, std::integral_constant<int, 2>{});
+    tile(t + 3, std::integral_constant<int, 3>{});
+  }
+
+  clk.end(g_attn_clk_probe);
+  // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
+  RF_ATT4_WAIT_BARRIER(0);
+  {
+    const int vslot = (nt - 1) % ATT4_RING;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 vf = *(const bf16x8*)(v_rd[b] + vslot * 16384 + dt * 16 * 128);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * 2 + qt], oacc[dt][qt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    // a query's keys are spread over the four lane groups: lanes l15, l15 + 16, + 32, + 48
+    float l_tot = l_run[qt];
+    l_tot += __shfl_xor(l_tot, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.0f / l_tot;
+    const int q_row = qb * 256 + w * 32 + qt * 16 + l15;
+    if (q_row < S) {
+      bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u32x2 v;
+        v[0] = pack2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
+        v[1] = pack2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
+        *(u32x2*)(orow + dt * 16) = v;
+      }
+    }
+  }
+}
+
 int read_clk_probe_attn(unsigned long long* h) {
   return hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_clk_probe), 4 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
 }
 
 static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)
-static int g_attn_v4 = 1;   // 1 = launches with a proven score bound that qualify for v2's plain instantiation run v4, 0 = never
+static int g_attn_v4 = 1;   // 1 = launches with a proven score bound that qualify for v2's plain instantiation run v4 / v5, 0 = never
+static int g_attn_v5 = 1;   // 1 = the bounded-score kernel on 16x16x32 MFMAs (v5), 0 = on 32x32x16 (v4)
 
 }  // namespace rf
 
 extern "C" int rf_debug_attn_v2(int on) {  // tuning hook (-1 = cost model), not part of the drop-in surface
   rf::g_attn_v2 = on < 0 ? -1 : (on ? 1 : 0);
+  return RF_OK;
+}
+
+extern "C" int rf_debug_attn_v5(int on) {  // A/B hook: MFMA shape of the bounded-score kernel
+  rf::g_attn_v5 = on ? 1 : 0;
   return RF_OK;
 }
 
@@ -746,6 +991,7 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v4, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     attr_set = true;
   }
   AttnParams p;
@@ -771,7 +1017,8 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
     const dim3 grid2(heads * cdiv(S, 256)), blk(512);
     const bool generic = !(mode == 0 && S % 64 == 0);
     if (!generic && S % 256 == 0 && pre && g_attn_v4 && score_bound > 0.f && score_bound <= 100.f) {
-      hipLaunchKernelGGL(attn_fwd_kernel_v4, grid2, blk, ATT4_LDS, st, p);
+      if (g_attn_v5) hipLaunchKernelGGL(attn_fwd_kernel_v5, grid2, blk, ATT4_LDS, st, p);
+      else hipLaunchKernelGGL(attn_fwd_kernel_v4, grid2, blk, ATT4_LDS, st, p);
     } else if (generic) {
       if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<true, true>), grid2, blk, ATT2_LDS, st, p);
       else hipLaunchKernelGGL((attn_fwd_kernel_v2<true, false>), grid2, blk, ATT2_LDS, st, p);

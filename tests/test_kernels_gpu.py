@@ -656,4 +656,4 @@ def test_gemm_stream_k_on_both_mfma_shapes(dev):
         for sk in (0, 1):
             assert torch.equal(outs[(0, sk)][i], outs[(1, sk)][i]), f"group {i}, stream-K={sk}: the MFMA shapes disagree"
         assert_close(outs[(1, 1)][i], xs[i].float() @ Ws[i].float().t(), f"stream-K group {i}")
-        assert_close(outs[(1, 1)][i], outs[(1, 0)][i].float(), f"stream-K vs tile-per-block, group {i}", rtol=4e-3)
+        assert_close(outs[(1, 1)][i], outs[(1, 0)][i].float(), f"stream-K vs tile-per-block, group {i}")   # (a bf16 ulp apart at most)

@@ -1,6 +1,7 @@
-"""Attention kernels A/B on one GPU: v1 (4 waves), v2 (8 waves, online softmax), v4 (8 waves, bounded score) at the
-BASELINE sequence lengths, realistic score scale (q, k ~ RMS-normalised rows, prescaled q), interleaved repetitions."""
-import os, sys, torch
+"""Attention kernels A/B on one GPU: v1 (4 waves), v2 (8 waves, online softmax), v4 (8 waves, bounded score, 32x32x16
+MFMAs), v5 (the same on 16x16x32) at the BASELINE sequence lengths, realistic score scale (q, k ~ RMS-normalised rows,
+prescaled q), interleaved repetitions; shader clock from the kernels' own probe."""
+import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reflectionflow_amd import _lib, ops
 from tools.kbench import timeit
@@ -14,10 +15,14 @@ for S in (4608, 5632, 17920):
     out = torch.empty(S, H * 128, device=dev, dtype=torch.bfloat16)
     for rep in range(3):
         line, outs = [], []
-        for name, v2, v4 in (("v1", 0, 0), ("v2", 1, 0), ("v4", 1, 1)):
-            lib.rf_debug_attn_v2(v2); lib.rf_debug_attn_v4(v4)
+        for name, v2, v4, v5 in (("v1", 0, 0, 0), ("v2", 1, 0, 0), ("v4", 1, 1, 0), ("v5", 1, 1, 1)):
+            lib.rf_debug_attn_v2(v2); lib.rf_debug_attn_v4(v4); lib.rf_debug_attn_v5(v5)
             t = timeit(lambda: ops.attention(q, k, vt, S, out=out, q_prescaled=True, score_bound=bound), 10 if S < 10000 else 4)
+            torch.cuda.synchronize()
             outs.append(out.clone())
-            line.append(f"{name}: {t*1e6:8.1f} us {4.0*S*S*H*128/t/1e12:6.1f} TF")
-        print(f"S={S} bound={bound:.1f}", " | ".join(line), " max|v4-v2|", float((outs[2].float()-outs[1].float()).abs().max()), flush=True)
-lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1)
+            mhz, us = C.c_double(0), C.c_double(0)
+            lib.rf_debug_clock_probe(1, C.byref(mhz), C.byref(us))
+            line.append(f"{name}: {t*1e6:8.1f} us {4.0*S*S*H*128/t/1e12:6.1f} TF" + (f" @{mhz.value:5.0f} MHz" if v4 else ""))
+        print(f"S={S} bound={bound:.1f}", " | ".join(line), " max|v4-v2|", float((outs[2].float()-outs[1].float()).abs().max()),
+              " max|v5-v4|", float((outs[3].float()-outs[2].float()).abs().max()), flush=True)
+lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1); lib.rf_debug_attn_v5(1)
