@@ -158,6 +158,17 @@ int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad
 int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                      int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
                      float cross_bias, float scale, int32_t q_prescaled, float score_bound, void* stream);
+/* The same call with scratch: when the bounded-score kernel applies and its grid of heads * S/256 workgroups would
+ * fill < 80 % of its rounds of CUs (S = 5632: 528 workgroups = 2.06 rounds run as 3), the library runs one persistent
+ * workgroup per CU over equal shares of the (query block, key range) space; a block whose keys were split between
+ * two workgroups leaves its partial (O, l) in `ws` and a second launch adds them (no rescaling: there is no running
+ * maximum).  ws: 16-byte aligned device memory, >= rf_attention_ws_bytes() bytes, may be shared with any other
+ * scratch that is idle during this call (the engine passes its GEMM scratch); NULL / too small = rf_attention_fwd. */
+int rf_attention_fwd_ws(const void* q, const void* k, const void* vt, void* out, int32_t heads,
+                        int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
+                        float cross_bias, float scale, int32_t q_prescaled, float score_bound,
+                        void* ws, int64_t ws_bytes, void* stream);
+int64_t rf_attention_ws_bytes(void);   /* scratch size that enables the split launch on the current device */
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm(no affine, eps) + (1+scale)*x + shift, row-wise over D

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 
@@ -98,6 +98,9 @@ _SIGS = {
                                      C.c_float, _P]),
     "rf_attention_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_float, C.c_float, C.c_int32, C.c_float, _P]),
+    "rf_attention_fwd_ws": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_float, C.c_float, C.c_int32, C.c_float, _P, C.c_int64, _P]),
+    "rf_attention_ws_bytes": (C.c_int64, []),
     "rf_layernorm_modulate": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, _P]),
     "rf_euler_step": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "rf_silu": (C.c_int, [_P, _P, C.c_int64, _P]),
@@ -121,6 +124,7 @@ RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quan
 # test / tuning hook, not part of the declared drop-in surface
 _EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
                "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
+               "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_last_attn_path": (C.c_int, []),
                "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
                "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]),

@@ -719,18 +719,43 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
 //     the K fragment read;
 //   * K ring swizzle: chunk ^ ((row & 7) | ((row >> 1) & 8)) -- the 16 rows of a T tile get 16 different chunk slots
 //     (for every fragment the term is just lane & 15).  VT ring: v4's (row >> 1) & 7.
-__global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ClkProbe clk;
-  clk.begin();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+// normalise a block's O^T accumulators by its row sums and store the 256 x 128 output rows (v5 accumulator layout)
+__device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[8][2], float (&l_run)[2], const int lane, const int w,
+                                             const int head, const int qb) {
   const int l15 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.x % p.heads;
-  const int qb = blockIdx.x / p.heads;
   const int S = p.S;
-  const int nt = S / ATT_KV;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    // a query's keys are spread over the four lane groups: lanes l15, l15 + 16, + 32, + 48
+    float l_tot = l_run[qt];
+    l_tot += __shfl_xor(l_tot, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.0f / l_tot;
+    const int q_row = qb * 256 + w * 32 + qt * 16 + l15;
+    if (q_row < S) {
+      bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u32x2 v;
+        v[0] = pack2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
+        v[1] = pack2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
+        *(u32x2*)(orow + dt * 16) = v;
+      }
+    }
+  }
+}
+
+
+// One (head, 256-query block) over the key tiles [t0, t0 + nt), nt % 4 == 0.  partial == nullptr: the range is the whole
+// key axis -> normalise and store the output rows.  Otherwise (split launch): leave the raw O^T accumulators and row sums of
+// this key range in the 132 KiB slot `partial` ([16 quads][512 threads] x 16 B, then [2][512] floats), thread-linear:
+// attn5_combine_kernel adds the slots of a block's pieces thread by thread and finishes it -- with no running maximum the
+// partial sums of disjoint key ranges simply add.
+template <bool PROBE>
+__device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
+                                           const int head, const int qb, const int t0, const int nt, float* partial, ClkProbe& clk) {
+  const int l15 = lane & 15, g = lane >> 4;
+  const int S = p.S;
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
   const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
   const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
@@ -759,12 +784,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   auto issue_k = [&](int t, int slot) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 8 + w) * 1024), k_src[i], t * (ATT_KV * 256));
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 8 + w) * 1024), k_src[i], (t0 + t) * (ATT_KV * 256));
   };
   auto issue_v = [&](int t, int slot) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 8 + w) * 1024), v_src[i], t * (128 * 64 * 2));
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 8 + w) * 1024), v_src[i], (t0 + t) * (128 * 64 * 2));
   };
   // fragment read addresses: 4 (K, per d step) + 2 (V^T, per 32-key block) per-lane registers; ring slot, key block,
   // T tile (+8 rows) and d tile are immediates.  K row of MFMA row l15 in tile T0: (l15 & 7) | ((l15 & 8) << 1).
@@ -908,7 +933,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
     tile(t + 3, std::integral_constant<int, 3>{});
   }
 
-  clk.end(g_attn_clk_probe);
+  if (PROBE) clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
   RF_ATT4_WAIT_BARRIER(0);
   {
@@ -922,25 +947,104 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
         for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * 2 + qt], oacc[dt][qt], 0, 0, 0);
       }
   }
+  if (partial != nullptr) {
+    float* dst = partial + tid * 4;
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    // a query's keys are spread over the four lane groups: lanes l15, l15 + 16, + 32, + 48
-    float l_tot = l_run[qt];
-    l_tot += __shfl_xor(l_tot, 16);
-    l_tot += __shfl_xor(l_tot, 32);
-    const float inv = 1.0f / l_tot;
-    const int q_row = qb * 256 + w * 32 + qt * 16 + l15;
-    if (q_row < S) {
-      bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * g;
+    for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        u32x2 v;
-        v[0] = pack2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
-        v[1] = pack2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
-        *(u32x2*)(orow + dt * 16) = v;
-      }
-    }
+      for (int qt = 0; qt < 2; ++qt) *(f32x4*)(dst + (dt * 2 + qt) * 2048) = oacc[dt][qt];
+    partial[16 * 2048 + tid] = l_run[0];
+    partial[16 * 2048 + 512 + tid] = l_run[1];
+    return;
   }
+  attn5_finish(p, oacc, l_run, lane, w, head, qb);
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  attn5_body<true>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
+}
+
+// Split launch (rf_attention_fwd_ws with scratch): 432 workgroups at S = 4608 are 1.69 rounds of 256 CUs run as 2, 528 at
+// S = 5632 are 2.06 run as 3.  One persistent workgroup per CU takes an equal share of the (block, 4-tile quad) space
+// instead -- at most one piece at the head and one at the tail of its range are partial blocks, which go to its two
+// scratch slots.  XCD x (workgroups x, x + 8, ...) keeps the heads h % 8 == x, as the one-block-per-workgroup launch does
+// (its block b runs on XCD b % 8 = head % 8 when heads % 8 == 0): a head's K / VT stay in one L2.
+struct AttnSkParams {
+  int nq;        // quads (4 key tiles) per block
+  int nqb;       // 256-query blocks
+  int hpx;       // heads per XCD (heads / 8)
+  int wpx;       // workgroups per XCD
+  float* ws;     // [workgroup][2] slots of ATT5_SLOT floats
+};
+constexpr int ATT5_SLOT = 16 * 2048 + 1024;
+
+__device__ __forceinline__ int att5_start(const AttnSkParams& sk, const int wl) {   // first quad of XCD-local workgroup wl
+  return (int)((int64_t)wl * (sk.hpx * sk.nqb * sk.nq) / sk.wpx);
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_kernel_v5sk(const AttnParams p, const AttnSkParams sk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = blockIdx.x & 7, wl = blockIdx.x >> 3;
+  const int start = att5_start(sk, wl), end = att5_start(sk, wl + 1);
+  bool first = true;
+  for (int cur = start; cur < end;) {
+    const int lu = cur / sk.nq, q0 = cur - lu * sk.nq;
+    const int len = min(sk.nq - q0, end - cur);
+    const int head = x + 8 * (lu / sk.nqb), qb = lu % sk.nqb;
+    float* partial = (q0 == 0 && len == sk.nq) ? nullptr : sk.ws + (int64_t)(2 * blockIdx.x + (cur == start ? 0 : 1)) * ATT5_SLOT;
+    if (!first) __builtin_amdgcn_s_barrier();   // every wave is done with the previous piece's rings
+    first = false;
+    // launder the thread id once per piece: keeps the per-lane address math inside the piece (LICM would hoist it
+    // across the loop and spill)
+    int tid_i = tid;
+    asm volatile("" : "+v"(tid_i));
+    attn5_body<false>(p, smem, tid_i, tid_i & 63, w, head, qb, 4 * q0, 4 * len, partial, clk);
+    cur += len;
+  }
+}
+
+// one workgroup per (head, query block): nothing to do if one piece covered it, else add its pieces' slots and finish
+__global__ __launch_bounds__(512) void attn5_combine_kernel(const AttnParams p, const AttnSkParams sk) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.x % p.heads, qb = blockIdx.x / p.heads;
+  const int x = head & 7, lu = (head >> 3) * sk.nqb + qb;
+  const int u0 = lu * sk.nq, u1 = u0 + sk.nq;
+  // the XCD-local workgroup whose range holds quad u0
+  int wl = (int)(((int64_t)u0 * sk.wpx) / (sk.hpx * sk.nqb * sk.nq));
+  while (wl > 0 && att5_start(sk, wl) > u0) --wl;
+  while (att5_start(sk, wl + 1) <= u0) ++wl;
+  if (att5_start(sk, wl + 1) >= u1) return;   // one workgroup held the whole block: it stored the rows itself
+  f32x4 oacc[8][2];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][qt][r] = 0.f;
+  float l_run[2] = {0.f, 0.f};
+  for (; att5_start(sk, wl) < u1; ++wl) {
+    const int s0 = att5_start(sk, wl);
+    const int piece_begin = s0 > u0 ? s0 : u0;
+    const float* src = sk.ws + (int64_t)(2 * (wl * 8 + x) + (piece_begin == s0 ? 0 : 1)) * ATT5_SLOT;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] += *(const f32x4*)(src + (dt * 2 + qt) * 2048 + tid * 4);
+    l_run[0] += src[16 * 2048 + tid];
+    l_run[1] += src[16 * 2048 + 512 + tid];
+  }
+  attn5_finish(p, oacc, l_run, lane, w, head, qb);
 }
 
 int read_clk_probe_attn(unsigned long long* h) {
@@ -950,6 +1054,8 @@ int read_clk_probe_attn(unsigned long long* h) {
 static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)
 static int g_attn_v4 = 1;   // 1 = launches with a proven score bound that qualify for v2's plain instantiation run v4 / v5, 0 = never
 static int g_attn_v5 = 1;   // 1 = the bounded-score kernel on 16x16x32 MFMAs (v5), 0 = on 32x32x16 (v4)
+static int g_attn_sk = -1;  // split launch of v5: -1 = heuristic, 0 = never, 1 = whenever possible
+static int g_last_attn_path = 0;
 
 }  // namespace rf
 
@@ -968,9 +1074,29 @@ extern "C" int rf_debug_attn_v4(int on) {  // tuning / test hook: allow (1) or f
   return RF_OK;
 }
 
+extern "C" int rf_debug_attn_sk(int mode) {  // split launch of the bounded-score kernel: -1 = heuristic, 0 = never, 1 = whenever possible
+  rf::g_attn_sk = mode < 0 ? -1 : (mode ? 1 : 0);
+  return RF_OK;
+}
+extern "C" int rf_debug_last_attn_path(void) { return rf::g_last_attn_path; }   // 1 / 2 / 4 / 5 = kernel version, 6 = v5 split launch
+
+extern "C" int64_t rf_attention_ws_bytes(void) {
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  return (int64_t)2 * (cus / 8 * 8) * rf::ATT5_SLOT * 4;
+}
+
 extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                                 int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
                                 float cross_bias, float scale, int32_t q_prescaled, float score_bound, void* stream) {
+  return rf_attention_fwd_ws(q, k, vt, out, heads, S, s_pad, ldo, n_main, mode, cross_bias, scale, q_prescaled, score_bound,
+                             nullptr, 0, stream);
+}
+
+extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt, void* out, int32_t heads,
+                                   int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
+                                   float cross_bias, float scale, int32_t q_prescaled, float score_bound,
+                                   void* ws, int64_t ws_bytes, void* stream) {
   using namespace rf;
   RF_REQUIRE(q && k && vt && out, RF_ERR_NULL, "rf_attention_fwd: NULL pointer");
   RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0, RF_ERR_SHAPE,
@@ -992,6 +1118,7 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v4, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     attr_set = true;
   }
   AttnParams p;
@@ -1013,13 +1140,44 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
   hipStream_t st = (hipStream_t)stream;
   const bool pre = q_prescaled != 0;
   ProfScope prof(RF_KC_ATTN, 4.0 * (double)S * (double)S * 128.0 * heads, st);
+  // the bounded-score kernel is 25-45 % faster than either online-softmax kernel wherever it applies (profiles/r02_kb_attn*.log)
+  const bool bounded = mode == 0 && S % 256 == 0 && pre && g_attn_v4 && score_bound > 0.f && score_bound <= 100.f;
+  if (bounded && g_attn_v2 != 0) use_v2 = true;
   if (use_v2) {
     const dim3 grid2(heads * cdiv(S, 256)), blk(512);
     const bool generic = !(mode == 0 && S % 64 == 0);
-    if (!generic && S % 256 == 0 && pre && g_attn_v4 && score_bound > 0.f && score_bound <= 100.f) {
-      if (g_attn_v5) hipLaunchKernelGGL(attn_fwd_kernel_v5, grid2, blk, ATT4_LDS, st, p);
-      else hipLaunchKernelGGL(attn_fwd_kernel_v4, grid2, blk, ATT4_LDS, st, p);
-    } else if (generic) {
+    if (bounded) {
+      // split launch: one persistent workgroup per CU over equal shares of the (block, key quad) space when the plain grid
+      // fills less than 80 % of its rounds.  Measured (profiles/r02_kb_attn_split.log): S = 5632 (528 blocks = 2.06 rounds
+      // run as 3, 69 %) 399 -> 328 us; S = 4608 (1.69 as 2, 84 %) break-even -- the part is power-limited, idle CUs in the
+      // last round let the busy ones clock higher; S = 17920 (6.56 as 7, 94 %) 8 % slower.
+      static int num_cus = 0;
+      if (num_cus == 0) {
+        int dev = 0;
+        RF_CHECK_HIP(hipGetDevice(&dev));
+        RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+      }
+      const int P = num_cus / 8 * 8, blocks = heads * (S / 256), rounds = cdiv(blocks, P);
+      AttnSkParams sk;
+      sk.nq = S / 256; sk.nqb = S / 256; sk.hpx = heads / 8; sk.wpx = P / 8; sk.ws = (float*)ws;
+      const bool can_split = g_attn_v5 && g_attn_sk != 0 && heads % 8 == 0 && P >= 8 && ws != nullptr && aligned16(ws) &&
+                             ws_bytes >= (int64_t)2 * P * ATT5_SLOT * 4 && (int64_t)sk.hpx * sk.nqb * sk.nq >= 2 * sk.wpx;
+      if (can_split && (g_attn_sk == 1 || (double)blocks / ((double)rounds * P) < 0.80)) {
+        hipLaunchKernelGGL(attn_fwd_kernel_v5sk, dim3(P), blk, ATT4_LDS, st, p, sk);
+        hipLaunchKernelGGL(attn5_combine_kernel, grid2, blk, 0, st, p, sk);
+        g_last_attn_path = 6;
+      } else if (g_attn_v5) {
+        hipLaunchKernelGGL(attn_fwd_kernel_v5, grid2, blk, ATT4_LDS, st, p);
+        g_last_attn_path = 5;
+      } else {
+        hipLaunchKernelGGL(attn_fwd_kernel_v4, grid2, blk, ATT4_LDS, st, p);
+        g_last_attn_path = 4;
+      }
+      RF_LAUNCH_CHECK();
+      return RF_OK;
+    }
+    g_last_attn_path = 2;
+    if (generic) {
       if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<true, true>), grid2, blk, ATT2_LDS, st, p);
       else hipLaunchKernelGGL((attn_fwd_kernel_v2<true, false>), grid2, blk, ATT2_LDS, st, p);
     } else {
@@ -1027,6 +1185,7 @@ extern "C" int rf_attention_fwd(const void* q, const void* k, const void* vt, vo
       else hipLaunchKernelGGL((attn_fwd_kernel_v2<false, false>), grid2, blk, ATT2_LDS, st, p);
     }
   } else {
+    g_last_attn_path = 1;
     const dim3 grid1(heads * p.nqb), blk(256);
     if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid1, blk, 2 * ATT_STAGE, st, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid1, blk, 2 * ATT_STAGE, st, p);

@@ -48,7 +48,8 @@ static WsLayout ws_layout(const rf_flux_dims& d) {
   L.x = take(SD);
   // GEMM scratch: 4 KiB of stream-K flags (must be zero before the first launch; every launch restores them),
   // then fp32 partial tiles: one 256x256 slot per CU for stream-K (64 MiB at 256 CUs), reused by the LoRA split-K
-  L.sk_bytes = 4096 + (64ll << 20);
+  // (attention's split launch borrows it too: 2 x 256 slots of 132 KiB = 66 MiB; the kernels run one after the other)
+  L.sk_bytes = 4096 + (68ll << 20);
   L.sk = take(L.sk_bytes / 2);
   L.xn8 = L.a8 = L.s_xn = L.s_a = 0;
   if (d.fp8) {
@@ -233,8 +234,9 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
   }
   // 3. per-head RMSNorm(q,k) (text rows: norm_added_*) + RoPE: fused into the QKV epilogue above
   // 4. joint attention
-  RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, St + Si, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
-                          0.08838834764831845f /* 1/sqrt(128) */, /*q_prescaled=*/1, w->qk_bound, st));
+  RF_TRY(rf_attention_fwd_ws(Q, K, VT, ATT, H, S, L.s_pad, D, St + Si, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
+                             0.08838834764831845f /* 1/sqrt(128) */, /*q_prescaled=*/1, w->qk_bound,
+                             (char*)ws->base + L.sk + 4096, L.sk_bytes - 4096, st));
   // 5. output projections + gated residual: x += gate_msa * proj(attn)
   {
     RF_TRY(quant_rows(ATT, D));
@@ -415,8 +417,9 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
   }
   // 3. RMSNorm(q,k) + RoPE: fused into the epilogue above (no added-norm rows in single blocks)
   // 4. attention
-  RF_TRY(rf_attention_fwd(Q, K, VT, ATT, H, S, L.s_pad, D, Sm, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
-                          0.08838834764831845f, /*q_prescaled=*/1, w->qk_bound, st));
+  RF_TRY(rf_attention_fwd_ws(Q, K, VT, ATT, H, S, L.s_pad, D, Sm, Sc > 0 ? dims->attn_mode : 0, dims->cross_bias,
+                             0.08838834764831845f, /*q_prescaled=*/1, w->qk_bound,
+                             (char*)ws->base + L.sk + 4096, L.sk_bytes - 4096, st));
   // 5. proj_out over cat([attn, mlp]) + gated residual.  bf16: two K segments, no concat.  fp8: the per-token
   //    quantisation writes [attn | mlp] side by side with ONE row scale, so it is a single K = D + mlp segment.
   {

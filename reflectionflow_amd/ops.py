@@ -248,6 +248,17 @@ def splitk_scratch(device) -> torch.Tensor:
     return _SPLITK[key]
 
 
+_ATTN_WS = {}
+
+
+def attn_scratch(device) -> torch.Tensor:
+    """Per-(device, stream) scratch of rf_attention_fwd_ws (partial (O, l) of split query blocks)."""
+    key = (torch.device(device).index, stream_ptr())
+    if key not in _ATTN_WS:
+        _ATTN_WS[key] = torch.empty(L.load().rf_attention_ws_bytes() // 4, dtype=torch.float32, device=device)
+    return _ATTN_WS[key]
+
+
 def lora_down(x: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
     """T = x . lora_A^T  ([M, r_pad]); few output tiles and a long K, so it runs split-K."""
     return linear(x, A)
@@ -289,7 +300,9 @@ def qk_score_bound(*norm_weights_qk) -> float:
 
 def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
               cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False,
-              score_bound: float = 0.0) -> torch.Tensor:
+              score_bound: float = 0.0, scratch: bool = True) -> torch.Tensor:
+    """scratch=True attaches the per-(device, stream) scratch that lets the library split a poorly filling grid
+    (rf_attention_fwd_ws); scratch=False is rf_attention_fwd."""
     lib = L.load()
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     heads, s_pad = q.shape[0], q.shape[1]
@@ -298,9 +311,11 @@ def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Opti
     _rows2d(out, "out")
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
-    L.check(lib.rf_attention_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), heads, S, s_pad,
-                                 out.stride(0), S if n_main is None else n_main, mode, cross_bias, scale,
-                                 1 if q_prescaled else 0, float(score_bound), stream_ptr()), "rf_attention_fwd")
+    ws = attn_scratch(q.device) if scratch else None
+    L.check(lib.rf_attention_fwd_ws(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), heads, S, s_pad,
+                                    out.stride(0), S if n_main is None else n_main, mode, cross_bias, scale,
+                                    1 if q_prescaled else 0, float(score_bound), ptr(ws), ws.numel() * 4 if ws is not None else 0,
+                                    stream_ptr()), "rf_attention_fwd_ws")
     return out
 
 

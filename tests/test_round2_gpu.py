@@ -210,6 +210,32 @@ def test_attention_bounded_score_kernel(dev, S, H):
     assert e4 <= 1.5 * e2 + 1e-4
 
 
+@pytest.mark.parametrize("S,H", [(2048, 8), (4608, 8), (5632, 24)])
+def test_attention_split_launch_and_mfma_shapes(dev, S, H):
+    """The bounded-score kernel three ways on the same operands: 16x16x32 MFMAs one workgroup per (head, query block)
+    [path 5], the same as ONE persistent workgroup per CU over equal shares of the (block, key range) space with partial
+    (O, l) added by a second launch [path 6: rf_attention_fwd_ws + scratch, forced], and the 32x32x16 form [path 4] -- all
+    against fp32 SDPA, and the split launch bit-stable run to run."""
+    from reflectionflow_amd import _lib, ops
+    q, k, vt, ref, bound = _prescaled_case(H, S, dev, seed=S + H)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for name, v5, sk, path in (("plain", 1, 0, 5), ("split", 1, 1, 6), ("split again", 1, 1, 6), ("32x32x16", 0, 0, 4)):
+            lib.rf_debug_attn_v2(1); lib.rf_debug_attn_v5(v5); lib.rf_debug_attn_sk(sk)
+            outs[name] = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
+            assert lib.rf_debug_last_attn_path() == path, (name, lib.rf_debug_last_attn_path())
+        lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(1)
+        ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
+        assert lib.rf_debug_last_attn_path() == 5, "without scratch the library must not split"
+    finally:
+        lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1)
+    for name, o in outs.items():
+        assert_close(o, ref, f"attention {name} S={S}", atol=2e-3)
+    assert torch.equal(outs["split"], outs["split again"]), "the split launch is not bit-stable"
+    assert (outs["split"].float() - outs["plain"].float()).abs().max() < 2e-3
+
+
 def test_attention_bounded_score_extremes(dev):
     """The shift-free softmax at the edges of its contract: scores near +bound and near -bound in the same rows
     (|s| up to ~60 in the exp2 domain: P spans 2^-60 .. 2^60), and rows whose scores are ALL very negative."""
