@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void gemm_mainloop_pp2(const GemmGroupDev& G, const i
 // all: the chip settles at 1.89 vs 2.13 GHz) -- the small shape reads and writes half the accumulator bytes per MAC.  Fragment
 // counts per phase, LDS image, staging and barriers are unchanged (a 32-row A half = 2 row tiles x 2 k-steps = 4 fragments,
 // a 64-column W half = 4 x 2 = 8); only the lane -> (row, chunk) map of a fragment read and the accumulator layout differ.
-template <bool W8 = false>
+template <bool W8 = false, int KNOCK = 0>   // KNOCK (timing diagnostics, wrong results): 1 = no DMA in the loop, 2 = no fragment reads
 __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                   const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
   constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
@@ -1132,12 +1132,14 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
   auto frag_coff = [&](int ks) { return ((ks * 4 + (lane >> 4)) ^ swz) << 4; };
   // A half: fragments [rt*2 + ks] (2 row tiles x 2 k-steps); W half: [ct*2 + ks] (4 column tiles x 2 k-steps)
   auto rdA = [&](bf16x8 (&dst)[4], const char* half) {
+    if (KNOCK & 2) return;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) dst[rt * 2 + ks] = *(const bf16x8*)(half + a_off + rt * 2048 + frag_coff(ks));
   };
   auto rdB = [&](bf16x8 (&dst)[8], const char* half) {
+    if (KNOCK & 2) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)      // k-step 0 of all four column tiles first: the phase's first MFMAs need those
 #pragma unroll
@@ -1207,7 +1209,7 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
   auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
     const char* base = smem + (t & 1) * BUF;
     const char* nbase = smem + ((t + 1) & 1) * BUF;
-    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    const bool more1 = !(KNOCK & 1) && t + 1 < nk, more2 = !(KNOCK & 1) && t + 2 < nk;
     // ---- p0: 8 reads ---------------------------------------------------------------------
     rdB(bq, base);
     RF_PP2_BAR();
@@ -1568,6 +1570,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) 
   tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  if constexpr (VAR >= 7) {   // the shipped 16x16x32 loop, whole (7) or knocked out (8: no DMA, 9: no reads, 10: neither)
+    f32x4 acc16[4][8];
+    gemm_mainloop_pp2_m16<false, VAR - 7>(G, p.N, m0, n0, 0, nk, acc16, smem, w, lane);
+    clk.end(g_clk_probe);
+    __syncthreads();
+    gemm_epilogue_lds16<2, false>(p, G, acc16, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+    return;
+  }
   f32x16 acc[2][4];
   if constexpr (VAR == 5) gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
   else if constexpr (VAR == 6) gemm_mainloop_pp3<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
@@ -2008,6 +2018,10 @@ static int launch_gemm_ppx(GemmParams& p, hipStream_t stream) {
     case 4: return launch_gemm_ppx_v<4>(p, stream);
     case 5: return launch_gemm_ppx_v<5>(p, stream);
     case 6: return launch_gemm_ppx_v<6>(p, stream);
+    case 7: return launch_gemm_ppx_v<7>(p, stream);
+    case 8: return launch_gemm_ppx_v<8>(p, stream);
+    case 9: return launch_gemm_ppx_v<9>(p, stream);
+    case 10: return launch_gemm_ppx_v<10>(p, stream);
     default: return launch_gemm_ppx_v<0>(p, stream);
   }
 }

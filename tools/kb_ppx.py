@@ -6,7 +6,8 @@ from reflectionflow_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-NAMES = {0: "production", 1: "reads first", 2: "no DMA", 3: "no reads", 4: "MFMA+barriers"}
+NAMES = {0: "round-1 loop", 1: "reads first", 2: "no DMA", 3: "no reads", 4: "MFMA+barriers", 5: "balanced 32x32", 6: "even 32x32",
+         7: "shipped 16x16x32", 8: "16x16 no DMA", 9: "16x16 no reads", 10: "16x16 MFMA+barriers"}
 if len(sys.argv) > 1:
     NAMES = {int(k): NAMES.get(int(k), f"var{k}") for k in sys.argv[1].split(",")}
 for (M, N, K) in ((4608, 3072, 12288), (4608, 9216, 3072)):
@@ -17,7 +18,7 @@ for (M, N, K) in ((4608, 3072, 12288), (4608, 9216, 3072)):
     ref = a.float() @ w.float().t()
     lib.rf_debug_force_gemm_tile(259)
     for k in NAMES:
-        if k in (2, 3, 4):
+        if k in (2, 3, 4, 8, 9, 10):
             continue
         lib.rf_debug_gemm_w4_knock(k)
         ops.gemm(g, N, splitk_ws=False)
