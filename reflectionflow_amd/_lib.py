@@ -124,7 +124,7 @@ RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quan
 # test / tuning hook, not part of the declared drop-in surface
 _EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
                "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
-               "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_last_attn_path": (C.c_int, []),
+               "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_attn_knock": (C.c_int, [C.c_int]), "rf_debug_attn_v6": (C.c_int, [C.c_int]), "rf_debug_last_attn_path": (C.c_int, []),
                "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
                "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]),

@@ -751,7 +751,7 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
 // this key range in the 132 KiB slot `partial` ([16 quads][512 threads] x 16 B, then [2][512] floats), thread-linear:
 // attn5_combine_kernel adds the slots of a block's pieces thread by thread and finishes it -- with no running maximum the
 // partial sums of disjoint key ranges simply add.
-template <bool PROBE>
+template <bool PROBE, int KNOCK = 0>   // KNOCK (timing diagnostics, wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing
 __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
                                            const int head, const int qb, const int t0, const int nt, float* partial, ClkProbe& clk) {
   const int l15 = lane & 15, g = lane >> 4;
@@ -857,6 +857,9 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     // fragment pair of group G: G < 8 -> V^T(t-1) [d tile G, key blocks 0, 1], else K(t+1) [(b, T) = (G-8)/2, d steps ((G-8)%2)*2 + 0, 1]
     auto load_group = [&](auto gtag) {
       constexpr int G = decltype(gtag)::value;
+      if constexpr (KNOCK & 1) {
+        if (t > 0) return;
+      }
       if constexpr (G < 8) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) fr[G & 1][e] = *(const bf16x8*)(v_rd[e] + VSLOT * 16384 + G * 16 * 128);
@@ -877,7 +880,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           oacc[G][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][b], pf[b * 2 + qt], oacc[G][qt], 0, 0, 0);
-      {
+      if constexpr (!(KNOCK & 2)) {
         float e4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) e4[j] = __builtin_amdgcn_exp2f(s_cur[G][j]);
@@ -910,7 +913,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
           s_nxt[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][e], qf[qt][dsb + e], s_nxt[bt * 2 + qt], 0, 0, 0);
-      {
+      if constexpr (!(KNOCK & 2)) {
         constexpr int ti = G - 8;                       // score tile (b, T, qt) = (ti >> 2, (ti >> 1) & 1, ti & 1)
         uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
         uint32_t w1 = pack2(s_cur[ti][2], s_cur[ti][3]);
@@ -960,6 +963,16 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   attn5_finish(p, oacc, l_run, lane, w, head, qb);
 }
 
+template <int KNOCK>
+__global__ __launch_bounds__(512) void attn_fwd_kernel_v5k(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  attn5_body<true, KNOCK>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
+}
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
@@ -968,6 +981,276 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   attn5_body<true>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
+}
+
+// =================================================================================================
+// v6 -- the bounded-score kernel with ONE wave per SIMD: 4 waves x 64 queries.  Knock-outs of v5 (tools/kb_attn_knock.py)
+// show its fragment reads cost 900 of its 3050 clocks per key tile: eight waves each read the whole K and VT tile, 256 KiB
+// per tile and CU = 2048 cycles of the 128 B/clk LDS, as long as the tile's MFMAs.  A wave that owns 64 queries (four
+// q-tiles) uses every K / VT fragment for four MFMAs instead of two: half the LDS traffic per flop.  Its 128 O^T + 2 x 64
+// score + 64 Q + 32 P registers need the 512-register budget of a single wave per SIMD, which hides nothing -- so, with the
+// lessons of the one-wave-per-SIMD GEMM (profiles/r02_gemm_power.md section 6): a group is four MFMAs on ONE fragment
+// read a group ahead into a double buffer; the tile's eight LDS-DMA pieces per wave go out one per four groups, wave w in
+// the groups G % 4 == w (the loop is specialised per wave, so the slot is straight-line code); exp2 / sums / packing ride
+// between the MFMAs as in v5.  Rings, layouts, swizzles, the key-row permutation and the output are v5's.
+// RESULT: bit-identical to v5, at 2.2-2.35 GHz instead of 2.0 (less LDS power), and 12-20 % slower: ~4050 clocks per key
+// tile for 2048 of MFMA.  A deeper fragment read-ahead changes nothing; what a lone wave cannot hide is its own VALU stream
+// (64 exp2 + 64 add + 64 accumulator reads + 32 cvt per tile): a 16-cycle MFMA leaves a 12-cycle issue shadow, a
+// transcendental does not fit in it, and there is no second wave to take the matrix pipe meanwhile.  Kept as an experiment
+// (rf_debug_attn_v6(1)); v5 ships.
+#define RF_ATT6_WAIT_BARRIER(allowed)                                            \
+  do {                                                                           \
+    if ((allowed) >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         \
+    else if ((allowed) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
+    __builtin_amdgcn_s_barrier();                                                \
+  } while (0)
+
+template <int WV>
+__device__ __forceinline__ void attn6_body(const AttnParams& p, char* smem, const int lane, const int head, const int qb, ClkProbe& clk) {
+  constexpr int w = WV;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int S = p.S;
+  const int nt = S / ATT_KV;
+  const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
+  const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
+  const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
+  char* const kring = smem;
+  char* const vring = smem + ATT4_RING * 16384;
+
+  bf16x8 qf[4][4];   // [q tile][d step of 32]: query w*64 + qt*16 + l15, d = 32 ds + 8g .. +8
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int q_row = qb * 256 + w * 64 + qt * 16 + l15;
+    const bf16_t* qp = p.q + ((int64_t)head * p.s_pad + (q_row < S ? q_row : S - 1)) * 128 + g * 8;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *(const bf16x8*)(qp + ds * 32);
+  }
+  // DMA pieces: 4 of the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each) per wave
+  uint32_t k_src[4], v_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + w) * 4 + (lane >> 4);
+    const int ksw = (row & 7) | ((row >> 1) & 8);
+    k_src[i] = (uint32_t)(row * 256 + (((lane & 15) ^ ksw) * 16));
+    const int vrow = (i * 4 + w) * 8 + (lane >> 3);
+    v_src[i] = (uint32_t)((vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
+  }
+  auto k_piece = [&](int i, int t, int slot) {
+    RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 4 + w) * 1024), k_src[i], t * (ATT_KV * 256));
+  };
+  auto v_piece = [&](int i, int t, int slot) {
+    RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 4 + w) * 1024), v_src[i], t * (128 * 64 * 2));
+  };
+  const char* k_rd[4];
+  const char* v_rd[2];
+  const int krow = (l15 & 7) | ((l15 & 8) << 1);
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) k_rd[ds] = kring + krow * 256 + (((ds * 4 + g) ^ l15) << 4);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) v_rd[b] = vring + l15 * 128 + (((b * 4 + g) ^ ((l15 >> 1) & 7)) << 4);
+
+  f32x4 oacc[8][4];   // O^T tiles [d tile][q tile]
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[dt][qt][r] = 0.f;
+  float l_run[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s_cur[16], s_nxt[16];   // score tiles, index ti = bt*4 + qt with bt = b*2 + T
+  bf16x8 pf[8];                  // P(t-1) B-operand fragments [b*4 + qt]: words T*2, T*2+1 from tile (b*2 + T, qt)
+
+  {  // V ring slot 3 stands in for V(-1): tile 0 multiplies it with P(-1) = 0, so it must be finite
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(u32x4*)(vring + 3 * 16384 + (i * 4 + w) * 1024 + lane * 16) = z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[i][j] = (bf16_t)0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) k_piece(i, 0, 0);
+  if (nt > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k_piece(i, 1, 1);
+  }
+  if (nt > 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k_piece(i, 2, 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v_piece(i, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill above
+  {
+    const int allowed = 4 * ((nt > 1) + (nt > 2) + 1);   // K0 landed
+    if (allowed == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (allowed == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int bt = 0; bt < 4; ++bt) {   // (b, T) = (bt >> 1, bt & 1)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_cur[bt * 4 + qt][r] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) s_cur[bt * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * 4 + qt], 0, 0, 0);
+    }
+  }
+
+  auto tile = [&](const int t, auto ts_tag) {
+    constexpr int TS = decltype(ts_tag)::value;
+    constexpr int KSLOT = (TS + 1) % 4, VSLOT = (TS + 3) % 4;
+    // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t) (4 pieces each)
+    RF_ATT6_WAIT_BARRIER(4 * ((t + 2 < nt) + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const bool k_more = t + 3 < nt, v_more = t + 1 < nt;
+    bf16x8 fr[4];   // fragment ring: group G multiplies fr[G & 3], read RA = 3 groups (192 MFMA cycles) earlier -- a lone wave
+                    // per SIMD has nobody to cover an LDS round trip
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};
+    // fragment of group G: G < 16 -> V^T(t-1) [d tile G/2, key block G%2], else K(t+1) [(b, T) = (G-16)/4, d step (G-16)%4]
+    auto load_group = [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value;
+      if constexpr (G < 16) {
+        fr[G & 3] = *(const bf16x8*)(v_rd[G & 1] + VSLOT * 16384 + (G >> 1) * 16 * 128);
+      } else if constexpr (G < 32) {
+        constexpr int bt = (G - 16) >> 2;
+        fr[G & 3] = *(const bf16x8*)(k_rd[(G - 16) & 3] + KSLOT * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+      }
+    };
+    // this wave's DMA slot: groups G % 4 == WV carry piece G / 4 of the tile's eight (K(t+3) x 4, then V(t+1) x 4)
+    auto dma_slot = [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value;
+      if constexpr ((G & 3) == WV) {
+        constexpr int j = G >> 2;
+        if constexpr (j < 4) {
+          if (__builtin_expect(k_more, 1)) k_piece(j, t + 3, (TS + 3) % 4);
+        } else {
+          if (__builtin_expect(v_more, 1)) v_piece(j - 4, t + 1, KSLOT);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    load_group(std::integral_constant<int, 0>{});
+    load_group(std::integral_constant<int, 1>{});
+    load_group(std::integral_constant<int, 2>{});
+    // ---- first half: pending PV product (16 groups: d tile G/2, key block G%2) | P = exp2(S tile G) + row sums ----
+    static_for(std::make_integer_sequence<int, 16>{}, [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value;
+      load_group(std::integral_constant<int, G + 3>{});
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+        oacc[G >> 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 3], pf[(G & 1) * 4 + qt], oacc[G >> 1][qt], 0, 0, 0);
+      {
+        float e4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e4[j] = __builtin_amdgcn_exp2f(s_cur[G][j]);
+        RF_PIN4(e4[0], e4[1], e4[2], e4[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s_cur[G][j] = e4[j];
+          psum[G & 3] += e4[j];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dma_slot(gtag);
+    });
+    asm volatile("" : "+v"(psum[0]), "+v"(psum[1]), "+v"(psum[2]), "+v"(psum[3]));
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) l_run[qt] += psum[qt];
+    // ---- second half: next tile's scores (16 groups: (b, T) = k/4, d step k%4) | pack P tile k into the PV operand ----
+    static_for(std::make_integer_sequence<int, 16>{}, [&](auto gtag) {
+      constexpr int G = decltype(gtag)::value + 16;
+      load_group(std::integral_constant<int, G + 3>{});
+      constexpr int bt = (G - 16) >> 2;
+      constexpr int ds = (G - 16) & 3;
+      if constexpr (ds == 0) {
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_nxt[bt * 4 + qt][r] = 0.f;
+      }
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+        s_nxt[bt * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 3], qf[qt][ds], s_nxt[bt * 4 + qt], 0, 0, 0);
+      {
+        constexpr int ti = G - 16;                      // score tile (bt, qt) = (ti >> 2, ti & 3)
+        uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
+        uint32_t w1 = pack2(s_cur[ti][2], s_cur[ti][3]);
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        constexpr int pi = ((ti >> 2) >> 1) * 4 + (ti & 3), wi = ((ti >> 2) & 1) * 2;
+        u32x4 t4 = __builtin_bit_cast(u32x4, pf[pi]);
+        t4[wi] = w0;
+        t4[wi + 1] = w1;
+        pf[pi] = __builtin_bit_cast(bf16x8, t4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      dma_slot(std::integral_constant<int, G>{});
+    });
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_cur[i] = s_nxt[i];
+  };
+  for (int t = 0; t < nt; t += 4) {   // unrolled by the ring size (dispatch guarantees nt % 4 == 0): one exit
+    tile(t, std::integral_constant<int, 0>{});
+    tile(t + 1, std::integral_constant<int, 1>{});
+    tile(t + 2, std::integral_constant<int, 2>{});
+    tile(t + 3, std::integral_constant<int, 3>{});
+  }
+
+  clk.end(g_attn_clk_probe);
+  // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
+  RF_ATT6_WAIT_BARRIER(0);
+  {
+    const int vslot = (nt - 1) % ATT4_RING;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 vf = *(const bf16x8*)(v_rd[b] + vslot * 16384 + dt * 16 * 128);
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * 4 + qt], oacc[dt][qt], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    float l_tot = l_run[qt];
+    l_tot += __shfl_xor(l_tot, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    const float inv = 1.0f / l_tot;
+    const int q_row = qb * 256 + w * 64 + qt * 16 + l15;
+    if (q_row < S) {
+      bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u32x2 v;
+        v[0] = pack2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
+        v[1] = pack2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
+        *(u32x2*)(orow + dt * 16) = v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel_v6(const AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.x % p.heads, qb = blockIdx.x / p.heads;
+  switch (w) {   // one specialisation per wave: its DMA slots are straight-line code
+    case 0: attn6_body<0>(p, smem, lane, head, qb, clk); break;
+    case 1: attn6_body<1>(p, smem, lane, head, qb, clk); break;
+    case 2: attn6_body<2>(p, smem, lane, head, qb, clk); break;
+    default: attn6_body<3>(p, smem, lane, head, qb, clk); break;
+  }
 }
 
 // Split launch (rf_attention_fwd_ws with scratch): 432 workgroups at S = 4608 are 1.69 rounds of 256 CUs run as 2, 528 at
@@ -1054,6 +1337,9 @@ int read_clk_probe_attn(unsigned long long* h) {
 static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)
 static int g_attn_v4 = 1;   // 1 = launches with a proven score bound that qualify for v2's plain instantiation run v4 / v5, 0 = never
 static int g_attn_v5 = 1;   // 1 = the bounded-score kernel on 16x16x32 MFMAs (v5), 0 = on 32x32x16 (v4)
+static int g_attn_v6 = 0;    // 1 = plain-grid launches of the bounded-score kernel use the one-wave-per-SIMD form (v6): an experiment,
+                             // bit-identical to v5 and 12-20 % SLOWER (profiles/r02_kb_attn_v6.log) -- see attn6_body
+static int g_attn_knock = 0; // timing diagnostics (rf_debug_attn_knock): 1 = no fragment reads, 2 = no softmax VALU, 3 = both
 static int g_attn_sk = -1;  // split launch of v5: -1 = heuristic, 0 = never, 1 = whenever possible
 static int g_last_attn_path = 0;
 
@@ -1074,6 +1360,8 @@ extern "C" int rf_debug_attn_v4(int on) {  // tuning / test hook: allow (1) or f
   return RF_OK;
 }
 
+extern "C" int rf_debug_attn_v6(int on) { rf::g_attn_v6 = on ? 1 : 0; return RF_OK; }   // A/B hook: one wave per SIMD (v6) vs two (v5)
+extern "C" int rf_debug_attn_knock(int k) { rf::g_attn_knock = k; return RF_OK; }   // timing diagnostics only (wrong results)
 extern "C" int rf_debug_attn_sk(int mode) {  // split launch of the bounded-score kernel: -1 = heuristic, 0 = never, 1 = whenever possible
   rf::g_attn_sk = mode < 0 ? -1 : (mode ? 1 : 0);
   return RF_OK;
@@ -1119,6 +1407,10 @@ extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt,
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v4, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v6, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     attr_set = true;
   }
   AttnParams p;
@@ -1166,6 +1458,14 @@ extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt,
         hipLaunchKernelGGL(attn_fwd_kernel_v5sk, dim3(P), blk, ATT4_LDS, st, p, sk);
         hipLaunchKernelGGL(attn5_combine_kernel, grid2, blk, 0, st, p, sk);
         g_last_attn_path = 6;
+      } else if (g_attn_v5 && g_attn_v6 && !g_attn_knock) {
+        hipLaunchKernelGGL(attn_fwd_kernel_v6, grid2, dim3(256), ATT4_LDS, st, p);
+        g_last_attn_path = 7;
+      } else if (g_attn_v5 && g_attn_knock) {
+        if (g_attn_knock == 1) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_attn_knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
+        else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
+        g_last_attn_path = 5;
       } else if (g_attn_v5) {
         hipLaunchKernelGGL(attn_fwd_kernel_v5, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;

@@ -214,22 +214,24 @@ def test_attention_bounded_score_kernel(dev, S, H):
 def test_attention_split_launch_and_mfma_shapes(dev, S, H):
     """The bounded-score kernel three ways on the same operands: 16x16x32 MFMAs one workgroup per (head, query block)
     [path 5], the same as ONE persistent workgroup per CU over equal shares of the (block, key range) space with partial
-    (O, l) added by a second launch [path 6: rf_attention_fwd_ws + scratch, forced], and the 32x32x16 form [path 4] -- all
-    against fp32 SDPA, and the split launch bit-stable run to run."""
+    (O, l) added by a second launch [path 6: rf_attention_fwd_ws + scratch, forced], the 32x32x16 form [path 4] and the
+    experimental one-wave-per-SIMD form [path 7] -- all against fp32 SDPA, and the split launch bit-stable run to run."""
     from reflectionflow_amd import _lib, ops
     q, k, vt, ref, bound = _prescaled_case(H, S, dev, seed=S + H)
     lib = _lib.load()
     outs = {}
     try:
-        for name, v5, sk, path in (("plain", 1, 0, 5), ("split", 1, 1, 6), ("split again", 1, 1, 6), ("32x32x16", 0, 0, 4)):
-            lib.rf_debug_attn_v2(1); lib.rf_debug_attn_v5(v5); lib.rf_debug_attn_sk(sk)
+        for name, v5, sk, v6, path in (("plain", 1, 0, 0, 5), ("split", 1, 1, 0, 6), ("split again", 1, 1, 0, 6), ("32x32x16", 0, 0, 0, 4),
+                                       ("one wave per SIMD", 1, 0, 1, 7)):
+            lib.rf_debug_attn_v2(1); lib.rf_debug_attn_v5(v5); lib.rf_debug_attn_sk(sk); lib.rf_debug_attn_v6(v6)
             outs[name] = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
             assert lib.rf_debug_last_attn_path() == path, (name, lib.rf_debug_last_attn_path())
-        lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(1)
+        lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(1); lib.rf_debug_attn_v6(0)
         ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
         assert lib.rf_debug_last_attn_path() == 5, "without scratch the library must not split"
     finally:
-        lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1)
+        lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
+    assert torch.equal(outs["one wave per SIMD"], outs["plain"]), "v6 walks the keys in v5's order: bit-identical"
     for name, o in outs.items():
         assert_close(o, ref, f"attention {name} S={S}", atol=2e-3)
     assert torch.equal(outs["split"], outs["split again"]), "the split launch is not bit-stable"

@@ -15,8 +15,9 @@ for S in (4608, 5632, 17920):
     out = torch.empty(S, H * 128, device=dev, dtype=torch.bfloat16)
     for rep in range(3):
         line, outs = [], []
-        for name, v2, v4, v5, sk in (("v1", 0, 0, 0, 0), ("v2", 1, 0, 0, 0), ("v4", 1, 1, 0, 0), ("v5", 1, 1, 1, 0), ("v5 split", 1, 1, 1, 1)):
-            lib.rf_debug_attn_v2(v2); lib.rf_debug_attn_v4(v4); lib.rf_debug_attn_v5(v5); lib.rf_debug_attn_sk(sk)
+        for name, v2, v4, v5, sk, v6 in (("v1", 0, 0, 0, 0, 0), ("v2", 1, 0, 0, 0, 0), ("v4", 1, 1, 0, 0, 0), ("v5", 1, 1, 1, 0, 0), ("v5 split", 1, 1, 1, 1, 0),
+                                        ("v6", 1, 1, 1, 0, 1)):
+            lib.rf_debug_attn_v2(v2); lib.rf_debug_attn_v4(v4); lib.rf_debug_attn_v5(v5); lib.rf_debug_attn_sk(sk); lib.rf_debug_attn_v6(v6)
             t = timeit(lambda: ops.attention(q, k, vt, S, out=out, q_prescaled=True, score_bound=bound), 10 if S < 10000 else 4)
             torch.cuda.synchronize()
             outs.append(out.clone())
@@ -25,5 +26,6 @@ for S in (4608, 5632, 17920):
             line.append(f"{name}: {t*1e6:8.1f} us {4.0*S*S*H*128/t/1e12:6.1f} TF" + (f" @{mhz.value:5.0f} MHz" if v4 else ""))
         print(f"S={S} bound={bound:.1f}", " | ".join(line), " max|v4-v2|", float((outs[2].float()-outs[1].float()).abs().max()),
               " max|v5-v4|", float((outs[3].float()-outs[2].float()).abs().max()),
-              " max|split-v5|", float((outs[4].float()-outs[3].float()).abs().max()), "path", lib.rf_debug_last_attn_path(), flush=True)
-lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1)
+              " max|split-v5|", float((outs[4].float()-outs[3].float()).abs().max()),
+              " max|v6-v5|", float((outs[5].float()-outs[3].float()).abs().max()), "path", lib.rf_debug_last_attn_path(), flush=True)
+lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
