@@ -2083,7 +2083,7 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
 
 // scratch layout shared by split-K and stream-K: [0, 4096) stream-K flags (zero outside a launch), partials after
 constexpr int64_t WS_FLAG_BYTES = 4096;
-static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K (test introspection)
+static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K, 3 = skinny-N (test introspection)
 static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = stream-K whenever feasible (tests), 2 = persistent whole tiles only
 static int g_persistent_rounds = 0;  // > 0: bf16 launches with >= this many tile rounds that do not qualify for stream-K run as ONE
                                      // persistent launch of whole tiles.  Worth +1..4 % with the round-1 main loop (a tile's stores
@@ -2328,6 +2328,116 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
   return RF_OK;
 }
 
+// ---- skinny-N GEMM: T[M x N] = A[M x K] . W[N x K]^T with N <= 128 (the LoRA down-projections x . lora_A^T) --------------
+// 8 output "tiles" of 128^2 and up to 240 K-tiles: the tiled kernels ran it as split-K + a reduce launch (12-16 + 5-9 us,
+// 134 times per cfg4 forward = 6 % of it).  Here ONE launch: a workgroup owns 16 rows and all N columns; its 8 waves take
+// the 64-wide K-tiles round robin, each multiplying 16x16x32 MFMAs straight from global memory (A fragment: row lane&15,
+// 16 bytes at k = 8*(lane>>4); W fragment likewise -- lora_A is <= 2 MB and stays in L2), with the next K-tile's fragments
+// in flight; the 8 partial accumulators meet in LDS and are summed in wave order (deterministic).  No bias, plain store.
+template <int NT>   // NT = N / 16 column tiles
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmParams p) {
+  __shared__ float part[8][NT][256];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const GemmGroupDev& G = p.g[0];
+  const int M = G.M;
+  const int m0 = blockIdx.x * 16;
+  const int row = m0 + l15 < M ? m0 + l15 : M - 1;
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[ct][r] = 0.f;
+  // K-tile kt of the concatenated segments -> fragment pointers (A row, W row l15 of column tile 0; + ct*16*ldw per tile)
+  auto locate = [&](int kt, const bf16_t*& a, const bf16_t*& wq, int64_t& ldw) {
+    int s = 0;
+    while (s < 2 && kt >= G.seg[s].nk) { kt -= G.seg[s].nk; ++s; }
+    a = G.seg[s].A + (int64_t)row * G.seg[s].lda + kt * 64 + g * 8;
+    wq = G.seg[s].W + (int64_t)l15 * G.seg[s].ldw + kt * 64 + g * 8;
+    ldw = G.seg[s].ldw;
+  };
+  // two fragment buffers with COMPILE-TIME names (a runtime buffer index would put the arrays in scratch memory)
+  struct Frag { bf16x8 a[2]; bf16x8 w[NT][2]; };   // [k-step of the K-tile]
+  auto load = [&](int kt, Frag& f) {
+    const bf16_t *a, *wq;
+    int64_t ldw;
+    locate(kt, a, wq, ldw);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f.a[ks] = *(const bf16x8*)(a + ks * 32);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) f.w[ct][ks] = *(const bf16x8*)(wq + (int64_t)ct * 16 * ldw + ks * 32);
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ks], f.w[ct][ks], acc[ct], 0, 0, 0);
+  };
+  Frag f0, f1;
+  int kt = w;
+  if (kt < nk) load(kt, f0);
+  while (kt < nk) {
+    if (kt + 8 < nk) load(kt + 8, f1);
+    mma(f0);
+    kt += 8;
+    if (kt >= nk) break;
+    if (kt + 8 < nk) load(kt + 8, f0);
+    mma(f1);
+    kt += 8;
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) *(f32x4*)&part[w][ct][lane * 4] = acc[ct];
+  __syncthreads();
+  // output element (r, c), r < 16, c < 16*NT: accumulator of lane (r/4)*16 + c%16, register r%4, tile c/16; two adjacent columns per thread
+  for (int e = tid; e < 16 * NT * 8; e += 512) {
+    const int r = e / (NT * 8), c = (e % (NT * 8)) * 2;
+    if (m0 + r >= M) continue;
+    float v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cc = c + j, idx = ((r >> 2) * 16 + (cc & 15)) * 4 + (r & 3);
+      float sum = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) sum += part[ww][cc >> 4][idx];
+      v[j] = sum;
+    }
+    *(uint32_t*)(G.out + (int64_t)(m0 + r) * G.ldo + c) = pack2(v[0], v[1]);
+  }
+}
+
+static bool skinny_ok(const GemmParams& p) {
+  if (p.ngroups != 1 || p.epi != RF_EPI_STORE || p.w8 || !p.vec_ok || p.N > 128 || p.N % 16 != 0) return false;
+  const GemmGroupDev& G = p.g[0];
+  if (G.bias != nullptr || G.M <= 0) return false;
+  for (int s = 0; s < 3; ++s)
+    if (G.seg[s].nk > 0 && (((uintptr_t)G.seg[s].A | (uintptr_t)G.seg[s].W) & 15 || (G.seg[s].lda | G.seg[s].ldw) % 8 != 0)) return false;
+  return true;
+}
+
+static int launch_gemm_skinny(GemmParams& p, hipStream_t stream) {
+  const dim3 grid(cdiv(p.g[0].M, 16)), blk(512);
+  switch (p.N / 16) {
+    case 1: hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, blk, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, blk, 0, stream, p); break;
+    case 3: hipLaunchKernelGGL(gemm_skinny_kernel<3>, grid, blk, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, blk, 0, stream, p); break;
+    case 5: hipLaunchKernelGGL(gemm_skinny_kernel<5>, grid, blk, 0, stream, p); break;
+    case 6: hipLaunchKernelGGL(gemm_skinny_kernel<6>, grid, blk, 0, stream, p); break;
+    case 7: hipLaunchKernelGGL(gemm_skinny_kernel<7>, grid, blk, 0, stream, p); break;
+    default: hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, blk, 0, stream, p); break;
+  }
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+static int g_skinny = 0;   // OFF: measured slower than split-K + reduce (tools/kb_skinny.py: 16 vs 13 us at K = 3072, 54 vs 23 at
+                           // K = 12288, M = 1024).  A wave's K-tiles are a dependent chain of ~2.5 us memory round trips and
+                           // 64 workgroups x 8 waves do not put enough loads in flight; split-K's 256 workgroups do.  Kept
+                           // behind rf_debug_gemm_skinny(1) with its test.
+
 static int dispatch(GemmParams& p, hipStream_t stream) {
   if (p.ngroups == 0) return RF_OK;
   int64_t rows = 0;
@@ -2350,6 +2460,10 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
+  if (g_skinny && g_force_tile == 0 && skinny_ok(p)) {
+    g_last_path = 3;
+    return launch_gemm_skinny(p, stream);
+  }
   if ((tile == 257 || tile == 258 || tile == 259) && (!p.vec_ok || p.w8)) tile = 256;
   if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
   if (tile == 256 && p.vec_ok && g_force_sk != 0) {   // (forced 257 / 258 skip the stream-K / persistent paths)
@@ -2464,6 +2578,7 @@ extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
   *mhz = *us > 0 ? (double)(h[2] - h[0]) / *us : 0.0;
   return RF_OK;
 }
+extern "C" int rf_debug_gemm_skinny(int on) { rf::g_skinny = on ? 1 : 0; return RF_OK; }   // A/B hook: skinny-N kernel vs split-K
 extern "C" int rf_debug_gemm_mi16(int on) { rf::g_mi16 = on ? 1 : 0; return RF_OK; }   // A/B hook: MFMA shape of the bf16 256x256 kernel
 extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
 extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds

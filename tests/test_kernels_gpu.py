@@ -657,3 +657,34 @@ def test_gemm_stream_k_on_both_mfma_shapes(dev):
             assert torch.equal(outs[(0, sk)][i], outs[(1, sk)][i]), f"group {i}, stream-K={sk}: the MFMA shapes disagree"
         assert_close(outs[(1, 1)][i], xs[i].float() @ Ws[i].float().t(), f"stream-K group {i}")
         assert_close(outs[(1, 1)][i], outs[(1, 0)][i].float(), f"stream-K vs tile-per-block, group {i}")   # (a bf16 ulp apart at most)
+
+
+@pytest.mark.parametrize("M,N,K,K2", [(1024, 64, 3072, 0), (1024, 64, 3072, 12288), (1000, 32, 2048, 0), (517, 128, 1024, 512),
+                                      (16384, 64, 3072, 0), (5, 16, 64, 0)])
+def test_gemm_skinny_lora_down(dev, M, N, K, K2):
+    """x . lora_A^T as the engine issues it (no bias, plain store, N = r_pad <= 128, one or two activation segments, output
+    rows 256 wide): the experimental skinny-N kernel [path 3, off by default: slower] vs fp32 and vs the split-K route
+    [path 1 or 0], bit-stable, and nothing written outside its N columns or M rows."""
+    from reflectionflow_amd import _lib, ops
+    lib = _lib.load()
+    x, A = rnd(M, K, dev=dev), rnd(N, K + K2, dev=dev, scale=0.05)
+    segs = [ops.Seg(x, A[:, :K])]
+    ref = x.float() @ A[:, :K].float().t()
+    if K2:
+        x2 = rnd(M, K2, dev=dev, seed=7)
+        segs.append(ops.Seg(x2, A[:, K:]))
+        ref = ref + x2.float() @ A[:, K:].float().t()
+    outs = []
+    try:
+        for skinny in (1, 1, 0):
+            lib.rf_debug_gemm_skinny(skinny)
+            y = torch.full((M + 3, 256), 7.0, dtype=BF, device=dev)
+            ops.gemm([ops.Group(segs, out=y[:M, :N])], N, ops.RF_EPI_STORE)
+            assert (lib.rf_debug_last_gemm_path() == 3) == bool(skinny)
+            outs.append(y)
+    finally:
+        lib.rf_debug_gemm_skinny(0)
+    assert_close(outs[0][:M, :N], ref, "skinny vs fp32")
+    assert torch.equal(outs[0], outs[1]), "the skinny kernel is not deterministic"
+    assert (outs[0][:, N:] == 7.0).all() and (outs[0][M:] == 7.0).all(), "wrote outside its block"
+    assert_close(outs[0][:M, :N], outs[2][:M, :N].float(), "skinny vs tiled route")

@@ -29,4 +29,13 @@ for T in (50, 28):
     assert all(torch.isfinite(x.float()).all() for x in outs)
     flops = 94.95e12 * T
     res[f"T{T}"] = dict(s_per_latent=round(dt, 3), latents_per_s=round(1 / dt, 4), tflops=round(flops / dt / 1e12, 1), frac_of_2p5PF=round(flops / dt / 2.5e15, 4))
+from reflectionflow_amd import ops
+with ops.profile(4096) as pr:     # per-kernel-class split over 4 profiled forwards (the library's in-sequence hook)
+    one(1, 4); torch.cuda.synchronize()
+cl = {}
+for k, v in pr.classes.items():
+    cl[k] = {"launches_per_forward": v["launches"] / 4, "ms_per_forward": round(v["us"] / 4e3, 2)}
+    if k not in ("rowop", "quant"):
+        cl[k]["tflops"] = round(v["work"] / (v["us"] * 1e-6) / 1e12, 1)
+res["classes_T4_profile"] = cl
 print(json.dumps({"workload": "cfg4-shaped: 1024^2 + 512^2 condition, LoRA r=32 on condition rows, S=5632, 94.95 TFLOP/forward (SURVEY 8d)", **res}))
