@@ -1,0 +1,20 @@
+"""What a 256x256 output tile costs besides its K loop: the same launch grids at K = 64 (one K-tile) and K = 3072,
+plain store vs gate-residual epilogue: time per round of 256 tiles."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib, ops
+lib = _lib.load(); dev = torch.device("cuda:0"); BF = torch.bfloat16
+lib.rf_debug_force_gemm_sk(0)
+for (M, N) in ((4608, 3072), (4608, 12288), (4608, 21504)):
+    tiles = (M // 256) * (N // 256); rounds = -(-tiles // 256)
+    for K in (64, 128, 3072):
+        x = torch.randn(M, K, device=dev).to(BF); W = (torch.randn(N, K, device=dev) * 0.05).to(BF)
+        b = torch.randn(N, device=dev).to(BF); gate = torch.randn(N, device=dev).to(BF)
+        y = torch.empty(M, N, device=dev, dtype=BF); res = torch.randn(M, N, device=dev).to(BF)
+        line = [f"M={M} N={N} K={K:5d} tiles={tiles} rounds={rounds}"]
+        for name, epi, kw in (("store", ops.RF_EPI_STORE, dict(bias=b, out=y)), ("gelu", ops.RF_EPI_GELU, dict(bias=b, out=y)),
+                              ("gate_res", ops.RF_EPI_GATE_RES, dict(bias=b, out=res, residual=res, gate=gate))):
+            t = min(ops.time_gemm([ops.Group([ops.Seg(x, W)], **kw)], N, epi, iters=20, splitk_ws=False) for _ in range(3))
+            line.append(f"{name} {t*1e6:7.1f} us = {t*1e6/rounds:6.1f} per round")
+        print(" | ".join(line), flush=True)
+lib.rf_debug_force_gemm_sk(-1)
