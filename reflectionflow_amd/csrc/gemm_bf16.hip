@@ -50,6 +50,7 @@ struct GemmParams {
   int w8;      // 1: at least one token group has fp8 e4m3 operands (1 byte / element; a K-tile is 128 elements = the same
                //    128 bytes): the launch uses the mixed-precision kernels, which pick the multiply per group
   int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
+  int nt_store;  // LDS-staged epilogue: write the output rows with non-temporal stores (rf_debug_gemm_nt_store)
   bf16_t* q; bf16_t* k; bf16_t* vt;
   const float* rope_cos; const float* rope_sin; float norm_eps; float q_scale;
   // deterministic split-K (few-tile GEMMs, e.g. the LoRA down-projections): blockIdx.y = K-slice of kchunk
@@ -61,6 +62,8 @@ struct GemmParams {
 };
 
 __device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
+__device__ unsigned long long g_clk_probe_epi[2];   // {s_memtime, s_memrealtime} when block 0 / wave 0 has drained its epilogue stores
+static int g_nt_store = 0;   // see GemmParams.nt_store
 static int g_mi16 = 1;   // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs (rf_debug_gemm_mi16)
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
@@ -393,7 +396,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_v(const GemmParams& p, const G
           } else {
             dst = G.out + (int64_t)m * G.ldo + (n - ncol_base);
           }
-          *(u32x4*)dst = pack8(v);
+          if (p.nt_store) __builtin_nontemporal_store(pack8(v), (u32x4*)dst);   // a round's 32 x 128 KiB per XCD would fill its 4 MiB L2
+          else *(u32x4*)dst = pack8(v);
         }
       }
     }
@@ -1544,6 +1548,14 @@ __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
     __syncthreads();  // every wave is done reading the staged operands: the LDS is free
     gemm_epilogue_lds16<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
   }
+  if (blockIdx.x == 0 && w == 0) {   // probe only: when has this wave's part of the tile left the CU?
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      unsigned long long c, r;
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c), "=s"(r)::"memory");
+      g_clk_probe_epi[0] = c; g_clk_probe_epi[1] = r;
+    }
+  }
 }
 __global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
 __global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p) { gemm_pp16_body<false>(p); }
@@ -2308,6 +2320,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
           (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
   }
   p.vec_ok = vec ? 1 : 0;
+  p.nt_store = g_nt_store;
   if (w8) {
     RF_REQUIRE(vec, RF_ERR_ALIGN, "rf_gemm_w8a8: needs N %% 8 == 0 and 16-byte aligned outputs / bias / gate / residual");
     bool any8 = false;
@@ -2572,12 +2585,21 @@ int read_clk_probe_gemm(unsigned long long* h) {
 // synchronises the stream first.
 extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
   unsigned long long h[4];
+  if (which == 2) {   // block 0 / wave 0 of the last 16x16x32 GEMM launch: end of its main loop -> its epilogue stores acknowledged
+    unsigned long long e[2];
+    if (rf::read_clk_probe_gemm(h) != RF_OK) return RF_ERR_HIP;
+    if (hipMemcpyFromSymbol(e, HIP_SYMBOL(rf::g_clk_probe_epi), sizeof(e)) != hipSuccess) return RF_ERR_HIP;
+    *us = (double)(e[1] - h[3]) / 100.0;
+    *mhz = *us > 0 ? (double)(e[0] - h[2]) / *us : 0.0;
+    return RF_OK;
+  }
   const int rc = which == 0 ? rf::read_clk_probe_gemm(h) : rf::read_clk_probe_attn(h);
   if (rc != RF_OK) return rc;
   *us = (double)(h[3] - h[1]) / 100.0;
   *mhz = *us > 0 ? (double)(h[2] - h[0]) / *us : 0.0;
   return RF_OK;
 }
+extern "C" int rf_debug_gemm_nt_store(int on) { rf::g_nt_store = on ? 1 : 0; return RF_OK; }   // A/B hook
 extern "C" int rf_debug_gemm_skinny(int on) { rf::g_skinny = on ? 1 : 0; return RF_OK; }   // A/B hook: skinny-N kernel vs split-K
 extern "C" int rf_debug_gemm_mi16(int on) { rf::g_mi16 = on ? 1 : 0; return RF_OK; }   // A/B hook: MFMA shape of the bf16 256x256 kernel
 extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
