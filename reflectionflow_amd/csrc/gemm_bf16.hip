@@ -3,15 +3,14 @@
 //   out[m,n] = epi( sum_k A[m,k] W[n,k] (+ sum_k2 A2[m,k2] W2[n,k2]) + bias[n] )
 //
 // Design (CDNA4-first, see DESIGN.md "K1"):
-//   * block tile BM x BN x 64, 64-lane waves in a WM x WN grid, each wave owns a
-//     (BM/WM) x (BN/WN) sub-tile built from v_mfma_f32_32x32x16_bf16 fragments
-//     (fp32 accumulators stay in registers for the whole K loop);
-//   * operands are staged HBM -> LDS with the LDS-DMA path (global_load_lds_dwordx4, 16 B per
+//   * block tile 256 x 256 x 64, 8 waves (4 x 2), each wave owns a 64 x 128 sub-tile of v_mfma_f32_16x16x32_bf16 tiles
+//     (the fp8 kernels: v_mfma_scale_f32_16x16x128_f8f6f4); fp32 accumulators stay in registers for the whole K loop;
+//   * operands are staged HBM -> LDS with the LDS-DMA path (buffer_load_dwordx4 ... lds, 16 B per
 //     lane, no VGPR round trip).  The DMA writes LDS lane-linearly, so the bank-conflict-free
 //     XOR swizzle is applied on the per-lane SOURCE address and mirrored on the ds_read_b128
 //     side (chunk' = chunk ^ ((row >> 1) & 7) for 128-byte rows);
-//   * two LDS stages, ONE barrier per K-tile: the DMA of tile t+1 flies while tile t is
-//     multiplied;
+//   * ping-pong main loop: two wave groups half a phase apart, four phases per K-tile, the staging re-used as four
+//     16 KiB half-tiles under counted vmcnt waits;
 //   * up to 4 token groups (text / image / condition streams) with their own A, W, bias, gate
 //     and output pointers ride in one launch, so the small text stream fills the tail of the
 //     grid instead of costing its own under-filled launch;
@@ -19,6 +18,14 @@
 //     input (single-block proj_out = [attn | mlp]) and/or LoRA (A = x.lora_A^T,
 //     W = scaling*lora_B) without materialising a concat or a merged weight;
 //   * blockIdx is remapped so that every XCD works on a contiguous chunk of tiles (private L2).
+//
+// Map of this file.  SHIPPED: the epilogues (gemm_epilogue / gemm_epilogue_lds_v over the Acc32 / Acc16 accumulator views),
+// gemm_mainloop (plain loop of the 128 x 128 kernel for small problems and of split-K), gemm_mainloop_pp2_m16 (the 256 x 256
+// loop: bf16 and fp8) with gemm_bf16_pp16_kernel / gemm_w8_pp16_kernel, gemm_bf16_sk_kernel (stream-K and persistent
+// schedules), splitk_reduce_kernel, dispatch() and the C entry points.  KEPT FOR A/B AND THE STUDIES IN
+// profiles/r02_gemm_power.md, reachable only through rf_debug_* switches: gemm_mainloop_pp (round-1 phases, with knock-outs),
+// gemm_mainloop_pp2 / _pp3 (balanced / evenly loaded phases on 32x32x16 MFMAs: pp2 is what rf_debug_gemm_mi16(0) selects),
+// gemm_bf16_ppx_kernel (their harness), gemm_mainloop_w4 (one wave per SIMD over an LDS ring), gemm_skinny_kernel.
 #include "common.hpp"
 #include <type_traits>
 #include <stdlib.h>
