@@ -18,6 +18,13 @@
 //     accumulator layout yields; the producer GEMM stores V^T with the matching key
 //     permutation (bits 2,3 of the key index swapped), so no in-kernel transpose or permute
 //     of V or P is needed.
+//
+// Map of this file.  attn_fwd_kernel (v1: the design above, online softmax; masks, bias, ragged S) and attn_fwd_kernel_v2
+// (8 waves x 32 queries, K / VT rings) are the general kernels.  With a proven score bound, no mask / bias, a prescaled q and
+// S % 256 == 0 the bounded-score kernels run instead (no running maximum): SHIPPED attn5_body = attn_fwd_kernel_v5
+// (16x16x32 MFMAs) and its split launch attn_fwd_kernel_v5sk + attn5_combine_kernel (rf_attention_fwd_ws).  KEPT FOR A/B
+// behind rf_debug_* switches: attn_fwd_kernel_v4 (the 32x32x16 form v5 was derived from), attn_fwd_kernel_v5k (knock-outs),
+// attn6_body = attn_fwd_kernel_v6 (one wave per SIMD, 64 queries per wave: slower).  profiles/r02_attention.md has the story.
 #include "common.hpp"
 #include <type_traits>
 #include <utility>
