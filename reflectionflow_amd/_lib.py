@@ -128,7 +128,7 @@ _EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_
                "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
                "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]),
-               "rf_debug_gemm_mi16": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]), "rf_debug_gemm_nt_store": (C.c_int, [C.c_int]),
+               "rf_debug_gemm_mi16": (C.c_int, [C.c_int]), "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]), "rf_debug_gemm_nt_store": (C.c_int, [C.c_int]),
                "rf_debug_clock_probe": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
                "rf_debug_gemm_timeline": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_void_p, C.c_void_p]),
                "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)])}

@@ -71,6 +71,7 @@ struct GemmParams {
 __device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
 __device__ unsigned long long g_clk_probe_epi[2];   // {s_memtime, s_memrealtime} when block 0 / wave 0 has drained its epilogue stores
 static int g_nt_store = 0;   // see GemmParams.nt_store
+static int g_even = 1;   // bf16 tile-per-block launches use the evenly loaded phases (gemm_mainloop_pp3_m16; rf_debug_gemm_even)
 static int g_mi16 = 1;   // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs (rf_debug_gemm_mi16)
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
@@ -1274,6 +1275,196 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
 }
 
 
+// Experiment (rf_debug_force_gemm_tile(259), variant 11): the evenly loaded 6/6/6/6 + 2/2/2/2 schedule of gemm_mainloop_pp3 on
+// 16x16x32 MFMAs: the k-step-0 fragments of column tiles 0, 1 of each W half are read one phase early (e0 / e1), the other six
+// share one register set m; a phase starts with the four MFMAs that need only the early pair.
+__device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
+                                                  const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
+  constexpr int ESZ = 2;  // bytes per element
+  constexpr bool W8 = false; constexpr int KNOCK = 0;
+  constexpr int HT = 128 * 128;  // half-tile bytes
+  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
+  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int M = G.M;
+
+  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
+  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
+  const int r8 = lane >> 3;
+  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
+  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
+  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
+  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
+  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
+  auto load_seg = [&](Cur& c) {
+    const KSegDev& S = G.seg[c.seg];
+    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
+    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
+    // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
+        const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
+        c.offA[sb][i] = (uint32_t)(gm < M ? gm : M - 1) * lda2 + chunk_b;
+        c.offB[sb][i] = (uint32_t)(gn < N ? gn : N - 1) * ldw2 + chunk_b;
+      }
+  };
+  auto next = [&](Cur& c) {
+    ++c.kk;
+    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
+      c.kk = 0;
+      ++c.seg;
+      load_seg(c);
+    }
+  };
+  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](const int kind, const Cur& c, const int buf) {
+    char* dst = smem + buf * BUF + kind * HT + w * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
+      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
+    }
+  };
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets inside a buffer (16x16x32 fragments: lane -> row lane&15, 16-byte chunk 4*ks + lane>>4)
+  const int l15 = lane & 15;
+  const int swz = (l15 >> 1) & 7;
+  const int a_off = (wm * 32 + l15) * 128;                 // + sb*HT + rt*16*128
+  const int b_off = 2 * HT + (wn * 64 + l15) * 128;        // + sb*HT + ct*16*128
+  auto frag_coff = [&](int ks) { return ((ks * 4 + (lane >> 4)) ^ swz) << 4; };
+  // A half: fragments [rt*2 + ks] (2 row tiles x 2 k-steps); W half: [ct*2 + ks] (4 column tiles x 2 k-steps)
+  auto rdA = [&](bf16x8 (&dst)[4], const char* half) {
+    if (KNOCK & 2) return;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) dst[rt * 2 + ks] = *(const bf16x8*)(half + a_off + rt * 2048 + frag_coff(ks));
+  };
+  // W half fragments [ct][ks]: early pair e = {(ct 0, ks 0), (ct 1, ks 0)}, main m = {(2,0), (3,0), (0,1), (1,1), (2,1), (3,1)}
+  auto rdBe = [&](bf16x8 (&e)[2], const char* half) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) e[ct] = *(const bf16x8*)(half + b_off + ct * 2048 + frag_coff(0));
+  };
+  auto rdBm = [&](bf16x8 (&m)[6], const char* half) {
+#pragma unroll
+    for (int ct = 2; ct < 4; ++ct) m[ct - 2] = *(const bf16x8*)(half + b_off + ct * 2048 + frag_coff(0));
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) m[2 + ct] = *(const bf16x8*)(half + b_off + ct * 2048 + frag_coff(1));
+  };
+  auto mma16s = [&](const int rb, const int cb, const bf16x8 (&A)[4], const bf16x8 (&e)[2], const bf16x8 (&m)[6]) {
+    auto B = [&](int ct, int ks) -> const bf16x8& { return ks == 0 ? (ct < 2 ? e[ct] : m[ct - 2]) : m[2 + ct]; };
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+          acc[rb + rt][cb + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[rt * 2 + ks], B(ct, ks), acc[rb + rt][cb + ct], 0, 0, 0);
+  };
+
+  Cur c1;
+  c1.seg = 0; c1.kk = kt_begin;
+  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
+    c1.kk -= G.seg[c1.seg].nk;
+    ++c1.seg;
+  }
+  load_seg(c1);
+  // prologue, in steady-state issue order: A0(0) B0(0) A1(0) B1(0) | A0(1) B0(1) A1(1)      (B1(1) goes out in p0 of tile 0)
+  Cur c2 = c1;
+  stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
+  if (nk > 1) {
+    next(c2);
+    stage(0, c2, 1); stage(2, c2, 1); stage(1, c2, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) have landed
+    c1 = c2;
+    next(c2);
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 X[4], Y[4], e0[2], e1[2], m[6];
+  rdA(X, smem);
+  rdBe(e0, smem);
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+#define RF_PP3_BAR()                    \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __builtin_amdgcn_s_barrier();         \
+  __builtin_amdgcn_sched_barrier(0)
+  auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
+    const char* base = smem + (t & 1) * BUF;
+    const char* nbase = smem + ((t + 1) & 1) * BUF;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- p0: B0 main; DMA B1(t+1) ----
+    rdBm(m, base);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1) {
+      stage(3, c1, (t + 1) & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP3_BAR();
+    mma16s(0, 0, P, e0, m);
+    RF_PP3_BAR();
+    // ---- p1: A1, B1 early; DMA A0(t+2) ----
+    rdA(Q, base + HT);
+    rdBe(e1, base + HT);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) stage(0, c2, t & 1);
+    RF_PP3_BAR();
+    mma16s(2, 0, Q, e0, m);
+    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+    RF_PP3_BAR();
+    // ---- p2: B1 main; DMA B0(t+2) ----
+    rdBm(m, base + HT);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      stage(2, c2, t & 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (more1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    RF_PP3_BAR();
+    mma16s(2, 4, Q, e1, m);
+    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
+    RF_PP3_BAR();
+    // ---- p3: next tile's A0 and B0 early; DMA A1(t+2) ----
+    if (more1) {
+      rdA(Q, nbase);
+      rdBe(e0, nbase);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) stage(1, c2, t & 1);
+    RF_PP3_BAR();
+    mma16s(0, 4, P, e1, m);
+    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
+    RF_PP3_BAR();
+    next(c1);
+    next(c2);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    tile(t, X, Y);
+    if (t + 1 < nk) tile(t + 1, Y, X);
+  }
+#undef RF_PP3_BAR
+  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
+}
+
 // Evenly loaded ping-pong schedule (experiment VAR 6): 6 fragment reads and 2 DMA pieces in EVERY phase.  On top of
 // gemm_mainloop_pp2's early A0 read, the k-step-0 pair of each B half is read one phase early into two spare fragment
 // pairs (e0 for B0, e1 for B1); the other six fragments of a half share one register set m.  18 fragments live (+2).
@@ -1566,6 +1757,30 @@ __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
 }
 __global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
 __global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p) { gemm_pp16_body<false>(p); }
+// bf16 launches, evenly loaded phases (gemm_mainloop_pp3_m16)
+__global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
+  int gi = 0;
+#pragma unroll
+  for (int t = 1; t < 4; ++t)
+    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
+  const GemmGroupDev& G = p.g[gi];
+  int tm, tn;
+  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
+  f32x4 acc[4][8];
+  gemm_mainloop_pp3_m16(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  clk.end(g_clk_probe);
+  __syncthreads();  // every wave is done reading the staged operands: the LDS is free
+  gemm_epilogue_lds16<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
+}
 __global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) { gemm_pp16_body<true>(p); }
 
 // experiment harness for the ping-pong main loop (one tile per block, bf16 only): rf_debug_force_gemm_tile(259)
@@ -1589,9 +1804,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) 
   tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  if constexpr (VAR >= 7) {   // the shipped 16x16x32 loop, whole (7) or knocked out (8: no DMA, 9: no reads, 10: neither)
+  if constexpr (VAR >= 7) {   // the shipped 16x16x32 loop, whole (7) or knocked out (8: no DMA, 9: no reads, 10: neither); 11: evenly loaded
     f32x4 acc16[4][8];
-    gemm_mainloop_pp2_m16<false, VAR - 7>(G, p.N, m0, n0, 0, nk, acc16, smem, w, lane);
+    if constexpr (VAR == 11) gemm_mainloop_pp3_m16(G, p.N, m0, n0, 0, nk, acc16, smem, w, lane);
+    else gemm_mainloop_pp2_m16<false, VAR - 7>(G, p.N, m0, n0, 0, nk, acc16, smem, w, lane);
     clk.end(g_clk_probe);
     __syncthreads();
     gemm_epilogue_lds16<2, false>(p, G, acc16, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
@@ -2041,6 +2257,7 @@ static int launch_gemm_ppx(GemmParams& p, hipStream_t stream) {
     case 8: return launch_gemm_ppx_v<8>(p, stream);
     case 9: return launch_gemm_ppx_v<9>(p, stream);
     case 10: return launch_gemm_ppx_v<10>(p, stream);
+    case 11: return launch_gemm_ppx_v<11>(p, stream);
     default: return launch_gemm_ppx_v<0>(p, stream);
   }
 }
@@ -2088,12 +2305,14 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
   if (p.w8 && g_mi16) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   else if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  else if (g_mi16 && g_even) hipLaunchKernelGGL(gemm_bf16_pp16e_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   else if (g_mi16) hipLaunchKernelGGL(gemm_bf16_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
@@ -2608,6 +2827,7 @@ extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
 }
 extern "C" int rf_debug_gemm_nt_store(int on) { rf::g_nt_store = on ? 1 : 0; return RF_OK; }   // A/B hook
 extern "C" int rf_debug_gemm_skinny(int on) { rf::g_skinny = on ? 1 : 0; return RF_OK; }   // A/B hook: skinny-N kernel vs split-K
+extern "C" int rf_debug_gemm_even(int on) { rf::g_even = on ? 1 : 0; return RF_OK; }   // A/B hook: 6/6/6/6 vs 8/4/8/4 phases
 extern "C" int rf_debug_gemm_mi16(int on) { rf::g_mi16 = on ? 1 : 0; return RF_OK; }   // A/B hook: MFMA shape of the bf16 256x256 kernel
 extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
 extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds

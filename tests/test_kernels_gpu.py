@@ -594,8 +594,8 @@ def test_gemm_persistent_whole_tiles_equals_tile_per_block(dev, rows, N, K):
 
 @pytest.mark.parametrize("rows,N,K", [((512, 4096), 3072, 3072), ((300, 5000, 77), 1536, 320), ((4608,), 3072, 64)])
 def test_gemm_mfma_shapes_and_experimental_loops_agree(dev, rows, N, K):
-    """The shipped 256x256 kernel multiplies with v_mfma_f32_16x16x32_bf16; rf_debug_gemm_mi16(0) selects the 32x32x16
-    loop it replaced.  Both walk the K-tiles in the same order with fp32 accumulation per output element, so the results
+    """The shipped 256x256 kernel multiplies with v_mfma_f32_16x16x32_bf16 in evenly loaded phases; rf_debug_gemm_even(0)
+    selects the 8/4/8/4 phases (which the fp8 and stream-K kernels still use), rf_debug_gemm_mi16(0) the 32x32x16 loop.  Both walk the K-tiles in the same order with fp32 accumulation per output element, so the results
     are bit-identical -- as are the experimental main loops kept in the library (rf_debug_force_gemm_tile 258: one wave
     per SIMD over an LDS ring; 259 + variant 5 / 6: the balanced and the evenly loaded ping-pong phases on 32x32x16),
     with grouped rows, a ragged last tile in M and N, 1 / 5 / 48 K-tiles and the gate-residual epilogue."""
@@ -608,12 +608,14 @@ def test_gemm_mfma_shapes_and_experimental_loops_agree(dev, rows, N, K):
     res = [rnd(m, N, dev=dev, seed=170 + i) for i, m in enumerate(rows)]
     outs = {}
     try:
-        for name, tile, var, mi16 in (("16x16x32", 256, 0, 1), ("32x32x16", 256, 0, 0), ("one wave per SIMD", 258, 0, 1),
-                                      ("balanced 32x32", 259, 5, 1), ("even 32x32", 259, 6, 1)):
+        for name, tile, var, mi16, even in (("16x16x32", 256, 0, 1, 1), ("16x16x32 8/4/8/4 phases", 256, 0, 1, 0), ("32x32x16", 256, 0, 0, 1),
+                                            ("one wave per SIMD", 258, 0, 1, 1), ("balanced 32x32", 259, 5, 1, 1), ("even 32x32", 259, 6, 1, 1),
+                                            ("16x16 harness, 8/4/8/4", 259, 7, 1, 1), ("16x16 harness, even", 259, 11, 1, 1)):
             lib.rf_debug_force_gemm_sk(0)
             lib.rf_debug_force_gemm_tile(tile)
             lib.rf_debug_gemm_w4_knock(var)
             lib.rf_debug_gemm_mi16(mi16)
+            lib.rf_debug_gemm_even(even)
             o = [r_.clone() for r_ in res]
             ops.gemm([Group([Seg(xs[i], Ws[i])], bias=b, out=o[i], residual=o[i], gate=gate) for i in range(len(rows))], N,
                      RF_EPI_GATE_RES, splitk_ws=False)
@@ -623,6 +625,7 @@ def test_gemm_mfma_shapes_and_experimental_loops_agree(dev, rows, N, K):
         lib.rf_debug_force_gemm_tile(0)
         lib.rf_debug_gemm_w4_knock(0)
         lib.rf_debug_gemm_mi16(1)
+        lib.rf_debug_gemm_even(1)
     for i in range(len(rows)):
         assert_close(outs["16x16x32"][i], res[i].float() + gate.float() * (xs[i].float() @ Ws[i].float().t() + b.float()), f"group {i}")
         for name in outs:

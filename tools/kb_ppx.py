@@ -7,7 +7,7 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 NAMES = {0: "round-1 loop", 1: "reads first", 2: "no DMA", 3: "no reads", 4: "MFMA+barriers", 5: "balanced 32x32", 6: "even 32x32",
-         7: "shipped 16x16x32", 8: "16x16 no DMA", 9: "16x16 no reads", 10: "16x16 MFMA+barriers"}
+         7: "shipped 16x16x32", 8: "16x16 no DMA", 9: "16x16 no reads", 10: "16x16 MFMA+barriers", 11: "even 16x16x32"}
 if len(sys.argv) > 1:
     NAMES = {int(k): NAMES.get(int(k), f"var{k}") for k in sys.argv[1].split(",")}
 for (M, N, K) in ((4608, 3072, 12288), (4608, 9216, 3072)):
