@@ -202,7 +202,7 @@ def in_sequence_roofline(one_latent_steps, T_prof, ms_per_forward_timed, dims):
                      "frac_at_gemm_clock": round(ach / (PEAK_BF16_TFLOPS * clk_gemm / NOMINAL_MHZ), 4),
                      "method": "block 0 of the last launch of each kernel inside the profiled forwards: s_memtime "
                                "(shader clocks) / s_memrealtime (100 MHz) around its main loop"}
-    return {"bound": "mfma", "kernel": "256x256x64 bf16 MFMA GEMM, balanced ping-pong loop (rf::gemm_bf16_pp_kernel; rf::gemm_bf16_sk_kernel<256,256,4,2,false> where stream-K qualifies)",
+    return {"bound": "mfma", "kernel": "256x256x64 bf16 MFMA GEMM on 16x16x32 MFMAs, evenly loaded ping-pong loop (rf::gemm_bf16_pp16e_kernel; rf::gemm_bf16_sk_kernel<256,256,4,2,false,true> where stream-K qualifies)",
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "sustained_clock": sustained,
             "traffic": traffic, "traffic_unit": "bytes/launch",

@@ -18,7 +18,7 @@ for pth in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out/pmc/p*/p*_counter_col
     per = collections.OrderedDict()
     for r in csv.DictReader(open(pth)):
         kn = r['Kernel_Name']
-        if not any(t in kn for t in ('rf::gemm_bf16_kernel<256', 'rf::gemm_bf16_pp_kernel', 'rf::gemm_bf16_pp16_kernel', 'rf::gemm_bf16_sk_kernel', 'rf::attn_fwd')):
+        if not any(t in kn for t in ('rf::gemm_bf16_kernel<256', 'rf::gemm_bf16_pp_kernel', 'rf::gemm_bf16_pp16_kernel', 'rf::gemm_bf16_pp16e_kernel', 'rf::gemm_bf16_sk_kernel', 'rf::attn_fwd')):
             continue
         d = per.setdefault(int(r['Dispatch_Id']), {'name': kn, 'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
         d[r['Counter_Name']] = float(r['Counter_Value'])
