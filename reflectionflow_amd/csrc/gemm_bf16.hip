@@ -20,9 +20,10 @@
 //   * blockIdx is remapped so that every XCD works on a contiguous chunk of tiles (private L2).
 //
 // Map of this file.  SHIPPED: the epilogues (gemm_epilogue / gemm_epilogue_lds_v over the Acc32 / Acc16 accumulator views),
-// gemm_mainloop (plain loop of the 128 x 128 kernel for small problems and of split-K), gemm_mainloop_pp2_m16 (the 256 x 256
-// loop: bf16 and fp8) with gemm_bf16_pp16_kernel / gemm_w8_pp16_kernel, gemm_bf16_sk_kernel (stream-K and persistent
-// schedules), splitk_reduce_kernel, dispatch() and the C entry points.  KEPT FOR A/B AND THE STUDIES IN
+// gemm_mainloop (plain loop of the 128 x 128 kernel for small problems and of split-K), the 256 x 256 loops
+// gemm_mainloop_pp3_m16 (bf16: gemm_bf16_pp16e_kernel one tile per block, gemm_bf16_sk_kernel<..., EVEN> for the stream-K and
+// persistent schedules) and gemm_mainloop_pp2_m16 (fp8 / mixed launches: gemm_w8_pp16_kernel and the W8 stream-K kernel),
+// splitk_reduce_kernel, dispatch() and the C entry points.  KEPT FOR A/B AND THE STUDIES IN
 // profiles/r02_gemm_power.md, reachable only through rf_debug_* switches: gemm_mainloop_pp (round-1 phases, with knock-outs),
 // gemm_mainloop_pp2 / _pp3 (balanced / evenly loaded phases on 32x32x16 MFMAs: pp2 is what rf_debug_gemm_mi16(0) selects),
 // gemm_bf16_ppx_kernel (their harness), gemm_mainloop_w4 (one wave per SIMD over an LDS ring), gemm_skinny_kernel.
@@ -71,8 +72,8 @@ struct GemmParams {
 __device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
 __device__ unsigned long long g_clk_probe_epi[2];   // {s_memtime, s_memrealtime} when block 0 / wave 0 has drained its epilogue stores
 static int g_nt_store = 0;   // see GemmParams.nt_store
-static int g_even = 1;   // bf16 tile-per-block launches use the evenly loaded phases (gemm_mainloop_pp3_m16; rf_debug_gemm_even)
 static int g_mi16 = 1;   // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs (rf_debug_gemm_mi16)
+static int g_even = 1;   // ... in evenly loaded phases (gemm_mainloop_pp3_m16; rf_debug_gemm_even)
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
 
@@ -2052,7 +2053,7 @@ struct SkParams {
   int* flags;           // [gridDim.x], zero outside a launch
 };
 
-template <int BM, int BN, int WM, int WN, bool W8, bool MI16 = false>   // MI16: the 16x16 MFMA shapes (gemm_mainloop_pp2_m16)
+template <int BM, int BN, int WM, int WN, bool W8, bool MI16 = false, bool EVEN = false>   // MI16: the 16x16 MFMA shapes; EVEN: bf16 groups on gemm_mainloop_pp3_m16
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmParams p, const SkParams sk) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -2136,6 +2137,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
     const bool g8 = W8 && G.w8;   // mixed-precision launch: multiply chosen per token group
     if constexpr (MI16) {
       if (g8) gemm_mainloop_pp2_m16<W8>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+      else if constexpr (EVEN && !W8) gemm_mainloop_pp3_m16(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
       else gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     } else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     else gemm_mainloop_pp2<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
@@ -2431,13 +2433,16 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
   auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>;
-  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true>;
+  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, false>;
+  auto kern16e = gemm_bf16_sk_kernel<BM, BN, WM, WN, false, true, true>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16e, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
-  if (g_mi16) hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  if (g_mi16 && g_even && !W8) hipLaunchKernelGGL(kern16e, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  else if (g_mi16) hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   else hipLaunchKernelGGL(kern, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   RF_LAUNCH_CHECK();
   g_last_path = 2;
