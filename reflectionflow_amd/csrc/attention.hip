@@ -1343,7 +1343,12 @@ int read_clk_probe_attn(unsigned long long* h) {
 
 static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)
 static int g_attn_v4 = 1;   // 1 = launches with a proven score bound that qualify for v2's plain instantiation run v4 / v5, 0 = never
-static int g_attn_v5 = 1;   // 1 = the bounded-score kernel on 16x16x32 MFMAs (v5), 0 = on 32x32x16 (v4)
+static int g_attn_v5 = -1;  // MFMA shape of the bounded-score kernel: 1 = 16x16x32 (v5), 0 = 32x32x16 (v4), -1 = by size: v5 below 8192 keys.
+                            // In isolation v5 is faster at every length (+0.5 % at 4608 ... +4.6 % at 17920), but it also runs the chip
+                            // at 2.0 instead of 1.75 GHz, and inside a forward that costs the neighbouring GEMMs their clock:
+                            // interleaved in-sequence A/B (tools/bench_cfg5.py --ab-attn): S = 4608: attention 13.46 vs 13.40 ms and
+                            // GEMMs 47.6 vs 48.0 ms per forward with v5 vs v4 (v5 +0.6 % overall); S = 17920: attention 189.5 vs 187.6
+                            // and GEMMs 186.6 vs 183.5 ms (v5 -1.3 % overall).
 static int g_attn_v6 = 0;    // 1 = plain-grid launches of the bounded-score kernel use the one-wave-per-SIMD form (v6): an experiment,
                              // bit-identical to v5 and 12-20 % SLOWER (profiles/r02_kb_attn_v6.log) -- see attn6_body
 static int g_attn_knock = 0; // timing diagnostics (rf_debug_attn_knock): 1 = no fragment reads, 2 = no softmax VALU, 3 = both
@@ -1357,8 +1362,8 @@ extern "C" int rf_debug_attn_v2(int on) {  // tuning hook (-1 = cost model), not
   return RF_OK;
 }
 
-extern "C" int rf_debug_attn_v5(int on) {  // A/B hook: MFMA shape of the bounded-score kernel
-  rf::g_attn_v5 = on ? 1 : 0;
+extern "C" int rf_debug_attn_v5(int mode) {  // A/B hook: MFMA shape of the bounded-score kernel (-1 = by size, 0 = v4, 1 = v5)
+  rf::g_attn_v5 = mode < 0 ? -1 : (mode ? 1 : 0);
   return RF_OK;
 }
 
@@ -1442,6 +1447,7 @@ extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt,
   // the bounded-score kernel is 25-45 % faster than either online-softmax kernel wherever it applies (profiles/r02_kb_attn*.log)
   const bool bounded = mode == 0 && S % 256 == 0 && pre && g_attn_v4 && score_bound > 0.f && score_bound <= 100.f;
   if (bounded && g_attn_v2 != 0) use_v2 = true;
+  const bool use5 = g_attn_v5 == 1 || (g_attn_v5 < 0 && S < 8192);
   if (use_v2) {
     const dim3 grid2(heads * cdiv(S, 256)), blk(512);
     const bool generic = !(mode == 0 && S % 64 == 0);
@@ -1459,21 +1465,21 @@ extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt,
       const int P = num_cus / 8 * 8, blocks = heads * (S / 256), rounds = cdiv(blocks, P);
       AttnSkParams sk;
       sk.nq = S / 256; sk.nqb = S / 256; sk.hpx = heads / 8; sk.wpx = P / 8; sk.ws = (float*)ws;
-      const bool can_split = g_attn_v5 && g_attn_sk != 0 && heads % 8 == 0 && P >= 8 && ws != nullptr && aligned16(ws) &&
+      const bool can_split = use5 && g_attn_sk != 0 && heads % 8 == 0 && P >= 8 && ws != nullptr && aligned16(ws) &&
                              ws_bytes >= (int64_t)2 * P * ATT5_SLOT * 4 && (int64_t)sk.hpx * sk.nqb * sk.nq >= 2 * sk.wpx;
       if (can_split && (g_attn_sk == 1 || (double)blocks / ((double)rounds * P) < 0.80)) {
         hipLaunchKernelGGL(attn_fwd_kernel_v5sk, dim3(P), blk, ATT4_LDS, st, p, sk);
         hipLaunchKernelGGL(attn5_combine_kernel, grid2, blk, 0, st, p, sk);
         g_last_attn_path = 6;
-      } else if (g_attn_v5 && g_attn_v6 && !g_attn_knock) {
+      } else if (use5 && g_attn_v6 && !g_attn_knock) {
         hipLaunchKernelGGL(attn_fwd_kernel_v6, grid2, dim3(256), ATT4_LDS, st, p);
         g_last_attn_path = 7;
-      } else if (g_attn_v5 && g_attn_knock) {
+      } else if (use5 && g_attn_knock) {
         if (g_attn_knock == 1) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1>, grid2, blk, ATT4_LDS, st, p);
         else if (g_attn_knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
         else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;
-      } else if (g_attn_v5) {
+      } else if (use5) {
         hipLaunchKernelGGL(attn_fwd_kernel_v5, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;
       } else {

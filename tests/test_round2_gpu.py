@@ -230,7 +230,7 @@ def test_attention_split_launch_and_mfma_shapes(dev, S, H):
         ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
         assert lib.rf_debug_last_attn_path() == 5, "without scratch the library must not split"
     finally:
-        lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
+        lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v5(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
     assert torch.equal(outs["one wave per SIMD"], outs["plain"]), "v6 walks the keys in v5's order: bit-identical"
     for name, o in outs.items():
         assert_close(o, ref, f"attention {name} S={S}", atol=2e-3)

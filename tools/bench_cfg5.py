@@ -20,6 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10, help="Euler steps per timed latent (per-step cost is step-invariant)")
 ap.add_argument("--res", type=int, default=2048)
 ap.add_argument("--w8", action="store_true")
+ap.add_argument("--no-cond", action="store_true", help="no condition image (with --res 1024 this is cfg2's S = 4608)")
+ap.add_argument("--ab-attn", action="store_true", help="instead: interleaved in-sequence A/B of the attention kernels (v4 / v5) over profiled forwards")
 args = ap.parse_args()
 dev = torch.device("cuda:0"); bf = torch.bfloat16
 pipe = bench.build_model(dev, {}, seed=0)
@@ -37,12 +39,25 @@ f_fwd, f_gemm, f_attn = bench.flops_per_forward(512, S_img, S_cond=1024)
 
 def one(seed, T):
     cond = Condition("cot", tokens=cond_tokens, ids=ids, position_delta=[0, -32])
-    return generate(pipe, conditions=[cond], model_config=mc, default_lora=True, height=args.res, width=args.res,
+    return generate(pipe, conditions=None if args.no_cond else [cond], model_config=mc, default_lora=True, height=args.res, width=args.res,
                     num_inference_steps=T, guidance_scale=3.5, latents=noises[seed], prompt_embeds=pe,
                     pooled_prompt_embeds=pooled, output_type="latent").images
 
 T = args.steps
 one(1, 2); torch.cuda.synchronize()
+if args.ab_attn:
+    from reflectionflow_amd import _lib
+    lib = _lib.load()
+    for rep in range(3):
+        for v5 in (0, 1):
+            lib.rf_debug_attn_v5(v5)
+            with ops.profile(4096) as pr:
+                one(1, 2); torch.cuda.synchronize()
+            a, gm = pr.classes["attention"], pr.classes.get("gemm_main", pr.classes.get("gemm_w8"))
+            print(f"rep {rep} attention {'v5 (16x16x32)' if v5 else 'v4 (32x32x16)'}: {a['us']/2e3:7.2f} ms/forward = {a['work']/(a['us']*1e-6)/1e12:7.1f} TF   "
+                  f"(GEMM class next to it: {gm['us']/2e3:7.2f} ms/forward)", flush=True)
+    lib.rf_debug_attn_v5(-1)
+    sys.exit(0)
 t0 = time.perf_counter(); o = one(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 assert torch.isfinite(o.float()).all()
 with ops.profile(4096) as pr:

@@ -28,4 +28,4 @@ for S in (4608, 5632, 17920):
               " max|v5-v4|", float((outs[3].float()-outs[2].float()).abs().max()),
               " max|split-v5|", float((outs[4].float()-outs[3].float()).abs().max()),
               " max|v6-v5|", float((outs[5].float()-outs[3].float()).abs().max()), "path", lib.rf_debug_last_attn_path(), flush=True)
-lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
+lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v4(1); lib.rf_debug_attn_v5(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
