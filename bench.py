@@ -12,7 +12,11 @@
     N GPUs : one process per GPU, candidates sharded rank-round-robin, weights replicated; the only collective
              is the round-boundary all-gather of verifier scores (RCCL).  `python bench.py --gpus N` launches its
              own N ranks (re-exec under torch.distributed.run on 127.0.0.1) when it is not already running under
-             one; rank 0 prints the line.
+             one; rank 0 prints the line.  Candidate c of the round (c = j * N + rank) is seeded by c alone, so
+             `selected_candidate` does not depend on N.
+             Rehearsal on a 1-GPU box: `--gpus 2 --ranks-share-gpu --dist-backend gloo` runs both ranks on cuda:0
+             (2 x 38 GB of 288 GB) with the collectives over gloo -- the same launch, model build, barriers, score
+             exchange and rank-0 line as the 8-GPU run, at ~0.5x per-rank throughput (NOT a scaling number).
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
     roofline     -- the dominant kernel class (the 256x256-tile bf16 MFMA GEMM; persistent whole-tile launches of the ping-pong loop): algorithmic FLOPs of its launches /
@@ -135,6 +139,54 @@ def isolated_shapes(dev, S_txt, S_img, D, mlp, heads, nd, ns):
 
 
 NOMINAL_MHZ = 2400.0   # the clock the 2.5 PFLOP/s dense bf16 peak is quoted at
+
+
+def attention_table(dev, pipe, S, heads):
+    """Which attention kernel the timed run used and what the alternatives cost (VERDICT r2 / ADVICE r2: the headline must
+    carry its floor).  The engine hands the bounded-score kernel the bound it derives from the checkpoint's norm_q / norm_k
+    weights (here synthetic, ~1); a checkpoint whose bound exceeds 100 takes the LAGGED-MAX kernel instead (exact for any
+    weights) -- `isolated_us` prices that kernel, the bounded one and the online-softmax kernel on the same operands."""
+    from reflectionflow_amd import _lib as L, ops
+    bounds = []
+    try:
+        for blk in list(pipe.transformer.transformer_blocks) + list(pipe.transformer.single_transformer_blocks):
+            a = blk.attn
+            wq = [a.norm_q.weight] + ([a.norm_added_q.weight] if getattr(a, "norm_added_q", None) is not None else [])
+            wk = [a.norm_k.weight] + ([a.norm_added_k.weight] if getattr(a, "norm_added_k", None) is not None else [])
+            bounds.append(ops.qk_score_bound(tuple(wq), tuple(wk)))
+    except Exception:           # noqa: BLE001 -- reporting only
+        pass
+    g = torch.Generator(device=dev).manual_seed(3)
+    q, k, vt, s_pad = ops.alloc_attn_operands(heads, S, dev)
+    q[:, :S] = (torch.randn(heads, S, 128, generator=g, device=dev) * ops.QK_PRESCALE).to(torch.bfloat16)
+    k[:, :S] = torch.randn(heads, S, 128, generator=g, device=dev).to(torch.bfloat16)
+    vt.copy_(torch.randn(vt.shape, generator=g, device=dev).to(torch.bfloat16))
+    out = torch.empty(S, heads * 128, dtype=torch.bfloat16, device=dev)
+    flops = 4.0 * S * S * 128 * heads
+    tab = {}
+    kernels = [("bounded_16x16x32", L.RF_ATTN_BOUNDED16, 25.0), ("lagged_max_16x16x32", L.RF_ATTN_LAGGED16, 0.0),
+               ("online_softmax_256", L.RF_ATTN_ONLINE256, 0.0)]
+    if S % 256 != 0:
+        kernels = kernels[2:]
+    for name, kern, bound in kernels:
+        for _ in range(3):
+            ops.attention(q, k, vt, S, out=out, q_prescaled=True, score_bound=bound, kernel=kern)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.attention(q, k, vt, S, out=out, q_prescaled=True, score_bound=bound, kernel=kern)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        tab[name] = {"us": round(us, 1), "tflops": round(flops / us / 1e6, 1)}
+    res = {"qk_bound_max_over_blocks": round(max(bounds), 2) if bounds else None,
+           "bounded_kernel_precondition": "qk_bound <= 100, i.e. max|norm_q.weight| * max|norm_k.weight| <= ~6.0",
+           "kernel_of_the_timed_run": "bounded-score (qk_bound <= 100)" if bounds and max(bounds) <= 100 else "lagged-max",
+           "fallback_when_bound_exceeds_100": "lagged_max_16x16x32 (exact for any q, k; no online softmax)",
+           "isolated_us": tab}
+    if "bounded_16x16x32" in tab and "lagged_max_16x16x32" in tab:
+        res["fallback_cost_frac_on_attention"] = round(tab["lagged_max_16x16x32"]["us"] / tab["bounded_16x16x32"]["us"] - 1.0, 4)
+    return res
 
 
 def clock_probe(which):
@@ -364,6 +416,11 @@ def main():
     ap.add_argument("--no-isolated-shapes", action="store_true")
     ap.add_argument("--small", action="store_true", help="debug: 2+2-block model (NOT a valid bench result)")
     ap.add_argument("--launch-check", action="store_true", help="CPU plumbing test of the N-rank launch (not a bench)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=None,
+                    help="process-group backend for N > 1 (default nccl = RCCL); gloo for the shared-GPU rehearsal")
+    ap.add_argument("--ranks-share-gpu", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (plumbing check, not a scaling measurement)")
+    ap.add_argument("--no-attention-table", action="store_true")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -378,11 +435,16 @@ def main():
     from reflectionflow_amd.flux.generate import generate
 
     _lib.load()
-    shard = search.init_distributed()
+    local = 0 if args.ranks_share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if args.ranks_share_gpu and args.dist_backend in (None, "nccl") and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--ranks-share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    if args.ranks_share_gpu:
+        os.environ["LOCAL_RANK"] = "0"        # init_distributed() binds the rank to cuda:LOCAL_RANK for nccl
+    shard = search.init_distributed(args.dist_backend)
     if shard.world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world_size}")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    backend = torch.distributed.get_backend() if shard.world_size > 1 else None
     dev = torch.device("cuda", local)
 
     cfg = dict(num_layers=2, num_single_layers=2) if args.small else {}
@@ -395,7 +457,10 @@ def main():
     pe = torch.randn(1, S_txt, tr.config.joint_attention_dim, generator=g).to(dev).to(torch.bfloat16)
     pooled = torch.randn(1, tr.config.pooled_projection_dim, generator=g).to(dev).to(torch.bfloat16)
     n_total = (args.warmup + args.steps)
-    seeds = [1000 * shard.rank + i for i in range(n_total)]
+    # candidate c = j * world + rank of the timed round is seeded by c alone (world-size independent selection); warm-up
+    # latents use seeds outside that range
+    seeds = [10 ** 6 + 1000 * shard.rank + i for i in range(args.warmup)] + \
+            [7919 * (j * shard.world_size + shard.rank) + 13 for j in range(args.steps)]
     noises = get_noises(2 ** 31 - 1, n_total, args.res, args.res, device=dev, dtype=torch.bfloat16, seeds=seeds)
 
     def one_latent(seed, steps=T):
@@ -416,17 +481,23 @@ def main():
     outs = []
     for i in range(args.steps):
         outs.append(one_latent(seeds[args.warmup + i]))
-    # round boundary: score this rank's candidates, exchange {score,label} (RCCL all-gather), top-k everywhere
+    # round boundary: ONE batched verifier call on the device for this rank's candidates (search.stub_score_batch: the
+    # score_batch contract a real on-device verifier plugs into), ONE all-gather of the 8-byte {f32 score, i32 label}
+    # records (RCCL), the same top-k on every rank
     n_round = args.steps * shard.world_size
-    for j, o in enumerate(outs):
-        local_scores[j * shard.world_size + shard.rank] = search.stub_verifier(o, seeds[args.warmup + j])
-    scores = search.allgather_scores(shard, n_round, local_scores)
+    t_rb = time.perf_counter()
+    sc, lab = search.stub_score_batch(torch.stack([o.reshape(-1, o.shape[-1]) for o in outs]), seeds[args.warmup:])
+    s_all, l_all = search.allgather_score_tensors(shard, n_round, sc, lab,
+                                                  device=dev if backend == "nccl" else torch.device("cpu"))
+    scores = [(float(a), int(b)) for a, b in zip(s_all.tolist(), l_all.tolist())]
     best = search.select_topk(scores, 1)
     torch.cuda.synchronize()
+    round_boundary_s = time.perf_counter() - t_rb        # includes draining the last candidate's kernels on this rank
     barrier()
     dt = time.perf_counter() - t0
     if shard.world_size > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        # MAX over ranks: a device tensor over RCCL, a host tensor over gloo (gloo has no GPU all_reduce here)
+        tmax = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     assert all(torch.isfinite(o.float()).all() for o in outs), "non-finite latents"
@@ -449,8 +520,12 @@ def main():
                        "parallelism": f"candidate-parallel x{shard.world_size}, weights replicated"},
             "whole_path": {"tflop_per_forward": round(f_fwd / 1e12, 2), "achieved_tflops_per_gpu": round(step_tflops / shard.world_size, 1),
                            "frac_of_bf16_mfma_peak": round(step_tflops / shard.world_size / PEAK_BF16_TFLOPS, 4)},
-            "selected_candidate": best[0],
+            "selected_candidate": best[0], "selected_seed": 7919 * best[0] + 13,
+            "round_boundary_ms": round(round_boundary_s * 1e3, 2),
+            "dist": {"backend": backend, "ranks_share_gpu": bool(args.ranks_share_gpu)} if shard.world_size > 1 else None,
         }
+        if args.ranks_share_gpu:
+            res["INVALID"] = "rehearsal: all ranks on one GPU (plumbing check, not a scaling measurement)"
         if args.small:
             res["INVALID"] = "debug model (--small), not the BASELINE workload"
         if shard.world_size == 1:
@@ -459,6 +534,8 @@ def main():
                                                        dt / args.steps * 1e3 / T, (S_txt, S_img, D, mlp))
                 if not args.no_isolated_shapes:
                     res["roofline"]["isolated_shapes"] = isolated_shapes(dev, S_txt, S_img, D, 4 * D, heads, nd, ns)
+            if not args.no_attention_table:
+                res["attention"] = attention_table(dev, pipe, S_txt + S_img, heads)
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(S_txt, S_img, T, D, heads, nd, ns)
         print(json.dumps(res), flush=True)

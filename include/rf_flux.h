@@ -58,6 +58,17 @@ typedef enum rf_epilogue {
   RF_EPI_QKV_GELU = 4   /* cols < n_split: QKV; cols >= n_split: GELU -> out  (single block fused) */
 } rf_epilogue;
 
+/* How a launch is cut into workgroups.  AUTO is what every product caller passes; the explicit values exist so that tests
+ * (and a caller who knows better) can pin a schedule PER LAUNCH -- the library has no process-global kernel switch. */
+typedef enum rf_gemm_schedule {
+  RF_SCHED_AUTO = 0,        /* by shape: 128x128 tiles for small problems, 256x256 otherwise, stream-K below 83 % round fill */
+  RF_SCHED_TILE128 = 1,     /* 128x128x64 tiles (split-K over the grid when it qualifies and scratch is attached)           */
+  RF_SCHED_TILE256 = 2,     /* 256x256x64 tiles, one per workgroup, never stream-K                                          */
+  RF_SCHED_STREAMK = 3,     /* 256x256 stream-K whenever feasible (needs splitk_ws; else as TILE256)                        */
+  RF_SCHED_PERSISTENT = 4,  /* one persistent workgroup per CU walking whole 256x256 tiles (needs splitk_ws)                */
+  RF_SCHED_PLAIN256 = 5     /* 256x256 tiles on the plain double-buffered loop: bit-exact reference of the ping-pong loops  */
+} rf_gemm_schedule;
+
 typedef struct rf_kseg {
   const void* A; int64_t lda;         /* [M x K] activations */
   const void* W; int64_t ldw;         /* [N x K] weights     */
@@ -95,6 +106,8 @@ typedef struct rf_gemm_desc {
   float q_scale;                      /* QKV: multiply the q rows by this (fp32, before the one bf16 rounding);
                                          0 = 1.0.  The engine folds softmax_scale*log2(e) in here and tells
                                          rf_attention_fwd via q_prescaled, saving a multiply per score. */
+  int32_t schedule;                   /* rf_gemm_schedule; 0 = RF_SCHED_AUTO */
+  int32_t _pad;
   /* optional GEMM scratch (caller-owned, 16-byte aligned; one per stream).  Layout: [0, 4096) flags, then fp32
    * partial tiles.  The first 4 KiB must be ZERO before the first launch that uses the buffer; every launch
    * leaves them zero again.  With it the library may
@@ -153,22 +166,55 @@ int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad
  *         whatever the activations are (rf_*_block_weights.qk_bound).  With a bound <= 100, no bias/mask, S % 64 == 0
  *         and a prescaled q the library runs the bounded-score kernel: softmax is shift invariant, so P = exp2(s)
  *         needs no running maximum, no exchange and no rescaling of O (bf16 P / fp32 O,l have the exponent range).
- *         A violated guarantee gives inf/NaN -- pass 0 when in doubt.
+ *         A violated guarantee gives inf/NaN -- pass 0 when in doubt.  Without a usable bound (0, or > 100) the same
+ *         launches take the LAGGED-MAX form of that kernel (rf_attn_desc below), which is exact for any q, k and within a
+ *         few per cent of the bounded form's speed, so a checkpoint's norm weights no longer decide how fast attention runs.
  * ---------------------------------------------------------------------------------- */
 int rf_attention_fwd(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                      int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
                      float cross_bias, float scale, int32_t q_prescaled, float score_bound, void* stream);
-/* The same call with scratch: when the bounded-score kernel applies and its grid of heads * S/256 workgroups would
+/* The same call with scratch: when a shift-free kernel applies and its grid of heads * S/256 workgroups would
  * fill < 80 % of its rounds of CUs (S = 5632: 528 workgroups = 2.06 rounds run as 3), the library runs one persistent
  * workgroup per CU over equal shares of the (query block, key range) space; a block whose keys were split between
- * two workgroups leaves its partial (O, l) in `ws` and a second launch adds them (no rescaling: there is no running
- * maximum).  ws: 16-byte aligned device memory, >= rf_attention_ws_bytes() bytes, may be shared with any other
+ * two workgroups leaves its partial (O, l, m) in `ws` and a second launch adds them.
+ * ws: 16-byte aligned device memory, >= rf_attention_ws_bytes() bytes, may be shared with any other
  * scratch that is idle during this call (the engine passes its GEMM scratch); NULL / too small = rf_attention_fwd. */
 int rf_attention_fwd_ws(const void* q, const void* k, const void* vt, void* out, int32_t heads,
                         int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
                         float cross_bias, float scale, int32_t q_prescaled, float score_bound,
                         void* ws, int64_t ws_bytes, void* stream);
 int64_t rf_attention_ws_bytes(void);   /* scratch size that enables the split launch on the current device */
+
+/* Descriptor form of the same call (rf_attention_fwd / _ws fill one with kernel = RF_ATTN_AUTO).  `kernel` pins the kernel
+ * PER LAUNCH (tests, A/B); a request whose preconditions do not hold FAILS (RF_ERR_UNSUPPORTED) instead of running something
+ * else.  AUTO: no mask / bias, S % 256 == 0 and a prescaled q take a shift-free kernel -- the bounded form when the caller
+ * proves 0 < score_bound <= 100, otherwise the LAGGED-MAX form, which needs no bound at all: P = exp2(s - m) with a per-row
+ * maximum m that starts as the exact maximum of the first key tile and is re-centred only when a tile's row sums exceed
+ * lag_thresh (2^30; the sums are formed anyway), so the result is the exact softmax to rounding for ANY q, k -- the speed of
+ * the path no longer depends on the norm weights of the checkpoint.  Everything else runs the online-softmax kernels. */
+typedef enum rf_attn_kernel {
+  RF_ATTN_AUTO = 0,
+  RF_ATTN_ONLINE128 = 1,        /* online softmax, 4 waves x 32 queries (masks, bias, ragged S)            */
+  RF_ATTN_ONLINE256 = 2,        /* online softmax, 8 waves x 32 queries, K / VT rings                      */
+  RF_ATTN_BOUNDED32 = 4,        /* bounded score, 32x32x16 MFMAs (AUTO picks it at >= 8192 keys)           */
+  RF_ATTN_BOUNDED16 = 5,        /* bounded score, 16x16x32 MFMAs                                           */
+  RF_ATTN_BOUNDED16_SPLIT = 6,  /* ... as one persistent workgroup per CU + combine launch (needs ws)      */
+  RF_ATTN_LAGGED16 = 8,         /* lagged-max, 16x16x32 MFMAs: no bound needed                             */
+  RF_ATTN_LAGGED16_SPLIT = 9    /* ... split launch (needs ws)                                             */
+} rf_attn_kernel;
+typedef struct rf_attn_desc {
+  const void *q, *k, *vt; void* out;  /* as rf_attention_fwd */
+  int32_t heads, S, s_pad, n_main;
+  int64_t ldo;
+  int32_t mode, q_prescaled;
+  float cross_bias, scale, score_bound;
+  float lag_thresh;                   /* lagged-max kernels: re-centre a row when a lane's 16-key sum of P exceeds this;
+                                         0 = 2^30.  (Tests sweep it: any value gives the same softmax to rounding.) */
+  int32_t kernel;                     /* rf_attn_kernel */
+  int32_t _pad;
+  void* ws; int64_t ws_bytes;         /* optional scratch, see rf_attention_fwd_ws */
+} rf_attn_desc;
+int rf_attention(const rf_attn_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm(no affine, eps) + (1+scale)*x + shift, row-wise over D
@@ -332,7 +378,7 @@ int rf_time_gemm_w8a8(const rf_gemm_desc* d, int32_t iters, float* us, void* str
 typedef enum rf_kernel_class {
   RF_KC_GEMM_MAIN = 0,   /* 256x256-tile MFMA GEMM launches (tile-per-block ping-pong loop and stream-K) */
   RF_KC_GEMM_SMALL = 1,  /* 128x128-tile launches (embedders, LoRA down-projections incl. split-K + reduce) */
-  RF_KC_ATTN = 2,        /* rf_attention_fwd */
+  RF_KC_ATTN = 2,        /* rf_attention / rf_attention_fwd */
   RF_KC_ROWOP = 3,       /* LayerNorm+modulate, RMSNorm+RoPE, Euler, SiLU, add */
   RF_KC_GEMM_W8 = 4,     /* fp8-weight GEMM launches (rf_gemm_w8a8) */
   RF_KC_QUANT = 5,       /* activation quantisation row kernels of the fp8 path */

@@ -11,9 +11,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
+# rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
+RF_SCHED_AUTO, RF_SCHED_TILE128, RF_SCHED_TILE256, RF_SCHED_STREAMK, RF_SCHED_PERSISTENT, RF_SCHED_PLAIN256 = range(6)
+# rf_attn_kernel (rf_attn_desc.kernel)
+RF_ATTN_AUTO, RF_ATTN_ONLINE128, RF_ATTN_ONLINE256 = 0, 1, 2
+RF_ATTN_BOUNDED32, RF_ATTN_BOUNDED16, RF_ATTN_BOUNDED16_SPLIT, RF_ATTN_LAGGED16, RF_ATTN_LAGGED16_SPLIT = 4, 5, 6, 8, 9
 
 
 class RFError(RuntimeError):
@@ -36,7 +41,16 @@ class rf_gemm_desc(C.Structure):
     _fields_ = [("N", C.c_int32), ("epilogue", C.c_int32), ("num_groups", C.c_int32), ("n_split", C.c_int32),
                 ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("heads", C.c_int32), ("s_pad", C.c_int32),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("norm_eps", C.c_float), ("q_scale", C.c_float),
+                ("schedule", C.c_int32), ("_pad", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("g", rf_gemm_group * 4)]
+
+
+class rf_attn_desc(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("out", C.c_void_p),
+                ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("n_main", C.c_int32),
+                ("ldo", C.c_int64), ("mode", C.c_int32), ("q_prescaled", C.c_int32),
+                ("cross_bias", C.c_float), ("scale", C.c_float), ("score_bound", C.c_float), ("lag_thresh", C.c_float),
+                ("kernel", C.c_int32), ("_pad", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
 
 
 class rf_w8(C.Structure):
@@ -101,6 +115,7 @@ _SIGS = {
     "rf_attention_fwd_ws": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_float, C.c_float, C.c_int32, C.c_float, _P, C.c_int64, _P]),
     "rf_attention_ws_bytes": (C.c_int64, []),
+    "rf_attention": (C.c_int, [C.POINTER(rf_attn_desc), _P]),
     "rf_layernorm_modulate": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, _P]),
     "rf_euler_step": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
     "rf_silu": (C.c_int, [_P, _P, C.c_int64, _P]),
@@ -121,17 +136,22 @@ _SIGS = {
                                  C.POINTER(C.c_int32)]),
 }
 RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant")
-# test / tuning hook, not part of the declared drop-in surface
-_EXTRA_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
-               "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
-               "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_attn_knock": (C.c_int, [C.c_int]), "rf_debug_attn_v6": (C.c_int, [C.c_int]), "rf_debug_last_attn_path": (C.c_int, []),
-               "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_last_gemm_path": (C.c_int, []),
-               "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
-               "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]),
-               "rf_debug_gemm_mi16": (C.c_int, [C.c_int]), "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]), "rf_debug_gemm_nt_store": (C.c_int, [C.c_int]),
+# read-only introspection (tests, bench); not part of the declared drop-in surface.  librf_flux.so exports NO kernel-selecting
+# switch: tests pin a kernel per launch through rf_gemm_desc.schedule / rf_attn_desc.kernel.
+_EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_clock_probe": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-               "rf_debug_gemm_timeline": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_void_p, C.c_void_p]),
                "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)])}
+# librf_flux_exp.so only (make -C reflectionflow_amd/csrc EXPERIMENTS=1; tools/kb_*.py): the A/B switches of the studies in profiles/
+_EXP_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
+             "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
+             "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_attn_knock": (C.c_int, [C.c_int]),
+             "rf_debug_attn_v6": (C.c_int, [C.c_int]), "rf_debug_attn_lag": (C.c_int, [C.c_int]),
+             "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
+             "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]), "rf_debug_gemm_mi16": (C.c_int, [C.c_int]),
+             "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]),
+             "rf_debug_gemm_nt_store": (C.c_int, [C.c_int]),
+             "rf_debug_gemm_timeline": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_void_p, C.c_void_p])}
+EXP_LIB_PATH = os.path.join(_HERE, "librf_flux_exp.so")
 
 _lib = None
 
@@ -161,6 +181,35 @@ def load():
         raise RFError("librf_flux was not built for gfx950")
     _lib = lib
     return lib
+
+
+_product = None
+
+
+def load_experiments():
+    """tools/ and tests/test_experiments_gpu.py only: make librf_flux_exp.so (same entry points + the rf_debug_* A/B switches)
+    the library `load()` returns.  The product never calls this; `unload_experiments()` switches back."""
+    global _lib, _product
+    if _lib is not None and getattr(_lib, "_rf_exp", False):
+        return _lib
+    if not os.path.exists(EXP_LIB_PATH):
+        raise RFError(f"{EXP_LIB_PATH} not found: build it with `make -C reflectionflow_amd/csrc EXPERIMENTS=1`")
+    import torch  # noqa: F401
+    lib = C.CDLL(EXP_LIB_PATH)
+    for name, (res, args) in {**_SIGS, **_EXTRA_SIGS, **_EXP_SIGS}.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.rf_abi_version() != ABI_VERSION:
+        raise RFError(f"librf_flux_exp ABI {lib.rf_abi_version()} != binding {ABI_VERSION}: rebuild")
+    lib._rf_exp = True
+    _product, _lib = _lib, lib
+    return lib
+
+
+def unload_experiments():
+    global _lib, _product
+    if _lib is not None and getattr(_lib, "_rf_exp", False):
+        _lib, _product = _product, None
 
 
 def declared_symbols():

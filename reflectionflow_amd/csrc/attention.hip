@@ -19,12 +19,15 @@
 //     permutation (bits 2,3 of the key index swapped), so no in-kernel transpose or permute
 //     of V or P is needed.
 //
-// Map of this file.  attn_fwd_kernel (v1: the design above, online softmax; masks, bias, ragged S) and attn_fwd_kernel_v2
-// (8 waves x 32 queries, K / VT rings) are the general kernels.  With a proven score bound, no mask / bias, a prescaled q and
-// S % 256 == 0 the bounded-score kernels run instead (no running maximum): SHIPPED attn5_body = attn_fwd_kernel_v5
-// (16x16x32 MFMAs) and its split launch attn_fwd_kernel_v5sk + attn5_combine_kernel (rf_attention_fwd_ws).  KEPT FOR A/B
-// behind rf_debug_* switches: attn_fwd_kernel_v4 (the 32x32x16 form v5 was derived from), attn_fwd_kernel_v5k (knock-outs),
-// attn6_body = attn_fwd_kernel_v6 (one wave per SIMD, 64 queries per wave: slower).  profiles/r02_attention.md has the story.
+// Map of this file (all of it ships in librf_flux.so).  attn_fwd_kernel (v1: the design above, online softmax; masks, bias,
+// ragged S) and attn_fwd_kernel_v2 (8 waves x 32 queries, K / VT rings) are the general kernels.  With no mask / bias, a
+// prescaled q and S % 256 == 0 the shift-free kernels run instead (no per-tile running maximum): attn5_body =
+// attn_fwd_kernel_v5<LAG> (16x16x32 MFMAs) and its split launch attn_fwd_kernel_v5sk<LAG> + attn5_combine_kernel; LAG = false
+// needs a proven score bound <= 100 (P = exp2(s)), LAG = true needs nothing (P = exp2(s - m) with a LAGGED row maximum m that
+// only moves when a tile overflows 2^30 -- checked on the row sums the kernel forms anyway).  attn_fwd_kernel_v4 is the
+// 32x32x16 form of the bounded kernel (shipped above 8192 keys).  The kernel of a launch is picked from the shape or by the
+// CALLER per launch (rf_attn_desc.kernel) -- no process-global switch.  Knock-out and one-wave-per-SIMD variants:
+// experiments/attention_exp.inc (-DRF_EXPERIMENTS only).  profiles/r02_attention.md / r03_attention.md have the story.
 #include "common.hpp"
 #include <type_traits>
 #include <utility>
@@ -38,6 +41,7 @@ struct AttnParams {
   int64_t ldo;
   float cross_bias_l2;  // bias * log2(e)
   float sl2;            // softmax scale * log2(e)
+  float lag_thresh;     // lagged-max kernels: a lane's 16-key row sum above this re-centres the row (default 2^30)
 };
 
 constexpr int ATT_QBLK = 128;        // query rows per workgroup (4 waves x 32)
@@ -755,10 +759,20 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
 
 // One (head, 256-query block) over the key tiles [t0, t0 + nt), nt % 4 == 0.  partial == nullptr: the range is the whole
 // key axis -> normalise and store the output rows.  Otherwise (split launch): leave the raw O^T accumulators and row sums of
-// this key range in the 132 KiB slot `partial` ([16 quads][512 threads] x 16 B, then [2][512] floats), thread-linear:
-// attn5_combine_kernel adds the slots of a block's pieces thread by thread and finishes it -- with no running maximum the
-// partial sums of disjoint key ranges simply add.
-template <bool PROBE, int KNOCK = 0>   // KNOCK (timing diagnostics, wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing
+// this key range in the 136 KiB slot `partial` ([16 quads][512 threads] x 16 B, then l [2][512] and m [2][512] floats),
+// thread-linear: attn5_combine_kernel adds the slots of a block's pieces thread by thread (scaled by exp2(m_piece - max m):
+// exactly 1 without LAG, where every m is 0) and finishes it.
+//
+// LAG = true: the weight-independent form.  Every query row carries a LAGGED maximum m (exp2 domain): P = exp2(s - m), and -m
+// rides into the score MFMAs as their C operand (a persistent f32x4 per q-tile: no VALU).  m starts as the exact row maximum
+// of the piece's first key tile; afterwards it moves only when a tile overflows: a lane's 16-key row sum (which the kernel
+// forms anyway) above lag_thresh (2^30) -- one compare per q-tile and tile.  The wave that trips re-centres ALONE, between the
+// two halves of the tile: it recomputes the tile's raw scores from the K ring slot (still resident), takes their exact maximum,
+// scales O and l by exp2(m_old - m_new) -- PV(t-1) is complete at that point, P(t) not yet packed, so everything at the old
+// scale is scaled exactly once (cdna_hip_programming.md T13 hazard) -- and re-exponentiates the tile against m_new.  fp32 l / O
+// and bf16 P hold 2^30 * S * |V| with room to spare, so between re-centrings nothing is lost; on i.i.d. data the slow path
+// never runs after the first tile.  With LAG = false, m == 0 throughout (the caller's proven bound |s| <= 100 makes that safe).
+template <bool PROBE, bool LAG, int KNOCK = 0>   // KNOCK (timing diagnostics, wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing
 __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
                                            const int head, const int qb, const int t0, const int nt, float* partial, ClkProbe& clk) {
   const int l15 = lane & 15, g = lane >> 4;
@@ -850,6 +864,26 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
       for (int qt = 0; qt < 2; ++qt) s_cur[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * 2 + qt], 0, 0, 0);
     }
   }
+  // -m of the two q-tiles, as the C operand of the score MFMAs (LAG); a query's four lanes (l15 + 16 g) hold the same value
+  f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if constexpr (LAG) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = s_cur[qt][0];
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_cur[bt * 2 + qt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_cur[bt * 2 + qt][r] -= mx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) negm[qt][r] = -mx;
+    }
+  }
 
   auto tile = [&](const int t, auto ts_tag) {
     constexpr int TS = decltype(ts_tag)::value;
@@ -901,6 +935,61 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("" : "+v"(psum[0]), "+v"(psum[1]));
+    if constexpr (LAG) {
+      // a P above ~2^30 shows in its lane's row sum (inf included; the negated compare also catches NaN)
+      const bool hot = !(psum[0] <= p.lag_thresh) || !(psum[1] <= p.lag_thresh);
+      if (__builtin_expect(__any(hot), 0)) {
+        // ---- re-centre (rare, wave-uniform, no barrier): K(t) is still in ring slot TS --------------------------------
+        float mx[2] = {-__builtin_huge_valf(), -__builtin_huge_valf()};
+        auto raw_tile = [&](const int bt, f32x4 (&a)[2]) {   // a += K(t)[(b, T) = bt] Q^T for both q-tiles
+#pragma unroll
+          for (int ds = 0; ds < 4; ++ds) {
+            const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + TS * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) a[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], a[qt], 0, 0, 0);
+          }
+        };
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+          f32x4 a[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          raw_tile(bt, a);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx[qt] = fmaxf(mx[qt], a[qt][r]);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          float m = mx[qt];
+          m = fmaxf(m, __shfl_xor(m, 16));
+          m = fmaxf(m, __shfl_xor(m, 32));
+          const float m_old = -negm[qt][0];
+          const float m_new = fmaxf(m_old, m);
+          const float f = __builtin_amdgcn_exp2f(m_old - m_new);   // <= 1; exactly 1 for the q-tile that did not trip
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][qt][r] *= f;
+          l_run[qt] *= f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) negm[qt][r] = -m_new;
+          psum[qt] = 0.f;
+        }
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+          f32x4 a[2] = {negm[0], negm[1]};
+          raw_tile(bt, a);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = __builtin_amdgcn_exp2f(a[qt][r]);
+              s_cur[bt * 2 + qt][r] = e;
+              psum[qt] += e;
+            }
+        }
+      }
+    }
     l_run[0] += psum[0];
     l_run[1] += psum[1];
     // ---- second half: next tile's scores (8 groups of 4 MFMA) | pack P tile G-8 into the PV operand ----------------
@@ -909,7 +998,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
       load_group(std::integral_constant<int, G + 1>{});
       constexpr int bt = (G - 8) / 2;
       constexpr int dsb = ((G - 8) % 2) * 2;
-      if constexpr (dsb == 0) {
+      if constexpr (dsb == 0 && !LAG) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -918,8 +1007,16 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < 2; ++qt) {
+          // LAG: the chain of a score tile starts from -m (C operand = the persistent negm registers, D = the tile)
+          if constexpr (LAG && dsb == 0) {
+            if (e == 0) {
+              s_nxt[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][e], qf[qt][dsb + e], negm[qt], 0, 0, 0);
+              continue;
+            }
+          }
           s_nxt[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][e], qf[qt][dsb + e], s_nxt[bt * 2 + qt], 0, 0, 0);
+        }
       if constexpr (!(KNOCK & 2)) {
         constexpr int ti = G - 8;                       // score tile (b, T, qt) = (ti >> 2, (ti >> 1) & 1, ti & 1)
         uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
@@ -965,21 +1062,14 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
       for (int qt = 0; qt < 2; ++qt) *(f32x4*)(dst + (dt * 2 + qt) * 2048) = oacc[dt][qt];
     partial[16 * 2048 + tid] = l_run[0];
     partial[16 * 2048 + 512 + tid] = l_run[1];
+    partial[16 * 2048 + 1024 + tid] = -negm[0][0];   // the piece's lagged row maxima (0 without LAG)
+    partial[16 * 2048 + 1536 + tid] = -negm[1][0];
     return;
   }
   attn5_finish(p, oacc, l_run, lane, w, head, qb);
 }
 
-template <int KNOCK>
-__global__ __launch_bounds__(512) void attn_fwd_kernel_v5k(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ClkProbe clk;
-  clk.begin();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  attn5_body<true, KNOCK>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
-}
+template <bool LAG>
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
@@ -987,278 +1077,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  attn5_body<true>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
+  attn5_body<true, LAG>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
 }
 
-// =================================================================================================
-// v6 -- the bounded-score kernel with ONE wave per SIMD: 4 waves x 64 queries.  Knock-outs of v5 (tools/kb_attn_knock.py)
-// show its fragment reads cost 900 of its 3050 clocks per key tile: eight waves each read the whole K and VT tile, 256 KiB
-// per tile and CU = 2048 cycles of the 128 B/clk LDS, as long as the tile's MFMAs.  A wave that owns 64 queries (four
-// q-tiles) uses every K / VT fragment for four MFMAs instead of two: half the LDS traffic per flop.  Its 128 O^T + 2 x 64
-// score + 64 Q + 32 P registers need the 512-register budget of a single wave per SIMD, which hides nothing -- so, with the
-// lessons of the one-wave-per-SIMD GEMM (profiles/r02_gemm_power.md section 6): a group is four MFMAs on ONE fragment
-// read a group ahead into a double buffer; the tile's eight LDS-DMA pieces per wave go out one per four groups, wave w in
-// the groups G % 4 == w (the loop is specialised per wave, so the slot is straight-line code); exp2 / sums / packing ride
-// between the MFMAs as in v5.  Rings, layouts, swizzles, the key-row permutation and the output are v5's.
-// RESULT: bit-identical to v5, at 2.2-2.35 GHz instead of 2.0 (less LDS power), and 12-20 % slower: ~4050 clocks per key
-// tile for 2048 of MFMA.  A deeper fragment read-ahead changes nothing; what a lone wave cannot hide is its own VALU stream
-// (64 exp2 + 64 add + 64 accumulator reads + 32 cvt per tile): a 16-cycle MFMA leaves a 12-cycle issue shadow, a
-// transcendental does not fit in it, and there is no second wave to take the matrix pipe meanwhile.  Kept as an experiment
-// (rf_debug_attn_v6(1)); v5 ships.
-#define RF_ATT6_WAIT_BARRIER(allowed)                                            \
-  do {                                                                           \
-    if ((allowed) >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         \
-    else if ((allowed) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
-    __builtin_amdgcn_s_barrier();                                                \
-  } while (0)
-
-template <int WV>
-__device__ __forceinline__ void attn6_body(const AttnParams& p, char* smem, const int lane, const int head, const int qb, ClkProbe& clk) {
-  constexpr int w = WV;
-  const int l15 = lane & 15, g = lane >> 4;
-  const int S = p.S;
-  const int nt = S / ATT_KV;
-  const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
-  const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
-  const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
-  char* const kring = smem;
-  char* const vring = smem + ATT4_RING * 16384;
-
-  bf16x8 qf[4][4];   // [q tile][d step of 32]: query w*64 + qt*16 + l15, d = 32 ds + 8g .. +8
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    const int q_row = qb * 256 + w * 64 + qt * 16 + l15;
-    const bf16_t* qp = p.q + ((int64_t)head * p.s_pad + (q_row < S ? q_row : S - 1)) * 128 + g * 8;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *(const bf16x8*)(qp + ds * 32);
-  }
-  // DMA pieces: 4 of the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each) per wave
-  uint32_t k_src[4], v_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + w) * 4 + (lane >> 4);
-    const int ksw = (row & 7) | ((row >> 1) & 8);
-    k_src[i] = (uint32_t)(row * 256 + (((lane & 15) ^ ksw) * 16));
-    const int vrow = (i * 4 + w) * 8 + (lane >> 3);
-    v_src[i] = (uint32_t)((vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
-  }
-  auto k_piece = [&](int i, int t, int slot) {
-    RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 4 + w) * 1024), k_src[i], t * (ATT_KV * 256));
-  };
-  auto v_piece = [&](int i, int t, int slot) {
-    RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 4 + w) * 1024), v_src[i], t * (128 * 64 * 2));
-  };
-  const char* k_rd[4];
-  const char* v_rd[2];
-  const int krow = (l15 & 7) | ((l15 & 8) << 1);
-#pragma unroll
-  for (int ds = 0; ds < 4; ++ds) k_rd[ds] = kring + krow * 256 + (((ds * 4 + g) ^ l15) << 4);
-#pragma unroll
-  for (int b = 0; b < 2; ++b) v_rd[b] = vring + l15 * 128 + (((b * 4 + g) ^ ((l15 >> 1) & 7)) << 4);
-
-  f32x4 oacc[8][4];   // O^T tiles [d tile][q tile]
-#pragma unroll
-  for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[dt][qt][r] = 0.f;
-  float l_run[4] = {0.f, 0.f, 0.f, 0.f};
-  f32x4 s_cur[16], s_nxt[16];   // score tiles, index ti = bt*4 + qt with bt = b*2 + T
-  bf16x8 pf[8];                  // P(t-1) B-operand fragments [b*4 + qt]: words T*2, T*2+1 from tile (b*2 + T, qt)
-
-  {  // V ring slot 3 stands in for V(-1): tile 0 multiplies it with P(-1) = 0, so it must be finite
-    const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(vring + 3 * 16384 + (i * 4 + w) * 1024 + lane * 16) = z;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf[i][j] = (bf16_t)0.f;
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) k_piece(i, 0, 0);
-  if (nt > 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) k_piece(i, 1, 1);
-  }
-  if (nt > 2) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) k_piece(i, 2, 2);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v_piece(i, 0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill above
-  {
-    const int allowed = 4 * ((nt > 1) + (nt > 2) + 1);   // K0 landed
-    if (allowed == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (allowed == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-#pragma unroll
-  for (int bt = 0; bt < 4; ++bt) {   // (b, T) = (bt >> 1, bt & 1)
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_cur[bt * 4 + qt][r] = 0.f;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
-#pragma unroll
-      for (int qt = 0; qt < 4; ++qt) s_cur[bt * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * 4 + qt], 0, 0, 0);
-    }
-  }
-
-  auto tile = [&](const int t, auto ts_tag) {
-    constexpr int TS = decltype(ts_tag)::value;
-    constexpr int KSLOT = (TS + 1) % 4, VSLOT = (TS + 3) % 4;
-    // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t) (4 pieces each)
-    RF_ATT6_WAIT_BARRIER(4 * ((t + 2 < nt) + 1));
-    __builtin_amdgcn_sched_barrier(0);
-    const bool k_more = t + 3 < nt, v_more = t + 1 < nt;
-    bf16x8 fr[4];   // fragment ring: group G multiplies fr[G & 3], read RA = 3 groups (192 MFMA cycles) earlier -- a lone wave
-                    // per SIMD has nobody to cover an LDS round trip
-    float psum[4] = {0.f, 0.f, 0.f, 0.f};
-    // fragment of group G: G < 16 -> V^T(t-1) [d tile G/2, key block G%2], else K(t+1) [(b, T) = (G-16)/4, d step (G-16)%4]
-    auto load_group = [&](auto gtag) {
-      constexpr int G = decltype(gtag)::value;
-      if constexpr (G < 16) {
-        fr[G & 3] = *(const bf16x8*)(v_rd[G & 1] + VSLOT * 16384 + (G >> 1) * 16 * 128);
-      } else if constexpr (G < 32) {
-        constexpr int bt = (G - 16) >> 2;
-        fr[G & 3] = *(const bf16x8*)(k_rd[(G - 16) & 3] + KSLOT * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
-      }
-    };
-    // this wave's DMA slot: groups G % 4 == WV carry piece G / 4 of the tile's eight (K(t+3) x 4, then V(t+1) x 4)
-    auto dma_slot = [&](auto gtag) {
-      constexpr int G = decltype(gtag)::value;
-      if constexpr ((G & 3) == WV) {
-        constexpr int j = G >> 2;
-        if constexpr (j < 4) {
-          if (__builtin_expect(k_more, 1)) k_piece(j, t + 3, (TS + 3) % 4);
-        } else {
-          if (__builtin_expect(v_more, 1)) v_piece(j - 4, t + 1, KSLOT);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    load_group(std::integral_constant<int, 0>{});
-    load_group(std::integral_constant<int, 1>{});
-    load_group(std::integral_constant<int, 2>{});
-    // ---- first half: pending PV product (16 groups: d tile G/2, key block G%2) | P = exp2(S tile G) + row sums ----
-    static_for(std::make_integer_sequence<int, 16>{}, [&](auto gtag) {
-      constexpr int G = decltype(gtag)::value;
-      load_group(std::integral_constant<int, G + 3>{});
-#pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
-        oacc[G >> 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 3], pf[(G & 1) * 4 + qt], oacc[G >> 1][qt], 0, 0, 0);
-      {
-        float e4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e4[j] = __builtin_amdgcn_exp2f(s_cur[G][j]);
-        RF_PIN4(e4[0], e4[1], e4[2], e4[3]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s_cur[G][j] = e4[j];
-          psum[G & 3] += e4[j];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      dma_slot(gtag);
-    });
-    asm volatile("" : "+v"(psum[0]), "+v"(psum[1]), "+v"(psum[2]), "+v"(psum[3]));
-#pragma unroll
-    for (int qt = 0; qt < 4; ++qt) l_run[qt] += psum[qt];
-    // ---- second half: next tile's scores (16 groups: (b, T) = k/4, d step k%4) | pack P tile k into the PV operand ----
-    static_for(std::make_integer_sequence<int, 16>{}, [&](auto gtag) {
-      constexpr int G = decltype(gtag)::value + 16;
-      load_group(std::integral_constant<int, G + 3>{});
-      constexpr int bt = (G - 16) >> 2;
-      constexpr int ds = (G - 16) & 3;
-      if constexpr (ds == 0) {
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s_nxt[bt * 4 + qt][r] = 0.f;
-      }
-#pragma unroll
-      for (int qt = 0; qt < 4; ++qt)
-        s_nxt[bt * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 3], qf[qt][ds], s_nxt[bt * 4 + qt], 0, 0, 0);
-      {
-        constexpr int ti = G - 16;                      // score tile (bt, qt) = (ti >> 2, ti & 3)
-        uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
-        uint32_t w1 = pack2(s_cur[ti][2], s_cur[ti][3]);
-        asm volatile("" : "+v"(w0), "+v"(w1));
-        constexpr int pi = ((ti >> 2) >> 1) * 4 + (ti & 3), wi = ((ti >> 2) & 1) * 2;
-        u32x4 t4 = __builtin_bit_cast(u32x4, pf[pi]);
-        t4[wi] = w0;
-        t4[wi + 1] = w1;
-        pf[pi] = __builtin_bit_cast(bf16x8, t4);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      dma_slot(std::integral_constant<int, G>{});
-    });
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s_cur[i] = s_nxt[i];
-  };
-  for (int t = 0; t < nt; t += 4) {   // unrolled by the ring size (dispatch guarantees nt % 4 == 0): one exit
-    tile(t, std::integral_constant<int, 0>{});
-    tile(t + 1, std::integral_constant<int, 1>{});
-    tile(t + 2, std::integral_constant<int, 2>{});
-    tile(t + 3, std::integral_constant<int, 3>{});
-  }
-
-  clk.end(g_attn_clk_probe);
-  // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
-  RF_ATT6_WAIT_BARRIER(0);
-  {
-    const int vslot = (nt - 1) % ATT4_RING;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const bf16x8 vf = *(const bf16x8*)(v_rd[b] + vslot * 16384 + dt * 16 * 128);
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * 4 + qt], oacc[dt][qt], 0, 0, 0);
-      }
-  }
-#pragma unroll
-  for (int qt = 0; qt < 4; ++qt) {
-    float l_tot = l_run[qt];
-    l_tot += __shfl_xor(l_tot, 16);
-    l_tot += __shfl_xor(l_tot, 32);
-    const float inv = 1.0f / l_tot;
-    const int q_row = qb * 256 + w * 64 + qt * 16 + l15;
-    if (q_row < S) {
-      bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * g;
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        u32x2 v;
-        v[0] = pack2(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv);
-        v[1] = pack2(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv);
-        *(u32x2*)(orow + dt * 16) = v;
-      }
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void attn_fwd_kernel_v6(const AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ClkProbe clk;
-  clk.begin();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int head = blockIdx.x % p.heads, qb = blockIdx.x / p.heads;
-  switch (w) {   // one specialisation per wave: its DMA slots are straight-line code
-    case 0: attn6_body<0>(p, smem, lane, head, qb, clk); break;
-    case 1: attn6_body<1>(p, smem, lane, head, qb, clk); break;
-    case 2: attn6_body<2>(p, smem, lane, head, qb, clk); break;
-    default: attn6_body<3>(p, smem, lane, head, qb, clk); break;
-  }
-}
+#ifdef RF_EXPERIMENTS
+#include "experiments/attention_exp.inc"
+#endif
 
 // Split launch (rf_attention_fwd_ws with scratch): 432 workgroups at S = 4608 are 1.69 rounds of 256 CUs run as 2, 528 at
 // S = 5632 are 2.06 run as 3.  One persistent workgroup per CU takes an equal share of the (block, 4-tile quad) space
@@ -1272,12 +1096,13 @@ struct AttnSkParams {
   int wpx;       // workgroups per XCD
   float* ws;     // [workgroup][2] slots of ATT5_SLOT floats
 };
-constexpr int ATT5_SLOT = 16 * 2048 + 1024;
+constexpr int ATT5_SLOT = 16 * 2048 + 2048;   // O^T quads, l [2][512], m [2][512]
 
 __device__ __forceinline__ int att5_start(const AttnSkParams& sk, const int wl) {   // first quad of XCD-local workgroup wl
   return (int)((int64_t)wl * (sk.hpx * sk.nqb * sk.nq) / sk.wpx);
 }
 
+template <bool LAG>
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5sk(const AttnParams p, const AttnSkParams sk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
@@ -1297,7 +1122,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5sk(const AttnParams p, 
     // across the loop and spill)
     int tid_i = tid;
     asm volatile("" : "+v"(tid_i));
-    attn5_body<false>(p, smem, tid_i, tid_i & 63, w, head, qb, 4 * q0, 4 * len, partial, clk);
+    attn5_body<false, LAG>(p, smem, tid_i, tid_i & 63, w, head, qb, 4 * q0, 4 * len, partial, clk);
     cur += len;
   }
 }
@@ -1323,16 +1148,27 @@ __global__ __launch_bounds__(512) void attn5_combine_kernel(const AttnParams p, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[dt][qt][r] = 0.f;
   float l_run[2] = {0.f, 0.f};
-  for (; att5_start(sk, wl) < u1; ++wl) {
-    const int s0 = att5_start(sk, wl);
+  auto slot_of = [&](const int wl2) {
+    const int s0 = att5_start(sk, wl2);
     const int piece_begin = s0 > u0 ? s0 : u0;
-    const float* src = sk.ws + (int64_t)(2 * (wl * 8 + x) + (piece_begin == s0 ? 0 : 1)) * ATT5_SLOT;
+    return sk.ws + (int64_t)(2 * (wl2 * 8 + x) + (piece_begin == s0 ? 0 : 1)) * ATT5_SLOT;
+  };
+  // the pieces' lagged maxima (all 0 for the bounded kernel): scale every piece to the largest
+  float mmax[2] = {-__builtin_huge_valf(), -__builtin_huge_valf()};
+  for (int wl2 = wl; att5_start(sk, wl2) < u1; ++wl2) {
+    const float* src = slot_of(wl2);
+    mmax[0] = fmaxf(mmax[0], src[16 * 2048 + 1024 + tid]);
+    mmax[1] = fmaxf(mmax[1], src[16 * 2048 + 1536 + tid]);
+  }
+  for (; att5_start(sk, wl) < u1; ++wl) {
+    const float* src = slot_of(wl);
+    const float f[2] = {__builtin_amdgcn_exp2f(src[16 * 2048 + 1024 + tid] - mmax[0]), __builtin_amdgcn_exp2f(src[16 * 2048 + 1536 + tid] - mmax[1])};
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] += *(const f32x4*)(src + (dt * 2 + qt) * 2048 + tid * 4);
-    l_run[0] += src[16 * 2048 + tid];
-    l_run[1] += src[16 * 2048 + 512 + tid];
+      for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] += *(const f32x4*)(src + (dt * 2 + qt) * 2048 + tid * 4) * f[qt];
+    l_run[0] += src[16 * 2048 + tid] * f[0];
+    l_run[1] += src[16 * 2048 + 512 + tid] * f[1];
   }
   attn5_finish(p, oacc, l_run, lane, w, head, qb);
 }
@@ -1341,44 +1177,42 @@ int read_clk_probe_attn(unsigned long long* h) {
   return hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_clk_probe), 4 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
 }
 
-static int g_attn_v2 = -1;  // -1 = cost model, 0 / 1 = forced (tests, tuning)
-static int g_attn_v4 = 1;   // 1 = launches with a proven score bound that qualify for v2's plain instantiation run v4 / v5, 0 = never
-static int g_attn_v5 = -1;  // MFMA shape of the bounded-score kernel: 1 = 16x16x32 (v5), 0 = 32x32x16 (v4), -1 = by size: v5 below 8192 keys.
-                            // In isolation v5 is faster at every length (+0.5 % at 4608 ... +4.6 % at 17920), but it also runs the chip
-                            // at 2.0 instead of 1.75 GHz, and inside a forward that costs the neighbouring GEMMs their clock:
-                            // interleaved in-sequence A/B (tools/bench_cfg5.py --ab-attn): S = 4608: attention 13.46 vs 13.40 ms and
-                            // GEMMs 47.6 vs 48.0 ms per forward with v5 vs v4 (v5 +0.6 % overall); S = 17920: attention 189.5 vs 187.6
-                            // and GEMMs 186.6 vs 183.5 ms (v5 -1.3 % overall).
-static int g_attn_v6 = 0;    // 1 = plain-grid launches of the bounded-score kernel use the one-wave-per-SIMD form (v6): an experiment,
-                             // bit-identical to v5 and 12-20 % SLOWER (profiles/r02_kb_attn_v6.log) -- see attn6_body
-static int g_attn_knock = 0; // timing diagnostics (rf_debug_attn_knock): 1 = no fragment reads, 2 = no softmax VALU, 3 = both
-static int g_attn_sk = -1;  // split launch of v5: -1 = heuristic, 0 = never, 1 = whenever possible
+// Kernel-selection knobs: compile-time constants in librf_flux.so; mutable (rf_debug_*) in the experiments build only.
+struct AttnTuning {
+  int v2;      // -1 = cost model between v1 and v2, 0 / 1 = forced
+  int v4;      // 1 = the shift-free kernels may run, 0 = never
+  int v5;      // MFMA shape of the bounded kernel: 1 = 16x16x32 (v5), 0 = 32x32x16 (v4), -1 = by size: v5 below 8192 keys.
+               // In isolation v5 is faster at every length (+0.5 % at 4608 ... +4.6 % at 17920), but it also runs the chip
+               // at 2.0 instead of 1.75 GHz, and inside a forward that costs the neighbouring GEMMs their clock:
+               // interleaved in-sequence A/B (tools/bench_cfg5.py --ab-attn): S = 4608: attention 13.46 vs 13.40 ms and
+               // GEMMs 47.6 vs 48.0 ms per forward with v5 vs v4 (v5 +0.6 % overall); S = 17920: attention 189.5 vs 187.6
+               // and GEMMs 186.6 vs 183.5 ms (v5 -1.3 % overall).
+  int v6;      // experiments: one wave per SIMD form
+  int knock;   // experiments: timing knock-outs
+  int sk;      // split launch: -1 = heuristic, 0 = never, 1 = whenever possible
+  int lag;     // -1 = lagged-max kernel only without a usable bound, 0 = never, 1 = always
+};
+#ifdef RF_EXPERIMENTS
+static AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1};
+#else
+static constexpr AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1};
+#endif
 static int g_last_attn_path = 0;
 
 }  // namespace rf
 
-extern "C" int rf_debug_attn_v2(int on) {  // tuning hook (-1 = cost model), not part of the drop-in surface
-  rf::g_attn_v2 = on < 0 ? -1 : (on ? 1 : 0);
-  return RF_OK;
-}
+// read-only introspection: 1 / 2 / 4 / 5 = kernel version, 6 = v5 split launch, 8 = v5 lagged-max, 9 = its split launch (7 = v6, experiments)
+extern "C" int rf_debug_last_attn_path(void) { return rf::g_last_attn_path; }
 
-extern "C" int rf_debug_attn_v5(int mode) {  // A/B hook: MFMA shape of the bounded-score kernel (-1 = by size, 0 = v4, 1 = v5)
-  rf::g_attn_v5 = mode < 0 ? -1 : (mode ? 1 : 0);
-  return RF_OK;
-}
-
-extern "C" int rf_debug_attn_v4(int on) {  // tuning / test hook: allow (1) or forbid (0) the bounded-score kernel
-  rf::g_attn_v4 = on ? 1 : 0;
-  return RF_OK;
-}
-
-extern "C" int rf_debug_attn_v6(int on) { rf::g_attn_v6 = on ? 1 : 0; return RF_OK; }   // A/B hook: one wave per SIMD (v6) vs two (v5)
-extern "C" int rf_debug_attn_knock(int k) { rf::g_attn_knock = k; return RF_OK; }   // timing diagnostics only (wrong results)
-extern "C" int rf_debug_attn_sk(int mode) {  // split launch of the bounded-score kernel: -1 = heuristic, 0 = never, 1 = whenever possible
-  rf::g_attn_sk = mode < 0 ? -1 : (mode ? 1 : 0);
-  return RF_OK;
-}
-extern "C" int rf_debug_last_attn_path(void) { return rf::g_last_attn_path; }   // 1 / 2 / 4 / 5 = kernel version, 6 = v5 split launch
+#ifdef RF_EXPERIMENTS
+extern "C" int rf_debug_attn_v2(int on) { rf::g_at.v2 = on < 0 ? -1 : (on ? 1 : 0); return RF_OK; }
+extern "C" int rf_debug_attn_v5(int mode) { rf::g_at.v5 = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
+extern "C" int rf_debug_attn_v4(int on) { rf::g_at.v4 = on ? 1 : 0; return RF_OK; }
+extern "C" int rf_debug_attn_v6(int on) { rf::g_at.v6 = on ? 1 : 0; return RF_OK; }
+extern "C" int rf_debug_attn_knock(int k) { rf::g_at.knock = k; return RF_OK; }
+extern "C" int rf_debug_attn_sk(int mode) { rf::g_at.sk = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
+extern "C" int rf_debug_attn_lag(int mode) { rf::g_at.lag = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
+#endif
 
 extern "C" int64_t rf_attention_ws_bytes(void) {
   int dev = 0, cus = 0;
@@ -1397,17 +1231,31 @@ extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt,
                                    int32_t S, int32_t s_pad, int64_t ldo, int32_t n_main, int32_t mode,
                                    float cross_bias, float scale, int32_t q_prescaled, float score_bound,
                                    void* ws, int64_t ws_bytes, void* stream) {
+  rf_attn_desc d;
+  memset(&d, 0, sizeof(d));
+  d.q = q; d.k = k; d.vt = vt; d.out = out; d.heads = heads; d.S = S; d.s_pad = s_pad; d.ldo = ldo; d.n_main = n_main;
+  d.mode = mode; d.cross_bias = cross_bias; d.scale = scale; d.q_prescaled = q_prescaled; d.score_bound = score_bound;
+  d.ws = ws; d.ws_bytes = ws_bytes; d.kernel = RF_ATTN_AUTO;
+  return rf_attention(&d, stream);
+}
+
+extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
   using namespace rf;
-  RF_REQUIRE(q && k && vt && out, RF_ERR_NULL, "rf_attention_fwd: NULL pointer");
+  RF_REQUIRE(d != nullptr, RF_ERR_NULL, "rf_attention: desc is NULL");
+  const int32_t heads = d->heads, S = d->S, s_pad = d->s_pad, mode = d->mode;
+  int32_t n_main = d->n_main;
+  const int64_t ldo = d->ldo;
+  RF_REQUIRE(d->q && d->k && d->vt && d->out, RF_ERR_NULL, "rf_attention: NULL pointer");
   RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0, RF_ERR_SHAPE,
-             "rf_attention_fwd: bad shape heads=%d S=%d s_pad=%d", heads, S, s_pad);
-  RF_REQUIRE(mode >= 0 && mode <= 2, RF_ERR_SHAPE, "rf_attention_fwd: mode=%d", mode);
-  RF_REQUIRE(score_bound >= 0.f, RF_ERR_SHAPE, "rf_attention_fwd: score_bound=%g (0 = unknown)", (double)score_bound);
-  RF_REQUIRE(aligned16(q) && aligned16(k) && aligned16(vt) && aligned16(out) && ldo % 4 == 0, RF_ERR_ALIGN,
-             "rf_attention_fwd: operands must be 16-byte aligned");
-  RF_REQUIRE(ldo >= (int64_t)heads * 128, RF_ERR_SHAPE, "rf_attention_fwd: ldo < heads*128");
+             "rf_attention: bad shape heads=%d S=%d s_pad=%d", heads, S, s_pad);
+  RF_REQUIRE(mode >= 0 && mode <= 2, RF_ERR_SHAPE, "rf_attention: mode=%d", mode);
+  RF_REQUIRE(d->score_bound >= 0.f, RF_ERR_SHAPE, "rf_attention: score_bound=%g (0 = unknown)", (double)d->score_bound);
+  RF_REQUIRE(d->lag_thresh >= 0.f, RF_ERR_SHAPE, "rf_attention: lag_thresh=%g (0 = default)", (double)d->lag_thresh);
+  RF_REQUIRE(aligned16(d->q) && aligned16(d->k) && aligned16(d->vt) && aligned16(d->out) && ldo % 4 == 0, RF_ERR_ALIGN,
+             "rf_attention: operands must be 16-byte aligned");
+  RF_REQUIRE(ldo >= (int64_t)heads * 128, RF_ERR_SHAPE, "rf_attention: ldo < heads*128");
   if (mode == 0) n_main = S;
-  RF_REQUIRE(n_main >= 0 && n_main <= S, RF_ERR_SHAPE, "rf_attention_fwd: n_main=%d", n_main);
+  RF_REQUIRE(n_main >= 0 && n_main <= S, RF_ERR_SHAPE, "rf_attention: n_main=%d", n_main);
   static bool attr_set = false;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE));
@@ -1417,91 +1265,142 @@ extern "C" int rf_attention_fwd_ws(const void* q, const void* k, const void* vt,
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT2_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v4, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+#ifdef RF_EXPERIMENTS
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v6, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+#endif
     attr_set = true;
   }
   AttnParams p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
+  p.q = (const bf16_t*)d->q; p.k = (const bf16_t*)d->k; p.vt = (const bf16_t*)d->vt; p.out = (bf16_t*)d->out;
   p.heads = heads; p.S = S; p.s_pad = s_pad; p.n_main = n_main; p.mode = mode;
   p.nqb = cdiv(S, ATT_QBLK); p.ldo = ldo;
-  p.cross_bias_l2 = cross_bias * 1.4426950408889634f;
-  p.sl2 = scale * 1.4426950408889634f;
-  // v2 (256-query workgroups, 1 per CU) is ~8 % more efficient per row but has a coarser tail than v1
-  // (128-query workgroups, 2 per CU); estimate both in units of "one CU doing 256 rows x S keys"
-  bool use_v2 = g_attn_v2 == 1;
-  if (g_attn_v2 < 0) {
-    const int nb1 = heads * cdiv(S, 128), nb2 = heads * cdiv(S, 256);
-    const int rem1 = nb1 % 512;
-    const float t1 = (float)(nb1 / 512) + (rem1 == 0 ? 0.f : (rem1 <= 256 ? 0.55f : 1.f));
-    const float t2 = (float)cdiv(nb2, 256) / 1.08f;
-    use_v2 = t2 < t1;
-  }
+  p.cross_bias_l2 = d->cross_bias * 1.4426950408889634f;
+  p.sl2 = d->scale * 1.4426950408889634f;
+  p.lag_thresh = d->lag_thresh > 0.f ? d->lag_thresh : 1073741824.0f;   // 2^30
   hipStream_t st = (hipStream_t)stream;
-  const bool pre = q_prescaled != 0;
+  const bool pre = d->q_prescaled != 0;
   ProfScope prof(RF_KC_ATTN, 4.0 * (double)S * (double)S * 128.0 * heads, st);
-  // the bounded-score kernel is 25-45 % faster than either online-softmax kernel wherever it applies (profiles/r02_kb_attn*.log)
-  const bool bounded = mode == 0 && S % 256 == 0 && pre && g_attn_v4 && score_bound > 0.f && score_bound <= 100.f;
-  if (bounded && g_attn_v2 != 0) use_v2 = true;
-  const bool use5 = g_attn_v5 == 1 || (g_attn_v5 < 0 && S < 8192);
-  if (use_v2) {
-    const dim3 grid2(heads * cdiv(S, 256)), blk(512);
-    const bool generic = !(mode == 0 && S % 64 == 0);
-    if (bounded) {
+
+  // ---- which kernel -------------------------------------------------------------------------------------------------
+  // shift-free kernels (no per-tile running maximum; 25-45 % faster than either online-softmax kernel wherever they apply,
+  // profiles/r02_kb_attn*.log): need no mask / bias, whole rounds of the 4-slot rings and a prescaled q.  Bounded form
+  // (P = exp2(s)): the caller's proven |s| <= score_bound <= 100.  Lagged-max form: nothing else.
+  const bool fast_ok = mode == 0 && S % 256 == 0 && pre;
+  const bool bound_ok = d->score_bound > 0.f && d->score_bound <= 100.f;
+  int kern = d->kernel;
+  void* ws = d->ws;
+  const int64_t ws_bytes = d->ws_bytes;
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    RF_CHECK_HIP(hipGetDevice(&dev));
+    RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int P = num_cus / 8 * 8;
+  AttnSkParams sk;
+  sk.nq = S / 256; sk.nqb = S / 256; sk.hpx = heads / 8; sk.wpx = P / 8; sk.ws = (float*)ws;
+  const bool can_split = fast_ok && heads % 8 == 0 && P >= 8 && ws != nullptr && aligned16(ws) &&
+                         ws_bytes >= (int64_t)2 * P * ATT5_SLOT * 4 && (int64_t)sk.hpx * sk.nqb * sk.nq >= 2 * sk.wpx;
+  if (kern == RF_ATTN_AUTO) {
+    bool use_v2 = g_at.v2 == 1;
+    if (g_at.v2 < 0) {
+      // v2 (256-query workgroups, 1 per CU) is ~8 % more efficient per row but has a coarser tail than v1
+      // (128-query workgroups, 2 per CU); estimate both in units of "one CU doing 256 rows x S keys"
+      const int nb1 = heads * cdiv(S, 128), nb2 = heads * cdiv(S, 256);
+      const int rem1 = nb1 % 512;
+      const float t1 = (float)(nb1 / 512) + (rem1 == 0 ? 0.f : (rem1 <= 256 ? 0.55f : 1.f));
+      const float t2 = (float)cdiv(nb2, 256) / 1.08f;
+      use_v2 = t2 < t1;
+    }
+    kern = use_v2 ? RF_ATTN_ONLINE256 : RF_ATTN_ONLINE128;
+    const bool lag = g_at.lag == 1 || (g_at.lag < 0 && !bound_ok);
+    if (fast_ok && g_at.v4 && g_at.v2 != 0 && (bound_ok || lag) && !(lag && g_at.lag == 0)) {
+      const bool use5 = lag || g_at.v5 == 1 || (g_at.v5 < 0 && S < 8192);
       // split launch: one persistent workgroup per CU over equal shares of the (block, key quad) space when the plain grid
       // fills less than 80 % of its rounds.  Measured (profiles/r02_kb_attn_split.log): S = 5632 (528 blocks = 2.06 rounds
       // run as 3, 69 %) 399 -> 328 us; S = 4608 (1.69 as 2, 84 %) break-even -- the part is power-limited, idle CUs in the
       // last round let the busy ones clock higher; S = 17920 (6.56 as 7, 94 %) 8 % slower.
-      static int num_cus = 0;
-      if (num_cus == 0) {
-        int dev = 0;
-        RF_CHECK_HIP(hipGetDevice(&dev));
-        RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
-      }
-      const int P = num_cus / 8 * 8, blocks = heads * (S / 256), rounds = cdiv(blocks, P);
-      AttnSkParams sk;
-      sk.nq = S / 256; sk.nqb = S / 256; sk.hpx = heads / 8; sk.wpx = P / 8; sk.ws = (float*)ws;
-      const bool can_split = use5 && g_attn_sk != 0 && heads % 8 == 0 && P >= 8 && ws != nullptr && aligned16(ws) &&
-                             ws_bytes >= (int64_t)2 * P * ATT5_SLOT * 4 && (int64_t)sk.hpx * sk.nqb * sk.nq >= 2 * sk.wpx;
-      if (can_split && (g_attn_sk == 1 || (double)blocks / ((double)rounds * P) < 0.80)) {
-        hipLaunchKernelGGL(attn_fwd_kernel_v5sk, dim3(P), blk, ATT4_LDS, st, p, sk);
-        hipLaunchKernelGGL(attn5_combine_kernel, grid2, blk, 0, st, p, sk);
-        g_last_attn_path = 6;
-      } else if (use5 && g_attn_v6 && !g_attn_knock) {
-        hipLaunchKernelGGL(attn_fwd_kernel_v6, grid2, dim3(256), ATT4_LDS, st, p);
-        g_last_attn_path = 7;
-      } else if (use5 && g_attn_knock) {
-        if (g_attn_knock == 1) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_attn_knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
-        else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
-        g_last_attn_path = 5;
-      } else if (use5) {
-        hipLaunchKernelGGL(attn_fwd_kernel_v5, grid2, blk, ATT4_LDS, st, p);
-        g_last_attn_path = 5;
-      } else {
-        hipLaunchKernelGGL(attn_fwd_kernel_v4, grid2, blk, ATT4_LDS, st, p);
-        g_last_attn_path = 4;
-      }
-      RF_LAUNCH_CHECK();
-      return RF_OK;
-    }
-    g_last_attn_path = 2;
-    if (generic) {
-      if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<true, true>), grid2, blk, ATT2_LDS, st, p);
-      else hipLaunchKernelGGL((attn_fwd_kernel_v2<true, false>), grid2, blk, ATT2_LDS, st, p);
-    } else {
-      if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<false, true>), grid2, blk, ATT2_LDS, st, p);
-      else hipLaunchKernelGGL((attn_fwd_kernel_v2<false, false>), grid2, blk, ATT2_LDS, st, p);
+      const int blocks = heads * (S / 256), rounds = cdiv(blocks, P);
+      const bool split = use5 && can_split && g_at.sk != 0 && (g_at.sk == 1 || (double)blocks / ((double)rounds * P) < 0.80);
+      kern = !use5 ? RF_ATTN_BOUNDED32 : lag ? (split ? RF_ATTN_LAGGED16_SPLIT : RF_ATTN_LAGGED16)
+                                             : (split ? RF_ATTN_BOUNDED16_SPLIT : RF_ATTN_BOUNDED16);
     }
   } else {
-    g_last_attn_path = 1;
-    const dim3 grid1(heads * p.nqb), blk(256);
-    if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid1, blk, 2 * ATT_STAGE, st, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid1, blk, 2 * ATT_STAGE, st, p);
+    // an explicit request must be runnable as asked: fail loudly instead of substituting another kernel
+    const bool want_fast = kern == RF_ATTN_BOUNDED32 || kern == RF_ATTN_BOUNDED16 || kern == RF_ATTN_BOUNDED16_SPLIT ||
+                           kern == RF_ATTN_LAGGED16 || kern == RF_ATTN_LAGGED16_SPLIT;
+    RF_REQUIRE(kern == RF_ATTN_ONLINE128 || kern == RF_ATTN_ONLINE256 || want_fast, RF_ERR_SHAPE, "rf_attention: kernel=%d", kern);
+    if (want_fast) RF_REQUIRE(fast_ok, RF_ERR_UNSUPPORTED, "rf_attention: kernel %d needs mode 0, S %% 256 == 0 and a prescaled q", kern);
+    if (kern == RF_ATTN_BOUNDED32 || kern == RF_ATTN_BOUNDED16 || kern == RF_ATTN_BOUNDED16_SPLIT)
+      RF_REQUIRE(bound_ok, RF_ERR_UNSUPPORTED, "rf_attention: kernel %d needs 0 < score_bound <= 100 (got %g)", kern, (double)d->score_bound);
+    if (kern == RF_ATTN_BOUNDED16_SPLIT || kern == RF_ATTN_LAGGED16_SPLIT)
+      RF_REQUIRE(can_split, RF_ERR_WORKSPACE, "rf_attention: the split launch needs heads %% 8 == 0 and %lld bytes of 16-byte aligned scratch",
+                 (long long)((int64_t)2 * P * ATT5_SLOT * 4));
+  }
+
+  const dim3 grid2(heads * cdiv(S, 256)), blk(512);
+  switch (kern) {
+    case RF_ATTN_BOUNDED16_SPLIT:
+      hipLaunchKernelGGL(attn_fwd_kernel_v5sk<false>, dim3(P), blk, ATT4_LDS, st, p, sk);
+      hipLaunchKernelGGL(attn5_combine_kernel, grid2, blk, 0, st, p, sk);
+      g_last_attn_path = 6;
+      break;
+    case RF_ATTN_LAGGED16_SPLIT:
+      hipLaunchKernelGGL(attn_fwd_kernel_v5sk<true>, dim3(P), blk, ATT4_LDS, st, p, sk);
+      hipLaunchKernelGGL(attn5_combine_kernel, grid2, blk, 0, st, p, sk);
+      g_last_attn_path = 9;
+      break;
+    case RF_ATTN_LAGGED16:
+      hipLaunchKernelGGL(attn_fwd_kernel_v5<true>, grid2, blk, ATT4_LDS, st, p);
+      g_last_attn_path = 8;
+      break;
+    case RF_ATTN_BOUNDED16:
+#ifdef RF_EXPERIMENTS
+      if (g_at.v6 && !g_at.knock) {
+        hipLaunchKernelGGL(attn_fwd_kernel_v6, grid2, dim3(256), ATT4_LDS, st, p);
+        g_last_attn_path = 7;
+        break;
+      }
+      if (g_at.knock) {
+        if (g_at.knock == 1) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
+        else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
+        g_last_attn_path = 5;
+        break;
+      }
+#endif
+      hipLaunchKernelGGL(attn_fwd_kernel_v5<false>, grid2, blk, ATT4_LDS, st, p);
+      g_last_attn_path = 5;
+      break;
+    case RF_ATTN_BOUNDED32:
+      hipLaunchKernelGGL(attn_fwd_kernel_v4, grid2, blk, ATT4_LDS, st, p);
+      g_last_attn_path = 4;
+      break;
+    case RF_ATTN_ONLINE256: {
+      const bool generic = !(mode == 0 && S % 64 == 0);
+      g_last_attn_path = 2;
+      if (generic) {
+        if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<true, true>), grid2, blk, ATT2_LDS, st, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel_v2<true, false>), grid2, blk, ATT2_LDS, st, p);
+      } else {
+        if (pre) hipLaunchKernelGGL((attn_fwd_kernel_v2<false, true>), grid2, blk, ATT2_LDS, st, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel_v2<false, false>), grid2, blk, ATT2_LDS, st, p);
+      }
+      break;
+    }
+    default: {
+      g_last_attn_path = 1;
+      const dim3 grid1(heads * p.nqb), blk1(256);
+      if (pre) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid1, blk1, 2 * ATT_STAGE, st, p);
+      else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid1, blk1, 2 * ATT_STAGE, st, p);
+    }
   }
   RF_LAUNCH_CHECK();
   return RF_OK;

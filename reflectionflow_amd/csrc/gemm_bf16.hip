@@ -19,14 +19,15 @@
 //     W = scaling*lora_B) without materialising a concat or a merged weight;
 //   * blockIdx is remapped so that every XCD works on a contiguous chunk of tiles (private L2).
 //
-// Map of this file.  SHIPPED: the epilogues (gemm_epilogue / gemm_epilogue_lds_v over the Acc32 / Acc16 accumulator views),
-// gemm_mainloop (plain loop of the 128 x 128 kernel for small problems and of split-K), the 256 x 256 loops
+// Map of this file (all of it ships in librf_flux.so): the epilogues (gemm_epilogue / gemm_epilogue_lds_v over the Acc32 / Acc16
+// accumulator views), gemm_mainloop (plain loop of the 128 x 128 kernel for small problems and of split-K), the 256 x 256 loops
 // gemm_mainloop_pp3_m16 (bf16: gemm_bf16_pp16e_kernel one tile per block, gemm_bf16_sk_kernel<..., EVEN> for the stream-K and
 // persistent schedules) and gemm_mainloop_pp2_m16 (fp8 / mixed launches: gemm_w8_pp16_kernel and the W8 stream-K kernel),
-// splitk_reduce_kernel, dispatch() and the C entry points.  KEPT FOR A/B AND THE STUDIES IN
-// profiles/r02_gemm_power.md, reachable only through rf_debug_* switches: gemm_mainloop_pp (round-1 phases, with knock-outs),
-// gemm_mainloop_pp2 / _pp3 (balanced / evenly loaded phases on 32x32x16 MFMAs: pp2 is what rf_debug_gemm_mi16(0) selects),
-// gemm_bf16_ppx_kernel (their harness), gemm_mainloop_w4 (one wave per SIMD over an LDS ring), gemm_skinny_kernel.
+// splitk_reduce_kernel, dispatch() and the C entry points.  The schedule of a launch is picked by dispatch() from the shape or
+// by the CALLER per launch (rf_gemm_desc.schedule) -- there is no process-global kernel switch in this library.
+// The loops kept for the A/B studies of profiles/r02_gemm_power.md (round-1 phases, 32x32x16 MFMA shapes, one wave per SIMD,
+// skinny-N, knock-outs, the s_memtime timeline) live in experiments/*.inc and are compiled only with -DRF_EXPERIMENTS
+// (make EXPERIMENTS=1 -> librf_flux_exp.so, which tools/kb_*.py load; its rf_debug_* setters do not exist in librf_flux.so).
 #include "common.hpp"
 #include <type_traits>
 #include <stdlib.h>
@@ -65,15 +66,31 @@ struct GemmParams {
   // K-tiles, fp32 partial tiles go to ws[slice][m][n_pad], splitk_reduce_kernel sums them in slice order
   int ksplit, kchunk; float* ws; int64_t ws_slice; int ws_ld;
   float* scratch; int64_t scratch_bytes;  // host side: the caller's scratch as passed (flags + partials)
+  int sched, _pad_s;                      // host side: rf_gemm_desc.schedule (rf_gemm_schedule)
   unsigned long long* timeline;           // debug build of the kernel only (rf_debug_gemm_timeline)
   GemmGroupDev g[4];
 };
 
 __device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
 __device__ unsigned long long g_clk_probe_epi[2];   // {s_memtime, s_memrealtime} when block 0 / wave 0 has drained its epilogue stores
-static int g_nt_store = 0;   // see GemmParams.nt_store
-static int g_mi16 = 1;   // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs (rf_debug_gemm_mi16)
-static int g_even = 1;   // ... in evenly loaded phases (gemm_mainloop_pp3_m16; rf_debug_gemm_even)
+
+// Kernel-selection knobs.  In librf_flux.so they are compile-time constants (the shipped choice); the experiments build
+// (-DRF_EXPERIMENTS) makes them mutable through rf_debug_* setters for the A/B tools.
+struct Tuning {
+  int nt_store;            // LDS-staged epilogue writes output rows with non-temporal stores
+  int mi16;                // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs
+  int even;                // ... in evenly loaded phases (gemm_mainloop_pp3_m16)
+  int force_tile;          // 0 = rf_gemm_desc.schedule / heuristic; 128 / 256 / 257 / 258 / 259 forced
+  int force_sk;            // -1 = schedule / heuristic, 0 = never, 1 = stream-K whenever feasible, 2 = persistent whole tiles
+  int persistent_rounds;   // > 0: bf16 launches with >= this many rounds run as ONE persistent launch (measured neutral: off)
+  int skinny;              // LoRA down-projections on the single-launch skinny-N kernel (measured slower: off)
+  int w4_knock;            // variant selector of the experimental kernels
+};
+#ifdef RF_EXPERIMENTS
+static Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0};
+#else
+static constexpr Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0};
+#endif
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
 
@@ -684,394 +701,9 @@ __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
 #define RF_MFMA_FP8_16(a, b, c) (c)
 #endif
 
-// one phase's multiply: the 32 x 64 quadrant (a x {b0, b1}) over the whole K-tile
-template <bool W8>
-__device__ __forceinline__ void mma_quadrant(f32x16& c0, f32x16& c1, const bf16x8 (&a)[4], const bf16x8 (&b0)[4], const bf16x8 (&b1)[4]) {
-  if constexpr (!W8) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b0[ks], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], b1[ks], c1, 0, 0, 0);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const i32x8 av = cat_frag(a[2 * j], a[2 * j + 1]);
-      c0 = RF_MFMA_FP8(av, cat_frag(b0[2 * j], b0[2 * j + 1]), c0);
-      c1 = RF_MFMA_FP8(av, cat_frag(b1[2 * j], b1[2 * j + 1]), c1);
-    }
-    // pin the results to this phase: hipcc's IR passes otherwise SINK all 16 scaled MFMAs of a K-tile below the last
-    // phase's barrier (seen in the ISA: eight empty barrier pairs, then 16 MFMAs back to back) -- sched_barrier only
-    // binds the machine scheduler inside a basic block, and the conditional DMA issue splits the K-tile into several
-    asm volatile("" : "+v"(c0), "+v"(c1));
-  }
-}
-
-// VAR (experiments, rf_debug_force_gemm_tile(259) + rf_debug_gemm_w4_knock(VAR)): 0 = production order;
-// 1 = a phase's fragment reads are issued BEFORE its two DMA pieces; timing-only knock-outs (wrong results):
-// 2 = no DMA in the loop, 3 = no fragment reads, 4 = neither.
-template <bool W8 = false, int VAR = 0>
-__device__ __forceinline__ void gemm_mainloop_pp(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
-                                                 const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
-  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
-  constexpr int HT = 128 * 128;  // half-tile bytes
-  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
-  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int M = G.M;
-
-  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
-  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
-  const int r8 = lane >> 3;
-  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
-  uint32_t rowA[2][2], rowB[2][2];  // [sub-block][instr] -> global row of A / W (clamped)
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
-      rowA[sb][i] = (uint32_t)(gm < M ? gm : M - 1);
-      const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
-      rowB[sb][i] = (uint32_t)(gn < N ? gn : N - 1);
-    }
-
-  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
-  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
-  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
-  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
-  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
-  auto load_seg = [&](Cur& c) {
-    const KSegDev& S = G.seg[c.seg];
-    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
-    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        c.offA[sb][i] = rowA[sb][i] * lda2 + chunk_b;
-        c.offB[sb][i] = rowB[sb][i] * ldw2 + chunk_b;
-      }
-  };
-  auto next = [&](Cur& c) {
-    ++c.kk;
-    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
-      c.kk = 0;
-      ++c.seg;
-      load_seg(c);
-    }
-  };
-  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
-  auto stage = [&](const int kind, const Cur& c, const int buf) {
-    char* dst = smem + buf * BUF + kind * HT + w * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
-      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
-    }
-  };
-
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment read offsets inside a buffer
-  const int swz = (l31 >> 1) & 7;
-  const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
-  const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
-  // logical 16-byte chunk of fragment ks: bf16 k-step ks = chunks 2ks + h; fp8 k-step ks/2 = chunks 4(ks/2) + 2h + (ks&1)
-  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
-
-  Cur c1;
-  c1.seg = 0; c1.kk = kt_begin;
-  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
-    c1.kk -= G.seg[c1.seg].nk;
-    ++c1.seg;
-  }
-  load_seg(c1);
-  // prologue: tile 0 entirely, A0/B0 of tile 1
-  stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
-  next(c1);   // c1 -> tile 1
-  Cur c2 = c1;
-  if (nk > 1) {
-    stage(0, c1, 1); stage(2, c1, 1);
-    next(c2);  // c2 -> tile 2
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
-  __builtin_amdgcn_sched_barrier(0);
-
-  bf16x8 a0[4], a1[4], bq[2][4];
-  for (int t = 0; t < nk; ++t) {
-    const char* base = smem + (t & 1) * BUF;
-    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
-    // ---- p0 -------------------------------------------------------------------------------
-    constexpr bool DMA = VAR != 2 && VAR != 4, RD = VAR != 3 && VAR != 4, RD_FIRST = VAR == 1;
-    auto rd0 = [&]() {
-      if (!RD) return;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int coff = frag_coff(ks);
-        a0[ks] = *(const bf16x8*)(base + a_off + coff);
-        bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
-        bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto rd1 = [&]() {
-      if (!RD) return;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a1[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    auto rd2 = [&]() {
-      if (!RD) return;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int coff = frag_coff(ks);
-        bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
-        bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    if (RD_FIRST) rd0();
-    if (more1 && DMA) stage(1, c1, (t + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!RD_FIRST) rd0();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mma_quadrant<W8>(acc[0][0], acc[0][1], a0, bq[0], bq[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- p1 -------------------------------------------------------------------------------
-    if (RD_FIRST) rd1();
-    if (more1 && DMA) stage(3, c1, (t + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!RD_FIRST) rd1();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mma_quadrant<W8>(acc[1][0], acc[1][1], a1, bq[0], bq[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- p2 -------------------------------------------------------------------------------
-    if (RD_FIRST) rd2();
-    if (more2 && DMA) stage(0, c2, t & 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!RD_FIRST) rd2();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mma_quadrant<W8>(acc[1][2], acc[1][3], a1, bq[0], bq[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- p3 -------------------------------------------------------------------------------
-    if (more2 && DMA) {
-      stage(2, c2, t & 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // everything but this tile's p2/p3 stages has landed
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    mma_quadrant<W8>(acc[0][2], acc[0][3], a0, bq[0], bq[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    next(c1);
-    next(c2);
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
-}
-
-// Balanced ping-pong schedule (experiment VAR 5; see profiles/r02_kb_ppx*.log and r02_ubench_lds_port.log).
-// The knock-outs say the production loop loses ~7 % to DMA alone, ~10 % to fragment reads alone, but 35 % to both:
-// its load phases carry 12 / 4 / 8 / 0 fragment reads and 2 DMA pieces each, and a wave group's load phase must fit under
-// the other group's 8 MFMAs (256 cycles).  Four waves' 12 reads are 384 cycles of the 128 B/clk LDS before any latency,
-// and the two DMA pieces queue behind three other waves' on the 64 B/clk DMA path (~128 cycles) -- phase 0 is twice its
-// budget while phase 3 idles.  Here the phases carry 8 / 4 / 8 / 4 reads and 0 / 4 / 0 / 4 pieces: the next tile's A0
-// fragments are read in phase 3 into the registers A1 just vacated (the two A register sets swap roles every tile, so
-// the loop is unrolled by two), and all DMA sits in the two light phases, behind that phase's reads.
-// Staging (buffer u & 1 holds tile u; a region may be overwritten two phases after the phase that reads it, which is
-// when BOTH wave groups have passed a barrier behind their reads of it):
-//   p1(t): A0(t+2) [last read p3(t-1)], B1(t+1) [B1(t-1) read p2(t-1)]      p3(t): B0(t+2) [read p0(t)], A1(t+2) [read p1(t)]
-// Every piece is issued >= 5 phases before its first read; s_waitcnt vmcnt(8) behind each issue retires the batch
-// issued two DMA phases earlier, one barrier before its first reader.
-template <bool W8>
-__device__ __forceinline__ void gemm_mainloop_pp2(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
-                                                  const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
-  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
-  constexpr int HT = 128 * 128;  // half-tile bytes
-  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
-  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int M = G.M;
-
-  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
-  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
-  const int r8 = lane >> 3;
-  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
-  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
-  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
-  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
-  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
-  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
-  auto load_seg = [&](Cur& c) {
-    const KSegDev& S = G.seg[c.seg];
-    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
-    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
-    // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
-        const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
-        c.offA[sb][i] = (uint32_t)(gm < M ? gm : M - 1) * lda2 + chunk_b;
-        c.offB[sb][i] = (uint32_t)(gn < N ? gn : N - 1) * ldw2 + chunk_b;
-      }
-  };
-  auto next = [&](Cur& c) {
-    ++c.kk;
-    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
-      c.kk = 0;
-      ++c.seg;
-      load_seg(c);
-    }
-  };
-  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
-  auto stage = [&](const int kind, const Cur& c, const int buf) {
-    char* dst = smem + buf * BUF + kind * HT + w * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
-      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
-    }
-  };
-
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment read offsets inside a buffer
-  const int swz = (l31 >> 1) & 7;
-  const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
-  const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
-  // logical 16-byte chunk of fragment ks: bf16 k-step ks = chunks 2ks + h; fp8 k-step ks/2 = chunks 4(ks/2) + 2h + (ks&1)
-  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
-
-  Cur c1;
-  c1.seg = 0; c1.kk = kt_begin;
-  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
-    c1.kk -= G.seg[c1.seg].nk;
-    ++c1.seg;
-  }
-  load_seg(c1);
-  // prologue, in steady-state issue order: A0(0) | B0(0) A1(0) | A0(1) B1(0) | B0(1) A1(1)
-  Cur c2 = c1;
-  if (nk > 1) {
-    next(c2);                                        // c1 = tile 0, c2 = tile 1
-    stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0);
-    stage(0, c2, 1); stage(3, c1, 0);
-    stage(2, c2, 1); stage(1, c2, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile 0 but B1 has landed
-    c1 = c2;                                         // c1 -> tile 1
-    next(c2);                                        // c2 -> tile 2
-  } else {
-    stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  bf16x8 X[4], Y[4], bq[2][4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) X[ks] = *(const bf16x8*)(smem + a_off + frag_coff(ks));   // A0 of tile 0
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
-  __builtin_amdgcn_sched_barrier(0);
-
-#define RF_PP2_BAR()                    \
-  __builtin_amdgcn_sched_barrier(0);    \
-  __builtin_amdgcn_s_barrier();         \
-  __builtin_amdgcn_sched_barrier(0)
-  // one K-tile: P holds its A0 fragments (read during the previous tile's phase 3), Q receives A1, then the next A0
-  auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
-    const char* base = smem + (t & 1) * BUF;
-    const char* nbase = smem + ((t + 1) & 1) * BUF;
-    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
-    // ---- p0: 8 reads ---------------------------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int coff = frag_coff(ks);
-      bq[0][ks] = *(const bf16x8*)(base + b_off + coff);
-      bq[1][ks] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
-    }
-    RF_PP2_BAR();
-    mma_quadrant<W8>(acc[0][0], acc[0][1], P, bq[0], bq[1]);
-    RF_PP2_BAR();
-    // ---- p1: 4 reads, 4 pieces -----------------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) {
-      stage(0, c2, t & 1); stage(3, c1, (t + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (more1) {
-      stage(3, c1, (t + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    RF_PP2_BAR();
-    mma_quadrant<W8>(acc[1][0], acc[1][1], Q, bq[0], bq[1]);
-    RF_PP2_BAR();
-    // ---- p2: 8 reads ---------------------------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int coff = frag_coff(ks);
-      bq[0][ks] = *(const bf16x8*)(base + HT + b_off + coff);
-      bq[1][ks] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
-    }
-    RF_PP2_BAR();
-    mma_quadrant<W8>(acc[1][2], acc[1][3], Q, bq[0], bq[1]);
-    // the next tile's A0 goes into Q: keep its reads behind these MFMAs' operand fetch
-    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
-    RF_PP2_BAR();
-    // ---- p3: 4 reads (next tile's A0), 4 pieces ------------------------------------------
-    if (more1) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(nbase + a_off + frag_coff(ks));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) {
-      stage(2, c2, t & 1); stage(1, c2, t & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (more1) {
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    RF_PP2_BAR();
-    mma_quadrant<W8>(acc[0][2], acc[0][3], P, bq[0], bq[1]);
-    RF_PP2_BAR();
-    next(c1);
-    next(c2);
-  };
-  for (int t = 0; t < nk; t += 2) {
-    tile(t, X, Y);
-    if (t + 1 < nk) tile(t + 1, Y, X);
-  }
-#undef RF_PP2_BAR
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
-}
+#ifdef RF_EXPERIMENTS
+#include "experiments/gemm_loops_exp.inc"
+#endif
 
 // The same balanced schedule on v_mfma_f32_16x16x32_bf16.  Under the 1.4 kW cap the matrix pipes sustain 1.82 PFLOP/s with
 // 32x32x16 MFMAs on random bf16 operands and 2.06 PFLOP/s with 16x16x32 (tools/ubench/mfma_power.py, no memory traffic at
@@ -1466,256 +1098,6 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
   if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
 }
 
-// Evenly loaded ping-pong schedule (experiment VAR 6): 6 fragment reads and 2 DMA pieces in EVERY phase.  On top of
-// gemm_mainloop_pp2's early A0 read, the k-step-0 pair of each B half is read one phase early into two spare fragment
-// pairs (e0 for B0, e1 for B1); the other six fragments of a half share one register set m.  18 fragments live (+2).
-//   reads   p0: B0 ks1..3 (6)      p1: A1 (4) + B1 ks0 (2)      p2: B1 ks1..3 (6)      p3: next A0 (4) + next B0 ks0 (2)
-//   DMA     p0: B1(t+1)            p1: A0(t+2)                  p2: B0(t+2)            p3: A1(t+2)
-// (each region is overwritten >= 2 phases after its last reader phase and >= 5 phases before its first; vmcnt(8) behind
-// the issue of p0 / p2 retires what p1 / p3 of the same tile read, one barrier ahead)
-template <bool W8>
-__device__ __forceinline__ void mma_split(f32x16& c0, f32x16& c1, const bf16x8 (&a)[4], const bf16x8 (&e)[2], const bf16x8 (&m)[6]) {
-  if constexpr (!W8) {
-    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e[0], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], e[1], c1, 0, 0, 0);
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) {
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], m[ks - 1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], m[ks + 2], c1, 0, 0, 0);
-    }
-  } else {
-    const i32x8 a01 = cat_frag(a[0], a[1]), a23 = cat_frag(a[2], a[3]);
-    c0 = RF_MFMA_FP8(a01, cat_frag(e[0], m[0]), c0);
-    c1 = RF_MFMA_FP8(a01, cat_frag(e[1], m[3]), c1);
-    c0 = RF_MFMA_FP8(a23, cat_frag(m[1], m[2]), c0);
-    c1 = RF_MFMA_FP8(a23, cat_frag(m[4], m[5]), c1);
-    asm volatile("" : "+v"(c0), "+v"(c1));   // see mma_quadrant
-  }
-}
-
-template <bool W8>
-__device__ __forceinline__ void gemm_mainloop_pp3(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
-                                                  const int nk, f32x16 (&acc)[2][4], char* smem, const int w, const int lane) {
-  constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
-  constexpr int HT = 128 * 128;  // half-tile bytes
-  constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
-  const int wm = w >> 1, wn = w & 1, grp = w >> 2;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int M = G.M;
-
-  // staging geometry: DMA instruction i (0,1) of wave w fills local rows (i*8 + w)*8 + lane/8 of a half-tile;
-  // local row lr of A_s is tile row (lr>>5)*64 + s*32 + (lr&31), of B_s tile column (lr>>6)*128 + s*64 + (lr&63)
-  const int r8 = lane >> 3;
-  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w & 1) << 2) + (lane >> 4))) * 16);  // swizzled 16-byte chunk
-  // K-tile cursors of the tiles being staged (c1 = tile t+1, c2 = tile t+2): segment, tile-in-segment and the
-  // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
-  // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
-  // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
-  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
-  auto load_seg = [&](Cur& c) {
-    const KSegDev& S = G.seg[c.seg];
-    c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
-    const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
-    // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int gm = m0 + (2 * i + (w >> 2)) * 64 + sb * 32 + 8 * (w & 3) + r8;
-        const int gn = n0 + i * 128 + sb * 64 + 8 * w + r8;
-        c.offA[sb][i] = (uint32_t)(gm < M ? gm : M - 1) * lda2 + chunk_b;
-        c.offB[sb][i] = (uint32_t)(gn < N ? gn : N - 1) * ldw2 + chunk_b;
-      }
-  };
-  auto next = [&](Cur& c) {
-    ++c.kk;
-    if (c.kk >= c.nk && c.seg < 2 && G.seg[c.seg + 1].nk > 0) {
-      c.kk = 0;
-      ++c.seg;
-      load_seg(c);
-    }
-  };
-  // kind: 0 = A0, 1 = A1, 2 = B0, 3 = B1
-  auto stage = [&](const int kind, const Cur& c, const int buf) {
-    char* dst = smem + buf * BUF + kind * HT + w * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
-      else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
-    }
-  };
-
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment read offsets inside a buffer
-  const int swz = (l31 >> 1) & 7;
-  const int a_off = (wm * 32 + l31) * 128;                 // + sb*HT
-  const int b_off = 2 * HT + (wn * 64 + l31) * 128;        // + sb*HT + jj*32*128
-  // logical 16-byte chunk of fragment ks: bf16 k-step ks = chunks 2ks + h; fp8 k-step ks/2 = chunks 4(ks/2) + 2h + (ks&1)
-  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
-
-  Cur c1;
-  c1.seg = 0; c1.kk = kt_begin;
-  while (c1.seg < 2 && c1.kk >= G.seg[c1.seg].nk && G.seg[c1.seg + 1].nk > 0) {
-    c1.kk -= G.seg[c1.seg].nk;
-    ++c1.seg;
-  }
-  load_seg(c1);
-  // prologue, in steady-state issue order: A0(0) B0(0) A1(0) B1(0) | A0(1) B0(1) A1(1)      (B1(1) goes out in p0 of tile 0)
-  Cur c2 = c1;
-  stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
-  if (nk > 1) {
-    next(c2);                                        // c2 = tile 1
-    stage(0, c2, 1); stage(2, c2, 1); stage(1, c2, 1);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) have landed
-    c1 = c2;                                         // c1 -> tile 1
-    next(c2);                                        // c2 -> tile 2
-  } else {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  bf16x8 X[4], Y[4], e0[2], e1[2], m[6];
-  {
-    const int c0 = frag_coff(0);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) X[ks] = *(const bf16x8*)(smem + a_off + frag_coff(ks));   // A0 of tile 0
-    e0[0] = *(const bf16x8*)(smem + b_off + c0);
-    e0[1] = *(const bf16x8*)(smem + b_off + 32 * 128 + c0);
-  }
-  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
-  __builtin_amdgcn_sched_barrier(0);
-
-#define RF_PP3_BAR()                    \
-  __builtin_amdgcn_sched_barrier(0);    \
-  __builtin_amdgcn_s_barrier();         \
-  __builtin_amdgcn_sched_barrier(0)
-  auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
-    const char* base = smem + (t & 1) * BUF;
-    const char* nbase = smem + ((t + 1) & 1) * BUF;
-    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
-    // ---- p0: B0 ks 1..3; DMA B1(t+1) ---------------------------------------------------------
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) {
-      const int coff = frag_coff(ks);
-      m[ks - 1] = *(const bf16x8*)(base + b_off + coff);
-      m[ks + 2] = *(const bf16x8*)(base + b_off + 32 * 128 + coff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more1) {
-      stage(3, c1, (t + 1) & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    RF_PP3_BAR();
-    mma_split<W8>(acc[0][0], acc[0][1], P, e0, m);
-    RF_PP3_BAR();
-    // ---- p1: A1, B1 ks 0; DMA A0(t+2) --------------------------------------------------------
-    {
-      const int c0 = frag_coff(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(base + HT + a_off + frag_coff(ks));
-      e1[0] = *(const bf16x8*)(base + HT + b_off + c0);
-      e1[1] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + c0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) stage(0, c2, t & 1);
-    RF_PP3_BAR();
-    mma_split<W8>(acc[1][0], acc[1][1], Q, e0, m);
-    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
-    RF_PP3_BAR();
-    // ---- p2: B1 ks 1..3; DMA B0(t+2) ---------------------------------------------------------
-#pragma unroll
-    for (int ks = 1; ks < 4; ++ks) {
-      const int coff = frag_coff(ks);
-      m[ks - 1] = *(const bf16x8*)(base + HT + b_off + coff);
-      m[ks + 2] = *(const bf16x8*)(base + HT + b_off + 32 * 128 + coff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) {
-      stage(2, c2, t & 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (more1) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    RF_PP3_BAR();
-    mma_split<W8>(acc[1][2], acc[1][3], Q, e1, m);
-    asm volatile("" : "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
-    RF_PP3_BAR();
-    // ---- p3: next tile's A0 and B0 ks 0; DMA A1(t+2) -----------------------------------------
-    if (more1) {
-      const int c0 = frag_coff(0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) Q[ks] = *(const bf16x8*)(nbase + a_off + frag_coff(ks));
-      e0[0] = *(const bf16x8*)(nbase + b_off + c0);
-      e0[1] = *(const bf16x8*)(nbase + b_off + 32 * 128 + c0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2) stage(1, c2, t & 1);
-    RF_PP3_BAR();
-    mma_split<W8>(acc[0][2], acc[0][3], P, e1, m);
-    asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
-    RF_PP3_BAR();
-    next(c1);
-    next(c2);
-  };
-  for (int t = 0; t < nk; t += 2) {
-    tile(t, X, Y);
-    if (t + 1 < nk) tile(t + 1, Y, X);
-  }
-#undef RF_PP3_BAR
-  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
-}
-
-// one 256x256 tile per block, ping-pong main loop, LDS-staged epilogue (vec_ok launches only)
-template <bool W8>
-__device__ __forceinline__ void gemm_pp_body(const GemmParams& p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ClkProbe clk;
-  clk.begin();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
-  int gi = 0;
-#pragma unroll
-  for (int t = 1; t < 4; ++t)
-    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
-  const GemmGroupDev& G = p.g[gi];
-  int tm, tn;
-  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  f32x16 acc[2][4];
-  if constexpr (W8) {
-    // mixed-precision launch: the multiply is chosen per token group (wave-uniform): fp8 groups next to bf16 groups
-    // (the LoRA'd condition rows of cfg5) in one grid, so the small group fills the tail instead of its own launch
-    if (G.w8) {
-      gemm_mainloop_pp2<true>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-      clk.end(g_clk_probe);
-      __syncthreads();
-      gemm_epilogue_lds<2, true>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
-    } else {
-      gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-      clk.end(g_clk_probe);
-      __syncthreads();
-      gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
-    }
-  } else {
-    gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-    clk.end(g_clk_probe);
-    __syncthreads();  // every wave is done reading the staged operands: the LDS is free
-    gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
-  }
-}
-__global__ __launch_bounds__(512) void gemm_bf16_pp_kernel(const GemmParams p) { gemm_pp_body<false>(p); }
 // launches on the 16x16 MFMA shapes (gemm_mainloop_pp2_m16): bf16, or W8 = mixed precision per token group
 template <bool W8>
 __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
@@ -1756,8 +1138,6 @@ __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
     }
   }
 }
-__global__ __launch_bounds__(512) void gemm_w8_pp_kernel(const GemmParams p) { gemm_pp_body<true>(p); }
-__global__ __launch_bounds__(512) void gemm_bf16_pp16_kernel(const GemmParams p) { gemm_pp16_body<false>(p); }
 // bf16 launches, evenly loaded phases (gemm_mainloop_pp3_m16)
 __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1784,248 +1164,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p
 }
 __global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) { gemm_pp16_body<true>(p); }
 
-// experiment harness for the ping-pong main loop (one tile per block, bf16 only): rf_debug_force_gemm_tile(259)
-// clock probe: block 0 stores {s_memtime, s_memrealtime} (shader clocks, 100 MHz reference) around its tile, so
-// rf_debug_gemm_clock_mhz() can report the shader clock the kernel actually ran at
-template <int VAR>
-__global__ __launch_bounds__(512) void gemm_bf16_ppx_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  ClkProbe clk;
-  clk.begin();
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
-  int gi = 0;
-#pragma unroll
-  for (int t = 1; t < 4; ++t)
-    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
-  const GemmGroupDev& G = p.g[gi];
-  int tm, tn;
-  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  if constexpr (VAR >= 7) {   // the shipped 16x16x32 loop, whole (7) or knocked out (8: no DMA, 9: no reads, 10: neither); 11: evenly loaded
-    f32x4 acc16[4][8];
-    if constexpr (VAR == 11) gemm_mainloop_pp3_m16(G, p.N, m0, n0, 0, nk, acc16, smem, w, lane);
-    else gemm_mainloop_pp2_m16<false, VAR - 7>(G, p.N, m0, n0, 0, nk, acc16, smem, w, lane);
-    clk.end(g_clk_probe);
-    __syncthreads();
-    gemm_epilogue_lds16<2, false>(p, G, acc16, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
-    return;
-  }
-  f32x16 acc[2][4];
-  if constexpr (VAR == 5) gemm_mainloop_pp2<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-  else if constexpr (VAR == 6) gemm_mainloop_pp3<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-  else gemm_mainloop_pp<false, VAR>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-  clk.end(g_clk_probe);
-  __syncthreads();
-  gemm_epilogue_lds<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
-}
-
-// ---- one wave per SIMD (rf_debug_force_gemm_tile(258)) -----------------------------------------------------------
-// 256x256x64 tile, FOUR waves (2 x 2), wave tile 128 x 128 = 4 x 4 MFMA fragments: 256 accumulator registers per lane,
-// which only fit because a 256-thread block leaves each SIMD to ONE wave (512 unified VGPR/AGPR).  Per K-tile a wave
-// multiplies 64 MFMAs from 32 fragment reads (0.5 per MFMA against 0.75 in the 8-wave kernels: a third less LDS energy
-// on a power-limited part) -- but a single wave per SIMD hides nothing, so every stall source had to go
-// (tools/kb_w4_knock.py, profiles/r02_kb_w4_knock_*.log; shader clocks per K-tile, 64 MFMAs = 2048 + issue = 2105):
-//   * fragment reads: per k-step (16 MFMAs) four groups of four MFMAs fenced by sched_barrier(0); each group first
-//     issues two of the NEXT k-step's eight reads into the other half of a register double buffer        -> 2250
-//   * LDS-DMA issue: a burst of pieces stalls the issuing wave ~55 cycles per piece and four waves issuing in lock step
-//     queue behind each other; ONE piece per group per wave, wave w behind the group's MFMA w, costs ~14.  A taken
-//     scalar branch around the piece costs a single-wave SIMD an instruction-fetch bubble, so the loop is specialised
-//     per wave (template WV) and the piece is straight-line code                                            -> 2480
-//   * landing: with two 64 KiB stages the pieces issued late in a tile have no time to land before the barrier that
-//     publishes them (3350 with the wait).  The 160 KiB LDS is therefore a RING of ten 16 KiB sub-blocks -- A rows
-//     0..127, A rows 128..255, W rows 0..127, W rows 128..255 of a K-tile, four per tile, ring position (4u + kind) % 10 --
-//     so 2.5 tiles are resident and every piece is issued >= 32 MFMA slots (~1050 cycles) before its barrier:
-//        k-step 3 of tile t-1 and k-step 0 of tile t : W(t+1), into the positions A(t-1) left at barrier(t-1)
-//        k-steps 1, 2 of tile t                      : A(t+2), into the positions W(t-1) left
-//     barrier(t) sits in front of k-step 3 (whose fragments are in registers): it publishes tile t+1 (s_waitcnt vmcnt(8):
-//     only A(t+2) may be in flight) and retires tile t, and tile t+1's first fragments are read under k-step 3's MFMAs.
-// KNOCK (timing diagnostics only, results are wrong): 1 = no LDS-DMA in the loop, 2 = no fragment reads in the loop,
-// 4 = no per-tile wait + barrier, 8 = DMA from a hot (two K-tile) source.
-template <bool W8, int KNOCK, int WV>
-__device__ __forceinline__ void gemm_mainloop_w4(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
-                                                 const int nk, f32x16 (&acc)[4][4], char* smem, const int lane) {
-  constexpr int ESZ = W8 ? 1 : 2;
-  constexpr int SUB = 16384;                 // one sub-block: 128 rows x 128 B
-  constexpr int w = WV, wm = WV >> 1, wn = WV & 1;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int M = G.M;
-  const int r8 = lane >> 3;
-  // piece j (0..3) of a sub-block, as loaded by this wave: rows (4j + w)*8 + lane/8, 1 KiB at sub-block offset (4j + w) KiB;
-  // swizzled 16-byte chunk: (row >> 1) & 7 = ((w*8 + r8) >> 1) & 7 since 32j rows do not reach those bits
-  const uint32_t chunk_b = (uint32_t)(((lane & 7) ^ (((w * 8 + r8) >> 1) & 7)) * 16);
-  // cursor over K-tiles for one operand: segment, tile in segment, resource, the wave's 8 per-lane byte offsets
-  // (pieces 0..3 of the low sub-block, 4..7 of the high one)
-  struct Cur { int seg, kk, nk; rsrc_t R; uint32_t off[8]; };   // nk: K-tiles until the next segment starts (INT_MAX in the last)
-  auto load_seg = [&](Cur& c, const bool isA) {
-    const KSegDev& S = G.seg[c.seg];
-    c.nk = (c.seg < 2 && G.seg[c.seg + 1].nk > 0) ? S.nk : 0x7fffffff;
-    c.R = isA ? RF_MAKE_RSRC(S.A) : RF_MAKE_RSRC(S.W);
-    const uint32_t pitch = (uint32_t)((isA ? S.lda : S.ldw) * ESZ);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (i >> 2) * 128 + ((i & 3) * 4 + w) * 8 + r8;
-      const int g = isA ? m0 + row : n0 + row;
-      const int lim = isA ? M : N;
-      c.off[i] = (uint32_t)(g < lim ? g : lim - 1) * pitch + chunk_b;
-    }
-  };
-  auto seek = [&](Cur& c, const bool isA) {
-    c.seg = 0; c.kk = kt_begin;
-    while (c.seg < 2 && c.kk >= G.seg[c.seg].nk && G.seg[c.seg + 1].nk > 0) {
-      c.kk -= G.seg[c.seg].nk;
-      ++c.seg;
-    }
-    load_seg(c, isA);
-  };
-  auto next = [&](Cur& c, const bool isA) {
-    ++c.kk;
-    // (a TAKEN branch costs this kernel's lone wave per SIMD a fetch bubble: the rare paths are laid out of line)
-    if (__builtin_expect(c.kk >= c.nk, 0)) {
-      c.kk = 0;
-      ++c.seg;
-      load_seg(c, isA);
-    }
-  };
-  // piece i (0..7) of the operand under cursor c into ring positions pos (low sub-block) / pos + 1 (high), pos in 0..9
-  auto mod10 = [](const int x) { return x >= 10 ? x - 10 : x; };
-  auto dma_piece = [&](const int i, const Cur& c, const int pos_lo) {
-    const int pos = mod10(pos_lo + (i >> 2));
-    char* dst = smem + pos * SUB + ((i & 3) * 4 + w) * 1024;
-    const int koff = (KNOCK & 64) ? 0 : (KNOCK & 8) ? (c.kk & 1) * 128 : c.kk * 128;
-    RF_BUF_LOAD_LDS(c.R, (lds_void*)dst, c.off[(KNOCK & 64) ? 0 : i], koff);   // 64: one 1 KiB piece over and over (TCP hits)
-  };
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int swz = (l31 >> 1) & 7;
-  auto frag_coff = [&](int ks) { return ((W8 ? ((ks >> 1) * 4 + h * 2 + (ks & 1)) : (ks * 2 + h)) ^ swz) << 4; };
-  const char* lane_rd = smem + l31 * 128;     // + ring position * SUB + row block * 4096 + frag_coff(ks)
-
-  Cur cA, cB;
-  seek(cA, true);
-  seek(cB, false);
-  // prologue, in steady-state issue order: A(0) W(0) | A(1) | W(1) pieces 0..3      (ring positions 0 1 | 2 3 | 4 5 | 6 7)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(i, cA, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(i, cB, 2);
-  next(cA, true);
-  next(cB, false);                            // both -> tile 1
-  if (nk > 1) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma_piece(i, cA, 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_piece(i, cB, 6);
-    next(cA, true);                           // cA -> tile 2; cB stays on tile 1 (pieces 4..7 go out in k-step 0)
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-
-  bf16x8 fa[2][4], fb[2][4];   // fragment double buffer by k-step parity
-  // read e of 8 of k-step ks of the tile whose A sub-blocks start at ring position pa: e < 4 -> A row block e of this
-  // wave's half, else W column block e - 4
-  auto rd = [&](const int pa, const int ks, const int e, const int par) {
-    const int coff = frag_coff(ks);
-    if (e < 4) fa[par][e] = *(const bf16x8*)(lane_rd + mod10(pa + wm) * SUB + e * 4096 + coff);
-    else fb[par][e - 4] = *(const bf16x8*)(lane_rd + mod10(pa + 2 + wn) * SUB + (e - 4) * 4096 + coff);
-  };
-#pragma unroll
-  for (int e = 0; e < 8; ++e) rd(0, 0, e, 0);
-  __builtin_amdgcn_sched_barrier(0);
-
-  int pa = 0;                                  // ring position of A(t), = (4t) % 10
-  // one K-tile; TAIL = false is the steady state (tiles t+1 and t+2 exist: no conditions, hence no branches, in it)
-  auto tile = [&](const int t, auto tail_tag) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
-    const bool more1 = !TAIL || t + 1 < nk, more2 = !TAIL || t + 2 < nk;
-    const int pa1 = mod10(pa + 4);             // A(t+1)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int par = ks & 1;
-      if (ks == 3 && !(KNOCK & 4)) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (KNOCK & 16) __builtin_amdgcn_s_waitcnt(0xc07f);   // (16: lgkmcnt(0) only)
-        else if (more2) __builtin_amdgcn_s_waitcnt(0x0078);   // vmcnt(8) lgkmcnt(0): only A(t+2) may still be in flight
-        else __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
-        if (!(KNOCK & 32)) __builtin_amdgcn_s_barrier();      // (32: waits but no barrier)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (!(KNOCK & 2)) {
-          if (ks < 3) {
-            rd(pa, ks + 1, 2 * g, par ^ 1);
-            rd(pa, ks + 1, 2 * g + 1, par ^ 1);
-          } else if (more1) {
-            rd(pa1, 0, 2 * g, 0);
-            rd(pa1, 0, 2 * g + 1, 0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if constexpr (!W8) acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[par][g], fb[par][j], acc[g][j], 0, 0, 0);
-          if (j == WV && !(KNOCK & 1)) {       // this wave's DMA slot of the group
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks == 0) { if (more1) dma_piece(4 + g, cB, mod10(pa + 6)); }        // W(t+1) pieces 4..7
-            else if (ks == 1) { if (more2) dma_piece(g, cA, mod10(pa + 8)); }       // A(t+2) pieces 0..3
-            else if (ks == 2) { if (more2) dma_piece(4 + g, cA, mod10(pa + 8)); }   // A(t+2) pieces 4..7
-            else { if (more2) dma_piece(g, cB, pa); }                               // W(t+2) pieces 0..3 (pa + 10)
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        asm volatile("" : "+a"(acc[g][0]), "+a"(acc[g][1]), "+a"(acc[g][2]), "+a"(acc[g][3]));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (ks == 0 && more1) next(cB, false);   // W(t+1) is out: cB -> tile t+2
-      if (ks == 2 && more2) next(cA, true);    // A(t+2) is out: cA -> tile t+3
-    }
-    pa = pa1;
-  };
-  int t = 0;
-  for (; t + 2 < nk; ++t) tile(t, std::false_type{});
-  for (; t < nk; ++t) tile(t, std::true_type{});
-}
-
-template <int KNOCK>
-__global__ __launch_bounds__(256) void gemm_bf16_w4_kernel(const GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  ClkProbe clk;
-  clk.begin();
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = xcd_remap(blockIdx.x, p.total_tiles);
-  int gi = 0;
-#pragma unroll
-  for (int t = 1; t < 4; ++t)
-    if (t < p.ngroups && tile >= p.g[t].tile_start) gi = t;
-  const GemmGroupDev& G = p.g[gi];
-  int tm, tn;
-  tile_coords(tile - G.tile_start, G.tiles_m, p.tiles_n, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  f32x16 acc[4][4];
-  switch (w) {
-    case 0: gemm_mainloop_w4<false, KNOCK, 0>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
-    case 1: gemm_mainloop_w4<false, KNOCK, 1>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
-    case 2: gemm_mainloop_w4<false, KNOCK, 2>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
-    default: gemm_mainloop_w4<false, KNOCK, 3>(G, p.N, m0, n0, 0, nk, acc, smem, lane); break;
-  }
-  clk.end(g_clk_probe);
-  __syncthreads();
-  gemm_epilogue_lds<4, false>(p, G, acc, m0, n0, (w >> 1) * 128, (w & 1) * 128, lane, smem + w * EPI_REGION);
-}
+#ifdef RF_EXPERIMENTS
+#include "experiments/gemm_kernels_exp.inc"
+#endif
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
 // One persistent block per CU.  The launch's MAC work is measured in K-tile iterations (tile-major) and cut into
@@ -2139,8 +1280,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
       if (g8) gemm_mainloop_pp2_m16<W8>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
       else if constexpr (EVEN && !W8) gemm_mainloop_pp3_m16(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
       else gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
-    } else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+    }
+#ifdef RF_EXPERIMENTS
+    else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     else gemm_mainloop_pp2<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
+#else
+    static_assert(MI16, "librf_flux.so ships the 16x16 MFMA shapes only");
+#endif
 
     if (!is_tail) {
       // head or middle piece: raw accumulators -> this block's slot, [quad k][thread] x 16 B, as agent-coherent
@@ -2200,8 +1346,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
       if constexpr (MI16) {
         if (g8) gemm_epilogue_lds16<FM, W8>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
         else gemm_epilogue_lds16<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
-      } else if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+      }
+#ifdef RF_EXPERIMENTS
+      else if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
       else gemm_epilogue_lds<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
+#endif
     }
   }
 }
@@ -2218,68 +1367,9 @@ static void layout_tiles(GemmParams& p) {
   p.total_tiles = start;
 }
 
-static int g_w4_knock = 0;
-template <int KNOCK>
-static int launch_gemm_w4_k(GemmParams& p, hipStream_t stream) {
-  constexpr int LDS = 10 * 16384;   // the whole 160 KiB: a ring of ten sub-blocks
-  static bool attr_set = false;
-  if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4_kernel<KNOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  layout_tiles<256, 256>(p);
-  if (p.total_tiles == 0) return RF_OK;
-  hipLaunchKernelGGL(gemm_bf16_w4_kernel<KNOCK>, dim3(p.total_tiles), dim3(256), LDS, stream, p);
-  RF_LAUNCH_CHECK();
-  return RF_OK;
-}
-template <int VAR>
-static int launch_gemm_ppx_v(GemmParams& p, hipStream_t stream) {
-  constexpr int LDS = 8 * EPI_REGION;   // > the main loop's 128 KiB
-  static bool attr_set = false;
-  if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_ppx_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  layout_tiles<256, 256>(p);
-  if (p.total_tiles == 0) return RF_OK;
-  hipLaunchKernelGGL(gemm_bf16_ppx_kernel<VAR>, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-  RF_LAUNCH_CHECK();
-  return RF_OK;
-}
-static int launch_gemm_ppx(GemmParams& p, hipStream_t stream) {
-  switch (g_w4_knock) {
-    case 1: return launch_gemm_ppx_v<1>(p, stream);
-    case 2: return launch_gemm_ppx_v<2>(p, stream);
-    case 3: return launch_gemm_ppx_v<3>(p, stream);
-    case 4: return launch_gemm_ppx_v<4>(p, stream);
-    case 5: return launch_gemm_ppx_v<5>(p, stream);
-    case 6: return launch_gemm_ppx_v<6>(p, stream);
-    case 7: return launch_gemm_ppx_v<7>(p, stream);
-    case 8: return launch_gemm_ppx_v<8>(p, stream);
-    case 9: return launch_gemm_ppx_v<9>(p, stream);
-    case 10: return launch_gemm_ppx_v<10>(p, stream);
-    case 11: return launch_gemm_ppx_v<11>(p, stream);
-    default: return launch_gemm_ppx_v<0>(p, stream);
-  }
-}
-static int launch_gemm_w4(GemmParams& p, hipStream_t stream) {
-  switch (g_w4_knock) {
-    case 1: return launch_gemm_w4_k<1>(p, stream);
-    case 2: return launch_gemm_w4_k<2>(p, stream);
-    case 3: return launch_gemm_w4_k<3>(p, stream);
-    case 4: return launch_gemm_w4_k<4>(p, stream);
-    case 7: return launch_gemm_w4_k<7>(p, stream);
-    case 8: return launch_gemm_w4_k<8>(p, stream);
-    case 10: return launch_gemm_w4_k<10>(p, stream);
-    case 16: return launch_gemm_w4_k<16>(p, stream);
-    case 64: return launch_gemm_w4_k<64>(p, stream);
-    case 66: return launch_gemm_w4_k<66>(p, stream);
-    case 32: return launch_gemm_w4_k<32>(p, stream);
-    default: return launch_gemm_w4_k<0>(p, stream);
-  }
-}
-
+#ifdef RF_EXPERIMENTS
+#include "experiments/gemm_launch_exp.inc"
+#endif
 
 template <int BM, int BN, int WM, int WN, bool VEC, bool TL = false>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
@@ -2303,33 +1393,49 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
   if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+#ifdef RF_EXPERIMENTS
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+#endif
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
-  if (p.w8 && g_mi16) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-  else if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-  else if (g_mi16 && g_even) hipLaunchKernelGGL(gemm_bf16_pp16e_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-  else if (g_mi16) hipLaunchKernelGGL(gemm_bf16_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-  else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+#ifdef RF_EXPERIMENTS
+  if (!g_tune.mi16 || (!p.w8 && !g_tune.even)) {
+    if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+    else if (g_tune.mi16) hipLaunchKernelGGL(gemm_bf16_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+    RF_LAUNCH_CHECK();
+    return RF_OK;
+  }
+#endif
+  if (p.w8) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  else hipLaunchKernelGGL(gemm_bf16_pp16e_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
 
 // scratch layout shared by split-K and stream-K: [0, 4096) stream-K flags (zero outside a launch), partials after
 constexpr int64_t WS_FLAG_BYTES = 4096;
-static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K, 3 = skinny-N (test introspection)
-static int g_force_sk = -1;  // -1 = heuristic, 0 = never, 1 = stream-K whenever feasible (tests), 2 = persistent whole tiles only
-static int g_persistent_rounds = 0;  // > 0: bf16 launches with >= this many tile rounds that do not qualify for stream-K run as ONE
-                                     // persistent launch of whole tiles.  Worth +1..4 % with the round-1 main loop (a tile's stores
-                                     // drain under the next tile's loop; profiles/r02_kb_persist.log); with the balanced loop it is
-                                     // neutral at cfg2 and -1..3 % at cfg5 sizes (profiles/r02_kb_persist_pp2.log), so it is OFF.
-                                     // rf_debug_gemm_persistent_rounds() / rf_debug_force_gemm_sk(2) still exercise it.
+static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-K / persistent, 3 = skinny-N (read-only introspection)
+// Persistent whole-tile schedule (RF_SCHED_PERSISTENT): worth +1..4 % with the round-1 main loop (a tile's stores drain under the
+// next tile's loop; profiles/r02_kb_persist.log); with the balanced loop it is neutral at cfg2 and -1..3 % at cfg5 sizes
+// (profiles/r02_kb_persist_pp2.log), so dispatch() never picks it on its own.
+
+// stream-K mode of a launch: -1 = heuristic, 0 = never, 1 = whenever feasible, 2 = persistent whole tiles only
+static int sk_mode(const GemmParams& p) {
+  if (g_tune.force_sk >= 0) return g_tune.force_sk;   // experiments build only (constant -1 in librf_flux.so)
+  switch (p.sched) {
+    case RF_SCHED_STREAMK: return 1;
+    case RF_SCHED_PERSISTENT: return 2;
+    case RF_SCHED_AUTO: return -1;
+    default: return 0;
+  }
+}
 
 // The stream-K launch relies on two properties HIP does not promise: lower-indexed blocks are dispatched first and
 // block b runs on XCD b % 8 (observed on MI355X in SPX mode; a wrong guess about the XCD costs speed only, but a
@@ -2407,7 +1513,8 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
     RF_CHECK_HIP(hipGetDevice(&dev));
     RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  if (!streamk_allowed(num_cus) && g_force_sk != 1) return 0;
+  const int force_sk = sk_mode(p);   // -1 = heuristic, 1 = whenever feasible, 2 = persistent whole tiles (0 never gets here)
+  if (!streamk_allowed(num_cus) && force_sk != 1) return 0;
   const int P = num_cus / 8 * 8;  // one persistent block per CU, 8 XCD chunks
   if (P < 8 || (int64_t)P * 4 > WS_FLAG_BYTES) return 0;
   if (ws == nullptr || ws_bytes < WS_FLAG_BYTES + (int64_t)P * BM * BN * 4) return 0;
@@ -2419,9 +1526,9 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   // under this kernel), so a last round that leaves CUs idle costs less than its tile count suggests, while the
   // stream-K region loses the lock-step L2 sharing of A/W panels.  Stream-K wins below ~83 % round utilisation
   // (S=5632: 264 tiles +40..58 %, 792 tiles +9 %, 1056 tiles +5 %) and loses above it (S=4608: 0.84 -> -2..-10 %).
-  const bool persistent_only = g_force_sk == 2 || (g_force_sk < 0 && !W8 && g_persistent_rounds > 0 && rounds >= g_persistent_rounds &&
-                                                   (double)T / ((double)rounds * P) >= 0.83);
-  if (g_force_sk < 0 && !persistent_only && (double)T / ((double)rounds * P) >= 0.83) return 0;
+  const bool persistent_only = force_sk == 2 || (force_sk < 0 && !W8 && g_tune.persistent_rounds > 0 && rounds >= g_tune.persistent_rounds &&
+                                                 (double)T / ((double)rounds * P) >= 0.83);
+  if (force_sk < 0 && !persistent_only && (double)T / ((double)rounds * P) >= 0.83) return 0;
   SkParams sk;
   {
     const int ok = sk_make_plan(p, P, sk, persistent_only);
@@ -2432,18 +1539,22 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
-  auto kern = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>;
-  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, false>;
-  auto kern16e = gemm_bf16_sk_kernel<BM, BN, WM, WN, false, true, true>;
+  // bf16 launches: evenly loaded phases (gemm_mainloop_pp3_m16); mixed-precision launches: the 8/4/8/4 loop for every group
+  auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, !W8>;
   if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16e, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+#ifdef RF_EXPERIMENTS
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+#endif
     attr_set = true;
   }
-  if (g_mi16 && g_even && !W8) hipLaunchKernelGGL(kern16e, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
-  else if (g_mi16) hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
-  else hipLaunchKernelGGL(kern, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+#ifdef RF_EXPERIMENTS
+  if (!g_tune.mi16) hipLaunchKernelGGL((gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>), dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  else if (!g_tune.even) hipLaunchKernelGGL((gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, false>), dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
+  else
+#endif
+  hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   RF_LAUNCH_CHECK();
   g_last_path = 2;
   return 1;
@@ -2474,8 +1585,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   *(u32x4*)(out + (int64_t)m * ldo + n) = pack8(v);
 }
 
-static int g_force_tile = 0;  // 0 = heuristic, 128 / 256 = forced (used by tests and the tuner)
-
 static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = false) {
   RF_REQUIRE(d != nullptr, RF_ERR_NULL, "rf_gemm_bf16: desc is NULL");
   RF_REQUIRE(d->N > 0, RF_ERR_SHAPE, "rf_gemm_bf16: N=%d", d->N);
@@ -2485,6 +1594,8 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
   memset(&p, 0, sizeof(p));
   p.w8 = w8 ? 1 : 0;
   p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
+  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_PLAIN256, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
+  p.sched = d->schedule;
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
   p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin; p.norm_eps = d->norm_eps;
@@ -2551,7 +1662,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
           (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
   }
   p.vec_ok = vec ? 1 : 0;
-  p.nt_store = g_nt_store;
+  p.nt_store = g_tune.nt_store;
   if (w8) {
     RF_REQUIRE(vec, RF_ERR_ALIGN, "rf_gemm_w8a8: needs N %% 8 == 0 and 16-byte aligned outputs / bias / gate / residual");
     bool any8 = false;
@@ -2572,125 +1683,24 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
   return RF_OK;
 }
 
-// ---- skinny-N GEMM: T[M x N] = A[M x K] . W[N x K]^T with N <= 128 (the LoRA down-projections x . lora_A^T) --------------
-// 8 output "tiles" of 128^2 and up to 240 K-tiles: the tiled kernels ran it as split-K + a reduce launch (12-16 + 5-9 us,
-// 134 times per cfg4 forward = 6 % of it).  Here ONE launch: a workgroup owns 16 rows and all N columns; its 8 waves take
-// the 64-wide K-tiles round robin, each multiplying 16x16x32 MFMAs straight from global memory (A fragment: row lane&15,
-// 16 bytes at k = 8*(lane>>4); W fragment likewise -- lora_A is <= 2 MB and stays in L2), with the next K-tile's fragments
-// in flight; the 8 partial accumulators meet in LDS and are summed in wave order (deterministic).  No bias, plain store.
-template <int NT>   // NT = N / 16 column tiles
-__global__ __launch_bounds__(512) void gemm_skinny_kernel(const GemmParams p) {
-  __shared__ float part[8][NT][256];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, g = lane >> 4;
-  const GemmGroupDev& G = p.g[0];
-  const int M = G.M;
-  const int m0 = blockIdx.x * 16;
-  const int row = m0 + l15 < M ? m0 + l15 : M - 1;
-  const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[ct][r] = 0.f;
-  // K-tile kt of the concatenated segments -> fragment pointers (A row, W row l15 of column tile 0; + ct*16*ldw per tile)
-  auto locate = [&](int kt, const bf16_t*& a, const bf16_t*& wq, int64_t& ldw) {
-    int s = 0;
-    while (s < 2 && kt >= G.seg[s].nk) { kt -= G.seg[s].nk; ++s; }
-    a = G.seg[s].A + (int64_t)row * G.seg[s].lda + kt * 64 + g * 8;
-    wq = G.seg[s].W + (int64_t)l15 * G.seg[s].ldw + kt * 64 + g * 8;
-    ldw = G.seg[s].ldw;
-  };
-  // two fragment buffers with COMPILE-TIME names (a runtime buffer index would put the arrays in scratch memory)
-  struct Frag { bf16x8 a[2]; bf16x8 w[NT][2]; };   // [k-step of the K-tile]
-  auto load = [&](int kt, Frag& f) {
-    const bf16_t *a, *wq;
-    int64_t ldw;
-    locate(kt, a, wq, ldw);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f.a[ks] = *(const bf16x8*)(a + ks * 32);
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) f.w[ct][ks] = *(const bf16x8*)(wq + (int64_t)ct * 16 * ldw + ks * 32);
-    }
-  };
-  auto mma = [&](const Frag& f) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.a[ks], f.w[ct][ks], acc[ct], 0, 0, 0);
-  };
-  Frag f0, f1;
-  int kt = w;
-  if (kt < nk) load(kt, f0);
-  while (kt < nk) {
-    if (kt + 8 < nk) load(kt + 8, f1);
-    mma(f0);
-    kt += 8;
-    if (kt >= nk) break;
-    if (kt + 8 < nk) load(kt + 8, f0);
-    mma(f1);
-    kt += 8;
-  }
-#pragma unroll
-  for (int ct = 0; ct < NT; ++ct) *(f32x4*)&part[w][ct][lane * 4] = acc[ct];
-  __syncthreads();
-  // output element (r, c), r < 16, c < 16*NT: accumulator of lane (r/4)*16 + c%16, register r%4, tile c/16; two adjacent columns per thread
-  for (int e = tid; e < 16 * NT * 8; e += 512) {
-    const int r = e / (NT * 8), c = (e % (NT * 8)) * 2;
-    if (m0 + r >= M) continue;
-    float v[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int cc = c + j, idx = ((r >> 2) * 16 + (cc & 15)) * 4 + (r & 3);
-      float sum = 0.f;
-#pragma unroll
-      for (int ww = 0; ww < 8; ++ww) sum += part[ww][cc >> 4][idx];
-      v[j] = sum;
-    }
-    *(uint32_t*)(G.out + (int64_t)(m0 + r) * G.ldo + c) = pack2(v[0], v[1]);
-  }
-}
-
-static bool skinny_ok(const GemmParams& p) {
-  if (p.ngroups != 1 || p.epi != RF_EPI_STORE || p.w8 || !p.vec_ok || p.N > 128 || p.N % 16 != 0) return false;
-  const GemmGroupDev& G = p.g[0];
-  if (G.bias != nullptr || G.M <= 0) return false;
-  for (int s = 0; s < 3; ++s)
-    if (G.seg[s].nk > 0 && (((uintptr_t)G.seg[s].A | (uintptr_t)G.seg[s].W) & 15 || (G.seg[s].lda | G.seg[s].ldw) % 8 != 0)) return false;
-  return true;
-}
-
-static int launch_gemm_skinny(GemmParams& p, hipStream_t stream) {
-  const dim3 grid(cdiv(p.g[0].M, 16)), blk(512);
-  switch (p.N / 16) {
-    case 1: hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, blk, 0, stream, p); break;
-    case 2: hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, blk, 0, stream, p); break;
-    case 3: hipLaunchKernelGGL(gemm_skinny_kernel<3>, grid, blk, 0, stream, p); break;
-    case 4: hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, blk, 0, stream, p); break;
-    case 5: hipLaunchKernelGGL(gemm_skinny_kernel<5>, grid, blk, 0, stream, p); break;
-    case 6: hipLaunchKernelGGL(gemm_skinny_kernel<6>, grid, blk, 0, stream, p); break;
-    case 7: hipLaunchKernelGGL(gemm_skinny_kernel<7>, grid, blk, 0, stream, p); break;
-    default: hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, blk, 0, stream, p); break;
-  }
-  RF_LAUNCH_CHECK();
-  return RF_OK;
-}
-static int g_skinny = 0;   // OFF: measured slower than split-K + reduce (tools/kb_skinny.py: 16 vs 13 us at K = 3072, 54 vs 23 at
-                           // K = 12288, M = 1024).  A wave's K-tiles are a dependent chain of ~2.5 us memory round trips and
-                           // 64 workgroups x 8 waves do not put enough loads in flight; split-K's 256 workgroups do.  Kept
-                           // behind rf_debug_gemm_skinny(1) with its test.
-
 static int dispatch(GemmParams& p, hipStream_t stream) {
   if (p.ngroups == 0) return RF_OK;
   int64_t rows = 0;
   for (int g = 0; g < p.ngroups; ++g) rows += p.g[g].M;
-  int tile = g_force_tile;
+  // tile: 128 / 256 = the shipped kernels, 257 = plain 256x256 loop (bit-exact reference of the ping-pong loops);
+  // 258 / 259 = experiments build only
+  int tile = g_tune.force_tile;
   if (tile == 0) {
-    // 256^2 tiles only pay when they still fill the 256 CUs; small problems get 128^2.
-    const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
-    tile = (t256 >= 200) ? 256 : 128;
+    switch (p.sched) {
+      case RF_SCHED_TILE128: tile = 128; break;
+      case RF_SCHED_TILE256: case RF_SCHED_STREAMK: case RF_SCHED_PERSISTENT: tile = 256; break;
+      case RF_SCHED_PLAIN256: tile = 257; break;
+      default: {
+        // 256^2 tiles only pay when they still fill the 256 CUs; small problems get 128^2.
+        const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
+        tile = (t256 >= 200) ? 256 : 128;
+      }
+    }
   }
   double flops = 0.0;  // algorithmic: 2 M N K over groups and K-segments
   for (int g = 0; g < p.ngroups; ++g)
@@ -2704,13 +1714,15 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
-  if (g_skinny && g_force_tile == 0 && skinny_ok(p)) {
+#ifdef RF_EXPERIMENTS
+  if (g_tune.skinny && g_tune.force_tile == 0 && p.sched == RF_SCHED_AUTO && skinny_ok(p)) {
     g_last_path = 3;
     return launch_gemm_skinny(p, stream);
   }
-  if ((tile == 257 || tile == 258 || tile == 259) && (!p.vec_ok || p.w8)) tile = 256;
+#endif
+  if (tile >= 257 && (!p.vec_ok || p.w8)) tile = 256;
   if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
-  if (tile == 256 && p.vec_ok && g_force_sk != 0) {   // (forced 257 / 258 skip the stream-K / persistent paths)
+  if (tile == 256 && p.vec_ok && sk_mode(p) != 0) {   // (the plain reference loop / experimental kernels skip the stream-K paths)
     const int rc = p.w8 ? try_launch_gemm_sk<256, 256, 4, 2, true>(p, ws_base, ws_total, stream)
                         : try_launch_gemm_sk<256, 256, 4, 2, false>(p, ws_base, ws_total, stream);
     if (rc != 0) return rc < 0 ? rc : RF_OK;
@@ -2739,9 +1751,11 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   }
   g_last_path = 0;
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
-  if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (A/B reference)
+  if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (bit-exact reference)
+#ifdef RF_EXPERIMENTS
   if (tile == 258) return launch_gemm_w4(p, stream);                       // one wave per SIMD (experimental A/B)
   if (tile == 259) return launch_gemm_ppx(p, stream);                      // ping-pong loop experiments
+#endif
   if (tile == 256) return p.vec_ok ? launch_gemm_pp(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }
@@ -2762,26 +1776,8 @@ extern "C" int rf_gemm_w8a8(const rf_gemm_desc* d, void* stream) {
   return rf::dispatch(p, (hipStream_t)stream);
 }
 
-// test / tuning hook (not part of the drop-in surface): force a tile config (0 = heuristic)
-extern "C" int rf_debug_force_gemm_tile(int tile) {
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 257 && tile != 258 && tile != 259) return RF_ERR_SHAPE;
-  rf::g_force_tile = tile;
-  return RF_OK;
-}
-
-// debug: run the 256x256 tile-per-block kernel with s_memtime instrumentation; out = device u64[16 blocks][8 waves][8]
-// (per wave: cycles in the DMA drain, in the barrier, in the K-tile bodies, total, K-tiles) of blocks 0..15 (mod 16)
-extern "C" int rf_debug_gemm_timeline(const rf_gemm_desc* d, unsigned long long* out, void* stream) {
-  rf::GemmParams p;
-  int rc = rf::build_params(d, p);
-  if (rc != RF_OK) return rc;
-  RF_REQUIRE(p.vec_ok && out != nullptr, RF_ERR_ALIGN, "rf_debug_gemm_timeline: needs the aligned path and an output buffer");
-  p.timeline = out;
-  p.ksplit = 1;
-  return rf::launch_gemm<256, 256, 4, 2, true, true>(p, (hipStream_t)stream);
-}
-
-// debug / CPU tests: the stream-K plan of a launch for a chip with num_cus CUs (no device access).
+// ---- read-only introspection (tests, bench): no entry point below changes what the library runs ----------------------------
+// CPU tests: the stream-K plan of a launch for a chip with num_cus CUs (no device access).
 // out[0..4] iter_start, [5..8] nk, [9..16] chunk_tile, [17..24] dp_rounds, [25..32] sk_begin, [33..40] chunk_end,
 // [41] tiles_n, [42..45] tiles_m per group, [46..49] tile_start per group, [50] total tiles.  Returns 1 = plan made,
 // 0 = launch does not qualify, < 0 error.
@@ -2804,6 +1800,7 @@ extern "C" int rf_debug_sk_plan(const rf_gemm_desc* d, int32_t num_cus, int32_t*
   return 1;
 }
 
+// which schedule the last GEMM launch took: 0 = one tile per block, 1 = split-K, 2 = stream-K / persistent (3 = skinny-N, experiments build)
 extern "C" int rf_debug_last_gemm_path(void) { return rf::g_last_path; }
 
 namespace rf {
@@ -2813,7 +1810,7 @@ int read_clk_probe_gemm(unsigned long long* h) {
 }  // namespace rf
 // which: 0 = the last completed 256x256 ping-pong GEMM launch (one tile per block), 1 = the last bounded-score attention
 // launch.  mhz = shader clocks per microsecond over block 0's main loop, us = that loop's duration.  The caller
-// synchronises the stream first.
+// synchronises the stream first; single-stream use only (the probe words are written by block 0 of the last launch).
 extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
   unsigned long long h[4];
   if (which == 2) {   // block 0 / wave 0 of the last 16x16x32 GEMM launch: end of its main loop -> its epilogue stores acknowledged
@@ -2830,21 +1827,37 @@ extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
   *mhz = *us > 0 ? (double)(h[2] - h[0]) / *us : 0.0;
   return RF_OK;
 }
-extern "C" int rf_debug_gemm_nt_store(int on) { rf::g_nt_store = on ? 1 : 0; return RF_OK; }   // A/B hook
-extern "C" int rf_debug_gemm_skinny(int on) { rf::g_skinny = on ? 1 : 0; return RF_OK; }   // A/B hook: skinny-N kernel vs split-K
-extern "C" int rf_debug_gemm_even(int on) { rf::g_even = on ? 1 : 0; return RF_OK; }   // A/B hook: 6/6/6/6 vs 8/4/8/4 phases
-extern "C" int rf_debug_gemm_mi16(int on) { rf::g_mi16 = on ? 1 : 0; return RF_OK; }   // A/B hook: MFMA shape of the bf16 256x256 kernel
-extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_w4_knock = k; return RF_OK; }
-extern "C" int rf_debug_gemm_persistent_rounds(int rounds) {  // tuning hook: see g_persistent_rounds
-  rf::g_persistent_rounds = rounds < 0 ? 0 : rounds;
+
+#ifdef RF_EXPERIMENTS
+// ---- experiments build only (librf_flux_exp.so): kernel-selecting switches for tools/kb_*.py ------------------------------
+extern "C" int rf_debug_force_gemm_tile(int tile) {
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 257 && tile != 258 && tile != 259) return RF_ERR_SHAPE;
+  rf::g_tune.force_tile = tile;
   return RF_OK;
 }
-
+// run the 256x256 tile-per-block kernel with s_memtime instrumentation; out = device u64[16 blocks][8 waves][8]
+// (per wave: cycles in the DMA drain, in the barrier, in the K-tile bodies, total, K-tiles) of blocks 0..15 (mod 16)
+extern "C" int rf_debug_gemm_timeline(const rf_gemm_desc* d, unsigned long long* out, void* stream) {
+  rf::GemmParams p;
+  int rc = rf::build_params(d, p);
+  if (rc != RF_OK) return rc;
+  RF_REQUIRE(p.vec_ok && out != nullptr, RF_ERR_ALIGN, "rf_debug_gemm_timeline: needs the aligned path and an output buffer");
+  p.timeline = out;
+  p.ksplit = 1;
+  return rf::launch_gemm<256, 256, 4, 2, true, true>(p, (hipStream_t)stream);
+}
+extern "C" int rf_debug_gemm_nt_store(int on) { rf::g_tune.nt_store = on ? 1 : 0; return RF_OK; }
+extern "C" int rf_debug_gemm_skinny(int on) { rf::g_tune.skinny = on ? 1 : 0; return RF_OK; }   // skinny-N kernel vs split-K
+extern "C" int rf_debug_gemm_even(int on) { rf::g_tune.even = on ? 1 : 0; return RF_OK; }       // 6/6/6/6 vs 8/4/8/4 phases
+extern "C" int rf_debug_gemm_mi16(int on) { rf::g_tune.mi16 = on ? 1 : 0; return RF_OK; }       // MFMA shape of the bf16 256x256 kernel
+extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_tune.w4_knock = k; return RF_OK; }
+extern "C" int rf_debug_gemm_persistent_rounds(int rounds) { rf::g_tune.persistent_rounds = rounds < 0 ? 0 : rounds; return RF_OK; }
 extern "C" int rf_debug_force_gemm_sk(int mode) {
   if (mode < -1 || mode > 2) return RF_ERR_SHAPE;
-  rf::g_force_sk = mode;
+  rf::g_tune.force_sk = mode;
   return RF_OK;
 }
+#endif
 
 static int time_gemm_impl(const rf_gemm_desc* d, int32_t iters, float* us, void* stream, bool w8);
 extern "C" int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream) { return time_gemm_impl(d, iters, us, stream, false); }

@@ -95,9 +95,10 @@ def attn_forward(attn, hidden_states, encoder_hidden_states=None, condition_late
             mode, bias = 1, math.log(cf)
         elif not model_config.get("union_cond_attn", True):
             mode = 2
-    # the per-head RMSNorm bounds every score by the norm weights alone (ops.qk_score_bound)
-    bound = ops.qk_score_bound((attn.norm_q.weight,) + ((attn.norm_added_q.weight,) if has_txt else ()),
-                               (attn.norm_k.weight,) + ((attn.norm_added_k.weight,) if has_txt else ()))
+    # No score bound on this per-op path: deriving one (ops.qk_score_bound) reads max|w| of the norm weights back to the
+    # host -- 2-4 device syncs per call and a hipGraph-capture error.  score_bound = 0 takes the lagged-max kernel, which is
+    # exact for any weights and as fast; the packed engine derives the bound ONCE at pack time (engine.pack_*).
+    bound = 0.0
     outs = []
     for b in range(B):
         q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)

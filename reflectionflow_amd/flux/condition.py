@@ -34,6 +34,14 @@ class Condition(object):
         else:
             self.condition = condition
         self.position_delta = position_delta
+        self.generator = None     # optional torch.Generator for the VAE posterior sample in encode() (None: global RNG, as the reference)
+
+    def with_generator(self, generator):
+        """A shallow copy that samples the VAE posterior from `generator` (the image / tokens are shared, not copied)."""
+        import copy
+        c = copy.copy(self)
+        c.generator = generator
+        return c
 
     def get_condition(self, condition_type: str, raw_img):
         if condition_type in _PASS_THROUGH:
@@ -60,7 +68,8 @@ class Condition(object):
             tokens, ids = self.tokens, self.ids.clone()
         else:
             # NB the reference encodes the real condition even when empty=True (condition.py:114-121)
-            tokens, ids = encode_images(pipe, self.condition)
+            tokens, ids = encode_images(pipe, self.condition) if self.generator is None else \
+                encode_images(pipe, self.condition, generator=self.generator)
         if self.position_delta is None and self.condition_type == "subject" and self.condition is not None:
             self.position_delta = [0, -self.condition.size[0] // 16]
         if self.position_delta is not None:

@@ -5,10 +5,13 @@ packed-token layout."""
 from torch import Tensor
 
 
-def encode_images(pipeline, images: Tensor):
+def encode_images(pipeline, images: Tensor, generator=None):
+    """`generator` (not in the reference signature, default None = the reference's global-RNG draw): the torch.Generator the
+    VAE posterior sample is drawn from."""
     images = pipeline.image_processor.preprocess(images)
     images = images.to(pipeline.device).to(pipeline.dtype)
-    images = pipeline.vae.encode(images).latent_dist.sample()
+    dist = pipeline.vae.encode(images).latent_dist
+    images = dist.sample() if generator is None else dist.sample(generator=generator)
     images = (images - pipeline.vae.config.shift_factor) * pipeline.vae.config.scaling_factor
     images_tokens = pipeline._pack_latents(images, *images.shape)
     images_ids = pipeline._prepare_latent_image_ids(images.shape[0], images.shape[2], images.shape[3],

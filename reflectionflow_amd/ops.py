@@ -6,6 +6,8 @@ library raises.
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import ctypes as C
 import math
 from typing import Optional, Sequence
@@ -17,7 +19,34 @@ from ._lib import (RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV, RF_EPI_QKV_GELU, RF
 
 __all__ = ["linear", "gemm", "build_gemm_desc", "time_gemm", "Group", "Seg", "qk_rmsnorm_rope", "attention", "layernorm_modulate",
            "euler_step_", "silu", "add_", "alloc_attn_operands", "stream_ptr", "ptr", "RFError", "QK_PRESCALE", "profile",
-           "quantize_weight_fp8", "dequantize_fp8", "quant_rows_fp8", "layernorm_modulate_fp8", "gemm_w8a8", "qk_score_bound"]
+           "quantize_weight_fp8", "dequantize_fp8", "quant_rows_fp8", "layernorm_modulate_fp8", "gemm_w8a8", "qk_score_bound",
+           "gemm_schedule", "attn_kernel"]
+
+
+# Per-context defaults for the `schedule` / `kernel` field of the launch descriptors (thread- and task-local; every launch still
+# carries its own value in its descriptor -- the library itself has no global switch).  Tests and tools use the context managers.
+_SCHED = contextvars.ContextVar("rf_gemm_schedule", default=L.RF_SCHED_AUTO)
+_ATTN_KERNEL = contextvars.ContextVar("rf_attn_kernel", default=L.RF_ATTN_AUTO)
+
+
+@contextlib.contextmanager
+def gemm_schedule(schedule: int):
+    """`with ops.gemm_schedule(L.RF_SCHED_STREAMK): ...` -- GEMM launches built inside default to this rf_gemm_schedule."""
+    tok = _SCHED.set(schedule)
+    try:
+        yield
+    finally:
+        _SCHED.reset(tok)
+
+
+@contextlib.contextmanager
+def attn_kernel(kernel: int):
+    """`with ops.attn_kernel(L.RF_ATTN_ONLINE256): ...` -- attention launches inside default to this rf_attn_kernel."""
+    tok = _ATTN_KERNEL.set(kernel)
+    try:
+        yield
+    finally:
+        _ATTN_KERNEL.reset(tok)
 
 
 def stream_ptr() -> int:
@@ -93,10 +122,12 @@ class Group:
 
 def build_gemm_desc(groups: Sequence[Group], N: int, epilogue: int = RF_EPI_STORE, n_split: int = 0,
                     q=None, k=None, vt=None, heads: int = 0, s_pad: int = 0, rope=None, norm_eps: float = 1e-6,
-                    q_scale: float = 0.0, splitk_ws: Optional[torch.Tensor] = None) -> "L.rf_gemm_desc":
+                    q_scale: float = 0.0, splitk_ws: Optional[torch.Tensor] = None,
+                    schedule: Optional[int] = None) -> "L.rf_gemm_desc":
     """rope=(cos, sin) fp32 [S,128]: fuse per-head RMSNorm (each group's norm_q/norm_k) + RoPE into the
-    QKV epilogue."""
+    QKV epilogue.  schedule: rf_gemm_schedule for THIS launch (tests pin kernels with it; the product passes AUTO)."""
     d = L.rf_gemm_desc()
+    d.schedule = _SCHED.get() if schedule is None else schedule
     d.N, d.epilogue, d.num_groups, d.n_split = N, epilogue, len(groups), n_split
     d.q, d.k, d.vt, d.heads, d.s_pad = ptr(q), ptr(k), ptr(vt), heads, s_pad
     d.q_scale = q_scale
@@ -300,9 +331,11 @@ def qk_score_bound(*norm_weights_qk) -> float:
 
 def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
               cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False,
-              score_bound: float = 0.0, scratch: bool = True) -> torch.Tensor:
+              score_bound: float = 0.0, scratch: bool = True, kernel: Optional[int] = None,
+              lag_thresh: float = 0.0) -> torch.Tensor:
     """scratch=True attaches the per-(device, stream) scratch that lets the library split a poorly filling grid
-    (rf_attention_fwd_ws); scratch=False is rf_attention_fwd."""
+    (rf_attention_fwd_ws); scratch=False is rf_attention_fwd.  kernel: rf_attn_kernel for THIS launch (an unrunnable
+    request raises); lag_thresh: re-centring threshold of the lagged-max kernels (0 = 2^30)."""
     lib = L.load()
     _chk(q, "q"), _chk(k, "k"), _chk(vt, "vt")
     heads, s_pad = q.shape[0], q.shape[1]
@@ -311,11 +344,16 @@ def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Opti
     _rows2d(out, "out")
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
-    ws = attn_scratch(q.device) if scratch else None
-    L.check(lib.rf_attention_fwd_ws(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), heads, S, s_pad,
-                                    out.stride(0), S if n_main is None else n_main, mode, cross_bias, scale,
-                                    1 if q_prescaled else 0, float(score_bound), ptr(ws), ws.numel() * 4 if ws is not None else 0,
-                                    stream_ptr()), "rf_attention_fwd_ws")
+    # the split launch exists for the shift-free kernels only (mode 0, whole rounds of the ring, prescaled q, heads % 8 == 0):
+    # do not pin 68 MiB per (device, stream) for launches that can never use it
+    ws = attn_scratch(q.device) if (scratch and mode == 0 and S % 256 == 0 and q_prescaled and heads % 8 == 0) else None
+    d = L.rf_attn_desc()
+    d.q, d.k, d.vt, d.out = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.heads, d.S, d.s_pad, d.n_main, d.ldo = heads, S, s_pad, S if n_main is None else n_main, out.stride(0)
+    d.mode, d.q_prescaled, d.cross_bias, d.scale = mode, 1 if q_prescaled else 0, cross_bias, scale
+    d.score_bound, d.lag_thresh, d.kernel = float(score_bound), float(lag_thresh), _ATTN_KERNEL.get() if kernel is None else kernel
+    d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4 if ws is not None else 0
+    L.check(lib.rf_attention(C.byref(d), stream_ptr()), "rf_attention")
     return out
 
 

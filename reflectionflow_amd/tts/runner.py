@@ -66,7 +66,7 @@ def candidate_condition(pipe: FluxPipeline, latents: torch.Tensor, height: int, 
     z = z / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor
     img = pipe.image_processor.postprocess(pipe.vae.decode(z.to(pipe.vae.dtype), return_dict=False)[0], output_type="pil")[0]
     img = img.resize((condition_size, condition_size))
-    return Condition(condition=img, condition_type="cot", position_delta=[0, -(condition_size // 16)])
+    return Condition(condition=img, condition_type="cot", position_delta=[0, -condition_size // 16])   # as the reference: -size // 16
 
 
 def latent_to_condition(latents: torch.Tensor, height: int, width: int, condition_size: int) -> Condition:
@@ -79,7 +79,7 @@ def latent_to_condition(latents: torch.Tensor, height: int, width: int, conditio
     z = torch.nn.functional.interpolate(z, size=(hc, hc), mode="area")
     tokens = P._pack_latents(z, 1, 16, hc, hc).to(latents.dtype)
     ids = P._prepare_latent_image_ids(1, hc // 2, hc // 2, latents.device, latents.dtype)
-    return Condition("cot", tokens=tokens, ids=ids, position_delta=[0, -(condition_size // 16)])
+    return Condition("cot", tokens=tokens, ids=ids, position_delta=[0, -condition_size // 16])
 
 
 def _save(path: str, latents: torch.Tensor, pipe: FluxPipeline, height: int, width: int):
@@ -115,7 +115,7 @@ def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: F
 
 
 def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
-                          start_index: int = 0, verifier=search.stub_verifier) -> List[dict]:
+                          start_index: int = 0, verifier=None, score_batch=None) -> List[dict]:
     """Reflection rounds.  Deliberate deviation from tts_reflectionflow.py:314-322: the reference's `generate`
     call passes neither `latents`, `num_inference_steps` nor `guidance_scale` (so its defaults -- 28 steps,
     guidance 3.5, noise from the global RNG -- apply and the `get_noises` seeds only name files, SURVEY 8a quirks);
@@ -133,30 +133,30 @@ def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pip
         for rnd in range(0, sa["search_rounds"] + 1):
             seeds = candidate_seeds(index + start_index, rnd, N)
 
+            cond_of_kept: Dict[int, Condition] = {}   # one decode -> resize per kept latent and round, shared by its candidates
+
             def gen(i, seed):
                 noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seed])[seed]
                 conds = None
                 if rnd > 0:                                                     # round 0 = plain t2i (noise scaling)
-                    conds = [candidate_condition(pipe, kept[i % len(kept)], pa["height"], pa["width"], pa["condition_size"])]
-                    torch.manual_seed(seed)     # Condition.encode samples the VAE posterior from the global RNG
-                                                # (pipeline_tools.py:10): seed it per candidate -> world-size independent
+                    j = i % len(kept)
+                    if j not in cond_of_kept:
+                        cond_of_kept[j] = candidate_condition(pipe, kept[j], pa["height"], pa["width"], pa["condition_size"])
+                    # Condition.encode samples the VAE posterior (pipeline_tools.py:10; the reference draws from the global
+                    # RNG): a per-candidate generator makes the sample a function of the candidate's seed alone --
+                    # world-size independent, and the search loop leaves the global CPU / GPU RNG state untouched
+                    conds = [cond_of_kept[j].with_generator(torch.Generator(device="cpu").manual_seed(seed))]
                 lat = generate(pipe, prompt=[prompt], conditions=conds, height=pa["height"], width=pa["width"],
                                num_inference_steps=pa["num_inference_steps"], guidance_scale=pa["guidance_scale"],
                                latents=noise, model_config=model_cfg, default_lora=True, output_type="latent").images
                 _save(os.path.join(pdir, "samples", f"{rnd}_round@{seed}"), lat, pipe, pa["height"], pa["width"])
                 return lat
 
-            sel, scores, local = search.run_round(shard, seeds, gen, verifier, topk=topk)
-            # hand the selected latents to every rank (N x 512 KiB at 1024^2; the reference hands PNG paths over)
-            kept = []
-            for i in sel:
-                lat = local.get(i)
-                if shard.world_size > 1:
-                    buf = lat if lat is not None else torch.empty(1, (pa["height"] // 16) * (pa["width"] // 16), 64,
-                                                                  device=dev, dtype=dtype)
-                    torch.distributed.broadcast(buf, src=shard.owner(i))
-                    lat = buf
-                kept.append(lat)
+            sel, scores, local = search.run_round(shard, seeds, gen, verifier, topk=topk, score_batch=score_batch)
+            # hand the selected latents to every rank: ONE all-gather (topk x 512 KiB per rank at 1024^2; the reference hands
+            # PNG paths over)
+            like = torch.empty(1, (pa["height"] // 16) * (pa["width"] // 16), 64, device=dev, dtype=dtype)
+            kept = search.allgather_selected_latents(shard, sel, local, like)
             log.append({"prompt": prompt, "round": rnd, "seeds": seeds, "scores": scores, "selected": sel})
         if shard.rank == 0:
             os.makedirs(pdir, exist_ok=True)

@@ -4,9 +4,10 @@ The reference generates the N candidates of a round one after the other on one G
 (tts/tts_t2i_noise_scaling.py:44-70, tts/tts_reflectionflow.py:297-332).  Candidates share nothing
 but the weights, so here candidate i of a round runs on rank i % world_size (one process per GPU,
 weights replicated: 24 GB of 288 GB), and the ONLY exchange is one all-gather of the per-candidate
-verifier outputs {score f32, label i32} at the round boundary (<= 256 B for N = 32 -> pure latency
+verifier outputs {score f32, label i32} (8-byte records) at the round boundary (<= 256 B for N = 32 -> pure latency
 on xGMI; RCCL when the backend is "nccl", gloo in the CPU tests).  Every rank then runs the same
-deterministic top-k, so no further communication is needed.
+deterministic top-k.  The reflection loop adds ONE all-gather of the selected packed latents per round
+(`allgather_selected_latents`, topk x 512 KiB per rank at 1024^2) instead of the reference's PNG-path hand-off.
 
 Selection rule = the reference's NVILA key (tts_reflectionflow.py:165-170): label "yes" first by
 descending score, then "no" by ascending score; ties broken by candidate index; the selection is
@@ -48,28 +49,70 @@ def init_distributed(backend: Optional[str] = None) -> Shard:
     return Shard(rank, world)
 
 
+def _collective_device(device=None):
+    if device is not None:
+        return torch.device(device)
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def allgather_scores(shard: Shard, n: int, local: Dict[int, Tuple[float, int]], device=None) -> List[Tuple[float, int]]:
-    """All-gather {score, label} of the n candidates of a round.  `local` maps this rank's candidate
-    indices to (score, label in {0: no, 1: yes}).  Returns the full list on every rank."""
+    """All-gather the round message of the n candidates: ONE collective of 8-byte records {float32 score, int32 label}
+    (<= 256 B for N = 32), label in {0: no, 1: yes}, -1 = empty slot.  `local` maps this rank's candidate
+    indices to (score, label).  Returns the full list on every rank."""
+    s = torch.tensor([float(local[i][0]) for i in shard.mine(n)], dtype=torch.float32)
+    lab = torch.tensor([int(local[i][1]) for i in shard.mine(n)], dtype=torch.int32)
+    sc, lb = allgather_score_tensors(shard, n, s, lab, device=device)
+    return [(float(a), int(b)) for a, b in zip(sc.tolist(), lb.tolist())]
+
+
+def allgather_score_tensors(shard: Shard, n: int, scores: torch.Tensor, labels: torch.Tensor, device=None,
+                            collective: Optional[bool] = None):
+    """Tensor form of the exchange (what an on-device verifier feeds): `scores` f32 / `labels` i32 of this rank's candidates
+    (in shard.mine(n) order, on any device) -> (scores [n] f32, labels [n] i32) in candidate order, on the CPU, identical on
+    every rank.  The wire format is one int32 [per, 2] tensor per rank: {bit pattern of the f32 score, label}.
+    collective: None = only when world_size > 1; True = also at world size 1 (the GPU-box RCCL rehearsal test)."""
     per = (n + shard.world_size - 1) // shard.world_size
-    buf = torch.full((per, 2), float("nan"), dtype=torch.float32)
-    for slot, i in enumerate(shard.mine(n)):
-        s, lab = local[i]
-        buf[slot, 0], buf[slot, 1] = float(s), float(lab)
-    if shard.world_size > 1:
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-        buf = buf.to(device)
-        out = torch.empty(shard.world_size * per, 2, dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(out, buf)
-        out = out.cpu().view(shard.world_size, per, 2)
+    mine = shard.mine(n)
+    assert scores.numel() == len(mine) and labels.numel() == len(mine)
+    if collective is None:
+        collective = shard.world_size > 1
+    dev = _collective_device(device) if collective else scores.device
+    rec = torch.empty(per, 2, dtype=torch.int32, device=dev)
+    rec[:, 0] = torch.tensor(float("nan"), dtype=torch.float32).view(torch.int32)
+    rec[:, 1] = -1
+    if len(mine):
+        rec[: len(mine), 0] = scores.to(dev, torch.float32).contiguous().view(torch.int32)
+        rec[: len(mine), 1] = labels.to(dev, torch.int32)
+    if collective:
+        out = torch.empty(shard.world_size * per, 2, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(out, rec)
     else:
-        out = buf.view(1, per, 2)
-    res: List[Tuple[float, int]] = []
-    for i in range(n):
-        r, slot = i % shard.world_size, i // shard.world_size
-        res.append((float(out[r, slot, 0]), int(out[r, slot, 1])))
-    return res
+        out = rec
+    out = out.cpu().view(shard.world_size, per, 2)
+    idx = torch.arange(n)
+    sel = out[idx % shard.world_size, idx // shard.world_size]             # candidate i lives at [i % world][i // world]
+    return sel[:, 0].contiguous().view(torch.float32), sel[:, 1].contiguous()
+
+
+def allgather_selected_latents(shard: Shard, sel: Sequence[int], local: Dict[int, torch.Tensor], like: torch.Tensor, device=None):
+    """Hand the selected candidates' packed latents to every rank with ONE all-gather (the reference hands PNG paths over,
+    tts_reflectionflow.py:145,160,328-332): every rank contributes a [len(sel), ...] buffer holding the selected latents it
+    owns (zeros elsewhere); slot j of the result is read from its owner's block.  len(sel) x 512 KiB per rank at 1024^2.
+    `like`: a tensor with a latent's shape/dtype (for ranks that own none).  Returns the list of latents in `sel` order."""
+    if shard.world_size == 1:
+        return [local[i] for i in sel]
+    dev = _collective_device(device)
+    k = len(sel)
+    mine = torch.zeros((k,) + tuple(like.shape), dtype=like.dtype, device=dev)
+    for j, i in enumerate(sel):
+        if i in local:
+            mine[j] = local[i].to(dev)
+    out = torch.empty((shard.world_size * k,) + tuple(like.shape), dtype=like.dtype, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    out = out.view((shard.world_size, k) + tuple(like.shape))
+    return [out[shard.owner(i), j].to(like.device) for j, i in enumerate(sel)]
 
 
 def nvila_sort_key(score: float, label: int, index: int):
@@ -89,23 +132,43 @@ def stub_verifier(latents: torch.Tensor, seed: int) -> Tuple[float, int]:
     """Deterministic stand-in for NVILA-Lite-2B / GPT-4o (remote-code VLM / HTTPS API, unavailable
     offline and outside the hot path): a score derived from the candidate's seed and latent
     statistics.  Only its OUTPUT CONTRACT (float score, yes/no label) matters for the exchange."""
-    h = (seed * 2654435761) & 0xFFFFFFFF
-    base = (h % 10007) / 10007.0
-    stat = float(latents.float().abs().mean().item())
-    score = 0.5 * base + 0.5 * (stat % 1.0)
-    return score, int(score >= 0.5)
+    sc, lab = stub_score_batch(latents[None] if latents.dim() == 2 else latents, [seed])
+    return float(sc[0]), int(lab[0])
+
+
+def stub_score_batch(latents: torch.Tensor, seeds: Sequence[int]):
+    """Batched verifier contract `score_batch(latents [n, S, 64], seeds) -> (scores f32 [n], labels i32 [n])` ON THE
+    LATENTS' DEVICE: what a real on-device verifier (NVILA yes/no logit, tts/verifiers/nvila_verifier.py:4-10;
+    tts_reflectionflow.py:157-170) plugs into -- one call per round and rank, no per-candidate host round trip; the round's
+    only host sync is the all-gather's.  The stub's score = f(seed, latent statistic), deterministic."""
+    lat = latents.reshape(latents.shape[0], -1) if latents.dim() > 2 else latents
+    base = torch.tensor([(((int(sd) * 2654435761) & 0xFFFFFFFF) % 10007) / 10007.0 for sd in seeds], dtype=torch.float32,
+                        device=lat.device)
+    stat = lat.float().abs().mean(dim=1)
+    scores = 0.5 * base + 0.5 * torch.remainder(stat, 1.0)
+    return scores, (scores >= 0.5).to(torch.int32)
 
 
 def run_round(shard: Shard, seeds: Sequence[int], generate_fn: Callable[[int, int], torch.Tensor],
-              verifier: Callable[[torch.Tensor, int], Tuple[float, int]] = stub_verifier, topk: int = 1):
-    """One search round: this rank generates its candidates, scores them, all ranks exchange the
-    scores and agree on the top-k.  Returns (selected candidate indices, all scores, local latents)."""
+              verifier: Optional[Callable[[torch.Tensor, int], Tuple[float, int]]] = None, topk: int = 1,
+              score_batch: Optional[Callable] = None):
+    """One search round: this rank generates its candidates, scores them (ONE batched verifier call: `score_batch`, default
+    the stub; a per-candidate `verifier(latents, seed) -> (score, label)` is wrapped), all ranks exchange the {f32, i32}
+    records with one all-gather and agree on the top-k.  Returns (selected candidate indices, all scores, local latents)."""
     n = len(seeds)
+    mine = shard.mine(n)
     local_lat: Dict[int, torch.Tensor] = {}
-    local_scores: Dict[int, Tuple[float, int]] = {}
-    for i in shard.mine(n):
-        lat = generate_fn(i, int(seeds[i]))
-        local_lat[i] = lat
-        local_scores[i] = verifier(lat, int(seeds[i]))
-    scores = allgather_scores(shard, n, local_scores)
+    for i in mine:
+        local_lat[i] = generate_fn(i, int(seeds[i]))
+    if verifier is not None and score_batch is None:
+        res = [verifier(local_lat[i], int(seeds[i])) for i in mine]
+        sc = torch.tensor([r[0] for r in res], dtype=torch.float32)
+        lab = torch.tensor([r[1] for r in res], dtype=torch.int32)
+    elif mine:
+        fn = score_batch or stub_score_batch
+        sc, lab = fn(torch.stack([local_lat[i].reshape(-1, local_lat[i].shape[-1]) for i in mine]), [int(seeds[i]) for i in mine])
+    else:
+        sc, lab = torch.empty(0, dtype=torch.float32), torch.empty(0, dtype=torch.int32)
+    s_all, l_all = allgather_score_tensors(shard, n, sc, lab)
+    scores = [(float(a), int(b)) for a, b in zip(s_all.tolist(), l_all.tolist())]
     return select_topk(scores, topk), scores, local_lat

@@ -40,11 +40,13 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
     from reflectionflow_amd import _lib
-    structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_lora_seg", "rf_double_block_weights",
-               "rf_single_block_weights", "rf_flux_dims", "rf_workspace", "rf_flux_model"]
+    structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_attn_desc", "rf_lora_seg", "rf_double_block_weights",
+               "rf_single_block_weights", "rf_flux_dims", "rf_workspace", "rf_flux_model"] + \
+        [n for n in ("rf_vae_conv", "rf_vae_norm", "rf_vae_resnet", "rf_vae_attn", "rf_vae_weights") if hasattr(_lib, n)]
     src = '#include "rf_flux.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){\n' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));\n' for s in structs) + \
-        'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\nreturn 0;}\n'
+        'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\n' \
+        'printf("off_sched %zu\\n", offsetof(rf_gemm_desc, schedule));\nprintf("off_kernel %zu\\n", offsetof(rf_attn_desc, kernel));\nreturn 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -55,6 +57,23 @@ def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
         assert int(out[s]) == C.sizeof(getattr(_lib, s)), f"sizeof({s}): C {out[s]} vs ctypes {C.sizeof(getattr(_lib, s))}"
     assert int(out["off_g"]) == _lib.rf_gemm_desc.g.offset
     assert int(out["off_out"]) == _lib.rf_gemm_group.out.offset
+    assert int(out["off_sched"]) == _lib.rf_gemm_desc.schedule.offset
+    assert int(out["off_kernel"]) == _lib.rf_attn_desc.kernel.offset
+
+
+def test_no_kernel_selecting_switch_is_exported(lib):
+    """VERDICT r2 item 6: the shipped library exports read-only introspection only -- no process-global rf_debug_* setter;
+    a launch's schedule / kernel travels in ITS descriptor and is validated."""
+    from reflectionflow_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    dbg = sorted(set(re.findall(r"\b(rf_debug_[a-z0-9_]+)", out)))
+    assert dbg == ["rf_debug_clock_probe", "rf_debug_last_attn_path", "rf_debug_last_gemm_path", "rf_debug_sk_plan"], dbg
+    d = _lib.rf_gemm_desc()
+    d.N, d.num_groups, d.schedule = 64, 1, 17
+    assert lib.rf_gemm_bf16(C.byref(d), None) == -1 and b"schedule=17" in lib.rf_last_error()
+    a = _lib.rf_attn_desc()
+    assert lib.rf_attention(C.byref(a), None) == -3                      # NULL operands
+    assert lib.rf_attention(None, None) == -3
 
 
 def test_argument_validation_is_loud(lib):

@@ -10,6 +10,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.pins import pins
+
 pytestmark = pytest.mark.gpu
 
 BF = torch.bfloat16
@@ -53,7 +55,7 @@ def assert_close(got, ref, what, rtol=1.2e-2, atol=None):
                                    (1024, 1536, 1024), (130, 100, 64), (513, 3076, 128)])
 def test_gemm_store(dev, tile, M, N, K):
     from reflectionflow_amd import _lib, ops
-    _lib.load().rf_debug_force_gemm_tile(tile)
+    pins.tile(tile)
     try:
         x, W, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.05), rnd(N, dev=dev)
         y = ops.linear(x, W, b)
@@ -62,7 +64,7 @@ def test_gemm_store(dev, tile, M, N, K):
         y2 = ops.linear(x, W, None)
         assert_close(y2, x.float() @ W.float().t(), "gemm no-bias")
     finally:
-        _lib.load().rf_debug_force_gemm_tile(0)
+        pins.reset()
 
 
 def test_gemm_transpose_detecting(dev):
@@ -79,7 +81,7 @@ def test_gemm_transpose_detecting(dev):
 def test_gemm_epilogues_and_segments(dev, tile):
     from reflectionflow_amd import _lib, ops
     from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, Group, Seg
-    _lib.load().rf_debug_force_gemm_tile(tile)
+    pins.tile(tile)
     try:
         M, N, K = 520, 384, 256
         x, W, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.05), rnd(N, dev=dev)
@@ -121,7 +123,7 @@ def test_gemm_epilogues_and_segments(dev, tile):
                 ref = ref + tl.float() @ Bl.float().t()
             assert_close(outs[i], ref, f"group {i}")
     finally:
-        _lib.load().rf_debug_force_gemm_tile(0)
+        pins.reset()
 
 
 def vt_unpermute(vt, S):
@@ -138,7 +140,7 @@ def vt_unpermute(vt, S):
 def test_gemm_qkv_epilogues(dev, tile, St, Si, Sc):
     from reflectionflow_amd import _lib, ops
     from reflectionflow_amd.ops import RF_EPI_QKV, RF_EPI_QKV_GELU, Group, Seg
-    _lib.load().rf_debug_force_gemm_tile(tile)
+    pins.tile(tile)
     try:
         H, D, MLP = 2, 256, 512
         S = St + Si + Sc
@@ -175,7 +177,7 @@ def test_gemm_qkv_epilogues(dev, tile, St, Si, Sc):
         assert_close(vt_unpermute(vt2, S), rv, "fused v^T")
         assert_close(hid, F.gelu(ref[:, 3 * D:], approximate="tanh"), "fused mlp gelu")
     finally:
-        _lib.load().rf_debug_force_gemm_tile(0)
+        pins.reset()
 
 
 # ------------------------------------------------------------------------------------- row kernels
@@ -256,10 +258,10 @@ def sdpa_ref(qf, kf, vf, mask=None):
 
 @pytest.fixture(params=[0, 1], ids=["attn_v1", "attn_v2"])
 def attn_impl(request, dev):
-    from reflectionflow_amd import _lib
-    _lib.load().rf_debug_attn_v2(request.param)
-    yield request.param
-    _lib.load().rf_debug_attn_v2(-1)
+    """Pin the online-softmax kernel of the attention launches of a test (rf_attn_desc.kernel)."""
+    from reflectionflow_amd import _lib, ops
+    with ops.attn_kernel(_lib.RF_ATTN_ONLINE256 if request.param else _lib.RF_ATTN_ONLINE128):
+        yield request.param
 
 
 @pytest.mark.parametrize("S", [64, 100, 128, 333, 768, 1500])
@@ -319,7 +321,7 @@ def test_gemm_qkv_fused_norm_rope(dev, tile, St, Si, Sc):
     from oracle import flux_oracle as O
     from reflectionflow_amd import _lib, ops
     from reflectionflow_amd.ops import RF_EPI_QKV, Group, Seg
-    _lib.load().rf_debug_force_gemm_tile(tile)
+    pins.tile(tile)
     try:
         H, D = 2, 256
         S = St + Si + Sc
@@ -354,7 +356,7 @@ def test_gemm_qkv_fused_norm_rope(dev, tile, St, Si, Sc):
         assert_close(k[:, :S], nr(ref[:, D:2 * D], nw[1], nw[3]), "fused k")
         assert_close(vt_unpermute(vt, S), ref[:, 2 * D:].reshape(S, H, 128).permute(1, 0, 2), "v^T (untouched by rope)")
     finally:
-        _lib.load().rf_debug_force_gemm_tile(0)
+        pins.reset()
 
 
 def test_attention_prescaled_q_matches_scaled_path(dev, attn_impl):
@@ -405,11 +407,10 @@ def test_gemm_splitk_lora_down(dev, M, N, K, K2, ws_mib):
 def force_sk(dev):
     from reflectionflow_amd import _lib
     lib = _lib.load()
-    lib.rf_debug_force_gemm_tile(256)
-    lib.rf_debug_force_gemm_sk(1)
-    yield lib
-    lib.rf_debug_force_gemm_sk(-1)
-    lib.rf_debug_force_gemm_tile(0)
+    pins.tile(256)
+    pins.sk(1)
+    yield pins
+    pins.reset()
 
 
 @pytest.mark.parametrize("rows,N,K,K2", [((4608,), 3072, 3072, 0),            # cfg2 out-proj: 216 tiles on 256 CUs
@@ -441,9 +442,9 @@ def test_gemm_stream_k_gate_res(dev, force_sk, rows, N, K, K2):
             outs.append(out)
         got = []
         for mode in (1, 1, 0):
-            lib.rf_debug_force_gemm_sk(mode)
+            pins.sk(mode)
             ops.gemm(groups, N, ops.RF_EPI_GATE_RES)
-            assert lib.rf_debug_last_gemm_path() == (2 if mode else 0), "stream-K path was not (de)selected"
+            assert pins.last_path() == (2 if mode else 0), "stream-K path was not (de)selected"
             got.append([o.clone() for o in outs])
         for gi in range(len(rows)):
             assert_close(got[0][gi], refs[gi], f"stream-K group {gi} vs fp32")
@@ -461,7 +462,7 @@ def test_gemm_stream_k_qkv_fused(dev, force_sk):
     cos, sin = torch.rand(S, 128, device=dev), torch.rand(S, 128, device=dev)
     res = []
     for mode in (1, 0):
-        lib.rf_debug_force_gemm_sk(mode)
+        pins.sk(mode)
         q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
         groups = []
         for gi, (M, off) in enumerate([(St, 0), (Si, St), (Sc, St + Si)]):
@@ -469,7 +470,7 @@ def test_gemm_stream_k_qkv_fused(dev, force_sk):
             nq, nk_ = rnd(128, dev=dev, seed=30 + gi) + 1.0, rnd(128, dev=dev, seed=40 + gi) + 1.0
             groups.append(ops.Group([ops.Seg(x, W)], bias=b, tok_offset=off, norm_q=nq, norm_k=nk_))
         ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin), q_scale=ops.QK_PRESCALE)
-        assert lib.rf_debug_last_gemm_path() == (2 if mode else 0)
+        assert pins.last_path() == (2 if mode else 0)
         res.append((q.clone(), k.clone(), vt.clone()))
     for a, b, name in zip(res[0], res[1], "q k vt".split()):
         assert_close(a, b.float(), f"stream-K {name}", rtol=8e-3)
@@ -494,13 +495,13 @@ def test_gemm_k_segment_boundaries(dev, tile, Ks):
     ref = F.gelu(ref + b.float(), approximate="tanh")
     outs = {}
     for t in (tile, 256 + 257 - tile):
-        lib.rf_debug_force_gemm_tile(t)
+        pins.tile(t)
         try:
             y = torch.empty(M, N, dtype=BF, device=dev)
             ops.gemm([ops.Group(segs, bias=b, out=y)], N, ops.RF_EPI_GELU, splitk_ws=False)
             outs[t] = y
         finally:
-            lib.rf_debug_force_gemm_tile(0)
+            pins.tile(0)
     assert_close(outs[tile], ref, f"K segments {Ks}, tile {tile}")
     assert torch.equal(outs[256], outs[257]), "ping-pong and plain loops disagree"
 
@@ -518,7 +519,7 @@ def test_gemm_stream_k_graph_replay(dev, force_sk):
     with torch.cuda.stream(side):
         x.copy_(rnd(M, K, dev=dev, seed=1))
         ops.gemm([ops.Group([ops.Seg(x, W)], out=outs[0])], N)   # allocates this stream's scratch outside the capture
-        assert lib.rf_debug_last_gemm_path() == 2
+        assert pins.last_path() == 2
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=side):
@@ -550,7 +551,7 @@ def test_gemm_pingpong_cold_cache_stress(dev):
             b, gate, res = rnd(N, dev=dev, seed=it), rnd(N, dev=dev, seed=it + 50), rnd(M, N, dev=dev, seed=it + 70)
             outs = []
             for tile in (256, 257, 256):
-                lib.rf_debug_force_gemm_tile(tile)
+                pins.tile(tile)
                 flush.fill_(float(it))
                 y = torch.empty(M, N, dtype=BF, device=dev)
                 ops.gemm([ops.Group([ops.Seg(x, W)], bias=b, out=y, residual=res, gate=gate)], N, ops.RF_EPI_GATE_RES, splitk_ws=False)
@@ -558,14 +559,14 @@ def test_gemm_pingpong_cold_cache_stress(dev):
             assert torch.equal(outs[0], outs[1]), f"round {it}: ping-pong loop differs from the plain loop on cold operands"
             assert torch.equal(outs[0], outs[2]), f"round {it}: ping-pong loop is not reproducible on cold operands"
     finally:
-        lib.rf_debug_force_gemm_tile(0)
+        pins.tile(0)
         del flush
         torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("rows,N,K", [((512, 4096), 9216, 3072), ((4608,), 3072, 3072), ((300, 5000, 77), 1536, 256)])
 def test_gemm_persistent_whole_tiles_equals_tile_per_block(dev, rows, N, K):
-    """rf_debug_force_gemm_sk(2): the persistent launch that walks whole 256x256 tiles (no stream-K region) computes
+    """RF_SCHED_PERSISTENT: the persistent launch that walks whole 256x256 tiles (no stream-K region) computes
     every tile with the same loop and epilogue as the one-tile-per-block launch -> bit-identical outputs, also with
     several token groups and a partial last round."""
     from reflectionflow_amd import _lib, ops
@@ -577,117 +578,16 @@ def test_gemm_persistent_whole_tiles_equals_tile_per_block(dev, rows, N, K):
     res = [rnd(m, N, dev=dev, seed=70 + i) for i, m in enumerate(rows)]
     outs = {}
     for mode in (0, 2):
-        lib.rf_debug_force_gemm_sk(mode)
-        lib.rf_debug_force_gemm_tile(256)
+        pins.sk(mode)
+        pins.tile(256)
         try:
             o = [r_.clone() for r_ in res]
             ops.gemm([Group([Seg(xs[i], Ws[i])], bias=b, out=o[i], residual=o[i], gate=gate) for i in range(len(rows))], N, RF_EPI_GATE_RES)
-            assert lib.rf_debug_last_gemm_path() == mode
+            assert pins.last_path() == mode
             outs[mode] = o
         finally:
-            lib.rf_debug_force_gemm_sk(-1)
-            lib.rf_debug_force_gemm_tile(0)
+            pins.sk(-1)
+            pins.tile(0)
     for i in range(len(rows)):
         assert torch.equal(outs[0][i], outs[2][i]), f"group {i}: persistent != tile-per-block"
         assert_close(outs[2][i], res[i].float() + gate.float() * (xs[i].float() @ Ws[i].float().t() + b.float()), f"persistent group {i}")
-
-
-@pytest.mark.parametrize("rows,N,K", [((512, 4096), 3072, 3072), ((300, 5000, 77), 1536, 320), ((4608,), 3072, 64)])
-def test_gemm_mfma_shapes_and_experimental_loops_agree(dev, rows, N, K):
-    """The shipped 256x256 kernel multiplies with v_mfma_f32_16x16x32_bf16 in evenly loaded phases; rf_debug_gemm_even(0)
-    selects the 8/4/8/4 phases (which the fp8 and stream-K kernels still use), rf_debug_gemm_mi16(0) the 32x32x16 loop.  Both walk the K-tiles in the same order with fp32 accumulation per output element, so the results
-    are bit-identical -- as are the experimental main loops kept in the library (rf_debug_force_gemm_tile 258: one wave
-    per SIMD over an LDS ring; 259 + variant 5 / 6: the balanced and the evenly loaded ping-pong phases on 32x32x16),
-    with grouped rows, a ragged last tile in M and N, 1 / 5 / 48 K-tiles and the gate-residual epilogue."""
-    from reflectionflow_amd import _lib, ops
-    from reflectionflow_amd.ops import RF_EPI_GATE_RES, Group, Seg
-    lib = _lib.load()
-    xs = [rnd(m, K, dev=dev, seed=150 + i) for i, m in enumerate(rows)]
-    Ws = [rnd(N, K, dev=dev, scale=0.05, seed=160 + i) for i in range(len(rows))]
-    b, gate = rnd(N, dev=dev), rnd(N, dev=dev)
-    res = [rnd(m, N, dev=dev, seed=170 + i) for i, m in enumerate(rows)]
-    outs = {}
-    try:
-        for name, tile, var, mi16, even in (("16x16x32", 256, 0, 1, 1), ("16x16x32 8/4/8/4 phases", 256, 0, 1, 0), ("32x32x16", 256, 0, 0, 1),
-                                            ("one wave per SIMD", 258, 0, 1, 1), ("balanced 32x32", 259, 5, 1, 1), ("even 32x32", 259, 6, 1, 1),
-                                            ("16x16 harness, 8/4/8/4", 259, 7, 1, 1), ("16x16 harness, even", 259, 11, 1, 1)):
-            lib.rf_debug_force_gemm_sk(0)
-            lib.rf_debug_force_gemm_tile(tile)
-            lib.rf_debug_gemm_w4_knock(var)
-            lib.rf_debug_gemm_mi16(mi16)
-            lib.rf_debug_gemm_even(even)
-            o = [r_.clone() for r_ in res]
-            ops.gemm([Group([Seg(xs[i], Ws[i])], bias=b, out=o[i], residual=o[i], gate=gate) for i in range(len(rows))], N,
-                     RF_EPI_GATE_RES, splitk_ws=False)
-            outs[name] = o
-    finally:
-        lib.rf_debug_force_gemm_sk(-1)
-        lib.rf_debug_force_gemm_tile(0)
-        lib.rf_debug_gemm_w4_knock(0)
-        lib.rf_debug_gemm_mi16(1)
-        lib.rf_debug_gemm_even(1)
-    for i in range(len(rows)):
-        assert_close(outs["16x16x32"][i], res[i].float() + gate.float() * (xs[i].float() @ Ws[i].float().t() + b.float()), f"group {i}")
-        for name in outs:
-            assert torch.equal(outs[name][i], outs["16x16x32"][i]), f"group {i}: '{name}' differs from the shipped kernel"
-
-
-def test_gemm_stream_k_on_both_mfma_shapes(dev):
-    """Stream-K (partial accumulators travel through scratch quad by quad) on the 16x16x32 kernel and on the 32x32x16 one
-    (S = 5632-like rows, 264 tiles): for a given schedule the two MFMA shapes agree bit for bit; stream-K splits the K sum
-    of a tile between workers, so against one tile per block it is compared with the usual tolerance."""
-    from reflectionflow_amd import _lib, ops
-    from reflectionflow_amd.ops import Group, Seg
-    lib = _lib.load()
-    rows, N, K = (512, 4096, 1024), 3072, 3072
-    xs = [rnd(m, K, dev=dev, seed=250 + i) for i, m in enumerate(rows)]
-    Ws = [rnd(N, K, dev=dev, scale=0.05, seed=260 + i) for i in range(len(rows))]
-    outs = {}
-    try:
-        for mi16 in (1, 0):
-            for sk in (0, 1):
-                lib.rf_debug_gemm_mi16(mi16)
-                lib.rf_debug_force_gemm_sk(sk)
-                o = [torch.empty(m, N, dtype=BF, device=dev) for m in rows]
-                ops.gemm([Group([Seg(xs[i], Ws[i])], out=o[i]) for i in range(len(rows))], N)
-                assert lib.rf_debug_last_gemm_path() == (2 if sk else 0)
-                outs[(mi16, sk)] = o
-    finally:
-        lib.rf_debug_force_gemm_sk(-1)
-        lib.rf_debug_gemm_mi16(1)
-    for i in range(len(rows)):
-        for sk in (0, 1):
-            assert torch.equal(outs[(0, sk)][i], outs[(1, sk)][i]), f"group {i}, stream-K={sk}: the MFMA shapes disagree"
-        assert_close(outs[(1, 1)][i], xs[i].float() @ Ws[i].float().t(), f"stream-K group {i}")
-        assert_close(outs[(1, 1)][i], outs[(1, 0)][i].float(), f"stream-K vs tile-per-block, group {i}")   # (a bf16 ulp apart at most)
-
-
-@pytest.mark.parametrize("M,N,K,K2", [(1024, 64, 3072, 0), (1024, 64, 3072, 12288), (1000, 32, 2048, 0), (517, 128, 1024, 512),
-                                      (16384, 64, 3072, 0), (5, 16, 64, 0)])
-def test_gemm_skinny_lora_down(dev, M, N, K, K2):
-    """x . lora_A^T as the engine issues it (no bias, plain store, N = r_pad <= 128, one or two activation segments, output
-    rows 256 wide): the experimental skinny-N kernel [path 3, off by default: slower] vs fp32 and vs the split-K route
-    [path 1 or 0], bit-stable, and nothing written outside its N columns or M rows."""
-    from reflectionflow_amd import _lib, ops
-    lib = _lib.load()
-    x, A = rnd(M, K, dev=dev), rnd(N, K + K2, dev=dev, scale=0.05)
-    segs = [ops.Seg(x, A[:, :K])]
-    ref = x.float() @ A[:, :K].float().t()
-    if K2:
-        x2 = rnd(M, K2, dev=dev, seed=7)
-        segs.append(ops.Seg(x2, A[:, K:]))
-        ref = ref + x2.float() @ A[:, K:].float().t()
-    outs = []
-    try:
-        for skinny in (1, 1, 0):
-            lib.rf_debug_gemm_skinny(skinny)
-            y = torch.full((M + 3, 256), 7.0, dtype=BF, device=dev)
-            ops.gemm([ops.Group(segs, out=y[:M, :N])], N, ops.RF_EPI_STORE)
-            assert (lib.rf_debug_last_gemm_path() == 3) == bool(skinny)
-            outs.append(y)
-    finally:
-        lib.rf_debug_gemm_skinny(0)
-    assert_close(outs[0][:M, :N], ref, "skinny vs fp32")
-    assert torch.equal(outs[0], outs[1]), "the skinny kernel is not deterministic"
-    assert (outs[0][:, N:] == 7.0).all() and (outs[0][M:] == 7.0).all(), "wrote outside its block"
-    assert_close(outs[0][:M, :N], outs[2][:M, :N].float(), "skinny vs tiled route")

@@ -114,8 +114,7 @@ def test_attention_at_baseline_sequence_lengths(dev, impl, S, n_main, mode):
     import math
     from reflectionflow_amd import _lib, ops
     H = 8 if S < 10000 else 2
-    _lib.load().rf_debug_attn_v2(impl)
-    try:
+    with ops.attn_kernel(_lib.RF_ATTN_ONLINE256 if impl else _lib.RF_ATTN_ONLINE128):
         q, k, vt, qf, kf, vf = make_qkv(H, S, dev, seed=S + mode)
         bias = math.log(1.5)
         o = ops.attention(q, k, vt, S, n_main=n_main, mode=mode, cross_bias=bias)
@@ -128,8 +127,6 @@ def test_attention_at_baseline_sequence_lengths(dev, impl, S, n_main, mode):
             mask[:-n, -n:] = bias
         assert_close(o, sdpa_ref(qf, kf, vf, mask), f"attention S={S} mode{mode}", atol=2e-3)
         assert torch.equal(o, o2), "attention is not bit-stable run to run"
-    finally:
-        _lib.load().rf_debug_attn_v2(-1)
 
 
 @torch.no_grad()
@@ -194,15 +191,11 @@ def test_attention_bounded_score_kernel(dev, S, H):
     q, k, vt, ref, bound = _prescaled_case(H, S, dev, seed=S)
     assert bound < 100
     lib = _lib.load()
-    lib.rf_debug_attn_v2(1)
-    try:
-        o4 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
-        o4b = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
-        lib.rf_debug_attn_v4(0)
-        o2 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
-    finally:
-        lib.rf_debug_attn_v4(1)
-        lib.rf_debug_attn_v2(-1)
+    o4 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
+    assert lib.rf_debug_last_attn_path() == (5 if S < 8192 else 4), "AUTO with a proven bound must take the bounded kernel"
+    o4b = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
+    o2 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, kernel=_lib.RF_ATTN_ONLINE256)
+    assert lib.rf_debug_last_attn_path() == 2
     assert_close(o4, ref, f"attention v4 S={S}", atol=2e-3)
     assert torch.equal(o4, o4b), "v4 is not bit-stable run to run"
     e4, e2 = rel_l2(o4, ref), rel_l2(o2, ref)
@@ -214,24 +207,20 @@ def test_attention_bounded_score_kernel(dev, S, H):
 def test_attention_split_launch_and_mfma_shapes(dev, S, H):
     """The bounded-score kernel three ways on the same operands: 16x16x32 MFMAs one workgroup per (head, query block)
     [path 5], the same as ONE persistent workgroup per CU over equal shares of the (block, key range) space with partial
-    (O, l) added by a second launch [path 6: rf_attention_fwd_ws + scratch, forced], the 32x32x16 form [path 4] and the
-    experimental one-wave-per-SIMD form [path 7] -- all against fp32 SDPA, and the split launch bit-stable run to run."""
+    (O, l, m) added by a second launch [path 6: scratch attached, kernel pinned], and the 32x32x16 form [path 4] -- all
+    against fp32 SDPA, and the split launch bit-stable run to run.  A split request without scratch must FAIL, not fall back."""
     from reflectionflow_amd import _lib, ops
     q, k, vt, ref, bound = _prescaled_case(H, S, dev, seed=S + H)
     lib = _lib.load()
     outs = {}
-    try:
-        for name, v5, sk, v6, path in (("plain", 1, 0, 0, 5), ("split", 1, 1, 0, 6), ("split again", 1, 1, 0, 6), ("32x32x16", 0, 0, 0, 4),
-                                       ("one wave per SIMD", 1, 0, 1, 7)):
-            lib.rf_debug_attn_v2(1); lib.rf_debug_attn_v5(v5); lib.rf_debug_attn_sk(sk); lib.rf_debug_attn_v6(v6)
-            outs[name] = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
-            assert lib.rf_debug_last_attn_path() == path, (name, lib.rf_debug_last_attn_path())
-        lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(1); lib.rf_debug_attn_v6(0)
-        ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
-        assert lib.rf_debug_last_attn_path() == 5, "without scratch the library must not split"
-    finally:
-        lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_v5(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0)
-    assert torch.equal(outs["one wave per SIMD"], outs["plain"]), "v6 walks the keys in v5's order: bit-identical"
+    for name, kern, path in (("plain", _lib.RF_ATTN_BOUNDED16, 5), ("split", _lib.RF_ATTN_BOUNDED16_SPLIT, 6),
+                             ("split again", _lib.RF_ATTN_BOUNDED16_SPLIT, 6), ("32x32x16", _lib.RF_ATTN_BOUNDED32, 4)):
+        outs[name] = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, kernel=kern)
+        assert lib.rf_debug_last_attn_path() == path, (name, lib.rf_debug_last_attn_path())
+    with pytest.raises(ops.RFError):
+        ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False, kernel=_lib.RF_ATTN_BOUNDED16_SPLIT)
+    with pytest.raises(ops.RFError):   # a bounded kernel without a usable bound is refused as well
+        ops.attention(q, k, vt, S, q_prescaled=True, score_bound=150.0, kernel=_lib.RF_ATTN_BOUNDED16)
     for name, o in outs.items():
         assert_close(o, ref, f"attention {name} S={S}", atol=2e-3)
     assert torch.equal(outs["split"], outs["split again"]), "the split launch is not bit-stable"
@@ -246,11 +235,7 @@ def test_attention_bounded_score_extremes(dev):
     q, k, vt, ref, bound = _prescaled_case(H, S, dev, seed=7, qscale=3.5)
     assert 30 < bound < 100, bound
     lib = _lib.load()
-    lib.rf_debug_attn_v2(1)
-    try:
-        o4 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
-    finally:
-        lib.rf_debug_attn_v2(-1)
+    o4 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, kernel=_lib.RF_ATTN_BOUNDED16)
     assert_close(o4, ref, "attention v4 peaked", atol=1.5e-2)
     # all-negative rows: q = -c * k_mean direction -> every score << 0, P tiny but the row still normalises
     q2, k2, vt2, qf, kf, vf = make_qkv(1, 256, dev, seed=9)
@@ -264,11 +249,7 @@ def test_attention_bounded_score_extremes(dev):
     ref2 = F.scaled_dot_product_attention((qp.float() * math.log(2.0))[None], kf2.float()[None], vf.float()[None], scale=1.0)
     ref2 = ref2[0].permute(1, 0, 2).reshape(256, -1)
     b2 = float(qp.float().norm(dim=-1).max() * kf2.float().norm(dim=-1).max()) * 1.01
-    lib.rf_debug_attn_v2(1)
-    try:
-        o = ops.attention(q2, k2, vt2, 256, q_prescaled=True, score_bound=b2)
-    finally:
-        lib.rf_debug_attn_v2(-1)
+    o = ops.attention(q2, k2, vt2, 256, q_prescaled=True, score_bound=b2, kernel=_lib.RF_ATTN_BOUNDED16)
     assert_close(o, ref2, "attention v4 all-negative rows", atol=4e-3)
 
 

@@ -257,14 +257,11 @@ def test_gemm_w8a8_stream_k_matches_tile_per_block(dev):
     W8, sw = ops.quantize_weight_fp8(W)
     outs = []
     for mode in (0, 1, 1):
-        lib.rf_debug_force_gemm_sk(mode)
-        try:
+        with ops.gemm_schedule(_lib.RF_SCHED_STREAMK if mode else _lib.RF_SCHED_TILE256):
             o = res.clone()
             ops.gemm_w8a8([Group([Seg(A8, W8)], bias=b, out=o, residual=o, gate=gate, a_scale=sa, w_scale=sw)], N, RF_EPI_GATE_RES)
             assert lib.rf_debug_last_gemm_path() == (2 if mode else 0)
             outs.append(o)
-        finally:
-            lib.rf_debug_force_gemm_sk(-1)
     assert_close(outs[0], res.float() + gate.float() * ref_w8(A8, sa, W8, sw, b), "w8 gate_res 264 tiles")
     assert torch.equal(outs[1], outs[2]), "stream-K fp8 launch is not bit-stable"
     assert rel_l2(outs[1], outs[0]) < 1e-3    # different fp32 summation order of split tiles only

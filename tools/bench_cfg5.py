@@ -9,6 +9,7 @@ Prints one JSON line: s/latent for T steps, TFLOP/s, fraction of the bf16 MFMA p
 (GEMM vs attention vs row kernels) from the library's in-sequence timing hook over 2 profiled forwards."""
 import argparse, json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 import bench
 from reflectionflow_amd import ops
 from reflectionflow_amd.flux.condition import Condition

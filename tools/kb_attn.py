@@ -3,6 +3,7 @@ MFMAs), v5 (the same on 16x16x32) at the BASELINE sequence lengths, realistic sc
 prescaled q), interleaved repetitions; shader clock from the kernels' own probe."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops
 from tools.kbench import timeit
 dev = torch.device("cuda:0"); lib = _lib.load()

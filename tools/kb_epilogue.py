@@ -1,6 +1,7 @@
 """Epilogue cost: time one-round GEMMs (216 tiles = 4608 x 3072 outputs) at K = 64..512 and extrapolate to K = 0."""
 import torch
 from reflectionflow_amd import _lib, ops
+_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 dev = torch.device("cuda:0"); lib = _lib.load(); BF = torch.bfloat16
 lib.rf_debug_force_gemm_sk(0)
 M, N = 4608, 3072

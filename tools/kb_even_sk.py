@@ -1,6 +1,7 @@
 """A/B of the evenly loaded phases inside the stream-K kernel (cfg4 / cfg5 shapes that take stream-K)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops
 lib = _lib.load(); dev = torch.device("cuda:0"); BF = torch.bfloat16
 G = ops.RF_EPI_GATE_RES

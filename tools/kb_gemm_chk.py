@@ -2,6 +2,7 @@
 fp32 matmul next to the production kernel: K-tile counts 1, 2, 3, 5, 48, 240, ragged M / N, two K-segments."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")

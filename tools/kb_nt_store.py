@@ -1,6 +1,7 @@
 """A/B: plain vs non-temporal output stores in the GEMM epilogue (rf_debug_gemm_nt_store) on the cfg2 launch shapes."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 import bench
 from reflectionflow_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")

@@ -3,6 +3,7 @@ vs ONE persistent launch walking whole tiles (rf_debug_force_gemm_sk(2)): a tile
 main loop and there is no block dispatch between rounds.  Interleaved repetitions in one process."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 import bench
 from reflectionflow_amd import _lib
 lib = _lib.load()

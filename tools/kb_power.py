@@ -2,6 +2,7 @@
 import json, subprocess, threading, time, sys
 import torch
 from reflectionflow_amd import _lib, ops
+_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 dev = torch.device("cuda:0"); lib = _lib.load(); BF = torch.bfloat16
 
 def sampler(stop, out):

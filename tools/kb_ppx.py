@@ -2,6 +2,7 @@
 0 production order, 1 reads before DMA, 2 no DMA (timing only), 3 no reads (timing only), 4 neither (timing only)."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")

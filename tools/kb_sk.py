@@ -3,6 +3,7 @@ sampling through rocm-smi while a long GEMM loop runs.  Usage: python tools/kb_s
 import json, subprocess, threading, time
 import torch
 from reflectionflow_amd import _lib, ops
+_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 
 dev = torch.device("cuda:0")
 lib = _lib.load()

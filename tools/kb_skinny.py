@@ -1,6 +1,7 @@
 """LoRA down-projection x . lora_A^T (N = r_pad = 64, M = condition rows): skinny-N kernel vs the split-K route."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops
 lib = _lib.load(); dev = torch.device("cuda:0"); BF = torch.bfloat16
 for (M, N, K, K2) in ((1024, 64, 3072, 0), (1024, 64, 12288, 0), (1024, 64, 3072, 12288), (4096, 64, 3072, 0), (16384, 64, 3072, 0)):

@@ -1,6 +1,7 @@
 """A/B of GEMM tile configurations through rf_debug_force_gemm_tile.  Usage: PYTHONPATH=. python tools/kb_tile.py 256 257"""
 import sys, torch
 from reflectionflow_amd import _lib, ops
+_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 dev = torch.device("cuda:0"); lib = _lib.load(); BF = torch.bfloat16
 tiles = [int(a) for a in sys.argv[1:]] or [256]
 lib.rf_debug_force_gemm_sk(0)

@@ -1,6 +1,7 @@
 """s_memtime timeline of the GEMM main loop (rf_debug_gemm_timeline): where do a wave's cycles go per K-tile?"""
 import ctypes as C, torch
 from reflectionflow_amd import _lib, ops
+_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 dev = torch.device("cuda:0"); lib = _lib.load(); BF = torch.bfloat16
 for name, M, N, K in [("8192^3", 8192, 8192, 8192), ("out 4608x3072x3072", 4608, 3072, 3072), ("sgl_in 4608x21504x3072", 4608, 21504, 3072)]:
     x = torch.randn(M, K, device=dev, dtype=BF); W = torch.randn(N, K, device=dev, dtype=BF) * 0.02

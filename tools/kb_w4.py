@@ -2,6 +2,7 @@
 (rf_debug_force_gemm_tile(258)) on the cfg2 launch shapes, plus a correctness check of the latter."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 import bench
 from reflectionflow_amd import _lib, ops
 lib = _lib.load()

@@ -2,6 +2,7 @@
 fragment reads, and the per-tile wait+barrier costs what on top of 64 MFMAs per K-tile."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops
 lib = _lib.load()
 dev = torch.device("cuda:0")

@@ -8,6 +8,7 @@ import os
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 from reflectionflow_amd import _lib, ops  # noqa: E402
 from reflectionflow_amd.ops import RF_EPI_GATE_RES, RF_EPI_GELU, RF_EPI_QKV_GELU, RF_EPI_STORE, Group, Seg  # noqa: E402
 
