@@ -485,6 +485,7 @@ def main():
     # score_batch contract a real on-device verifier plugs into), ONE all-gather of the 8-byte {f32 score, i32 label}
     # records (RCCL), the same top-k on every rank
     n_round = args.steps * shard.world_size
+    torch.cuda.synchronize()                             # (so that round_boundary_ms is the boundary's own cost, not the last denoise draining)
     t_rb = time.perf_counter()
     sc, lab = search.stub_score_batch(torch.stack([o.reshape(-1, o.shape[-1]) for o in outs]), seeds[args.warmup:])
     s_all, l_all = search.allgather_score_tensors(shard, n_round, sc, lab,
@@ -492,7 +493,7 @@ def main():
     scores = [(float(a), int(b)) for a, b in zip(s_all.tolist(), l_all.tolist())]
     best = search.select_topk(scores, 1)
     torch.cuda.synchronize()
-    round_boundary_s = time.perf_counter() - t_rb        # includes draining the last candidate's kernels on this rank
+    round_boundary_s = time.perf_counter() - t_rb
     barrier()
     dt = time.perf_counter() - t0
     if shard.world_size > 1:
