@@ -361,6 +361,49 @@ int rf_flux_denoise(const rf_flux_dims* dims, const rf_flux_model* m,
                     const float* dts, int32_t T, void* vel_scratch,
                     const rf_workspace* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * FLUX VAE (AutoencoderKL, 16 latent channels, 8x) -- SURVEY 8(f) row 1.  Replaces, either side of the denoise loop,
+ *   vae.decode(latents / scaling_factor + shift_factor)          generate.py:302-307, tts_reflectionflow.py:273-279
+ *   vae.encode(images).latent_dist (the moments mean | logvar)    pipeline_tools.py:7-14, condition.py:96-132
+ * (diffusers is not vendored by the reference: the arithmetic is diffusers' published Encoder / Decoder / ResnetBlock2D /
+ * Attention / Downsample2D / Upsample2D, GroupNorm(32, eps 1e-6), SiLU -- PARITY UNPINNED at this boundary, see DESIGN.md.)
+ * Every image crossing this interface is a ZERO-HALO NHWC bf16 image: (H+2) x (W+2) pixels of C channels, row-major, the
+ * one-pixel border zero; C is the layer's PADDED channel count (multiples of 64 on the input side, of 8 on the output side;
+ * the host wrapper pads latents 16 -> 64, RGB 3 -> 64 in / 3 -> 8 out and slices the interior of the result).
+ * 3x3 convolutions run on the library's grouped MFMA GEMM (three K-segments of 3*Cin contiguous taps), weights repacked once:
+ *   conv 3x3 : w bf16 [cout][3 (dy)][3 (dx)][cin], b bf16 [cout]          conv 1x1 / linear : w bf16 [cout][cin]
+ * ---------------------------------------------------------------------------------- */
+typedef struct rf_vae_conv { const void* w; const void* b; int32_t cin, cout; } rf_vae_conv;     /* w == NULL: layer absent */
+typedef struct rf_vae_norm { const void* gamma; const void* beta; } rf_vae_norm;                 /* GroupNorm affine, bf16 [C] */
+typedef struct rf_vae_resnet {                  /* ResnetBlock2D: x' = shortcut(x) + conv2(silu(norm2(conv1(silu(norm1(x)))))) */
+  rf_vae_norm norm1; rf_vae_conv conv1; rf_vae_norm norm2; rf_vae_conv conv2;
+  rf_vae_conv shortcut;                         /* 1x1 conv_shortcut when cin != cout, else w == NULL */
+} rf_vae_resnet;
+typedef struct rf_vae_attn {                    /* mid-block Attention: one head of C channels, residual */
+  rf_vae_norm norm;
+  const void* w_qk; const void* b_qk;           /* cat(to_q, to_k) [2C x C], [2C] */
+  const void* w_v;                              /* to_v.weight [C x C]; its bias is folded into b_out (softmax rows sum to 1) */
+  const void* w_out; const void* b_out;         /* to_out.0 [C x C]; b_out = to_out.0.bias + to_out.0.weight . to_v.bias */
+  int32_t C; int32_t _pad;
+} rf_vae_attn;
+typedef struct rf_vae_weights {                 /* ONE direction: the Decoder or the Encoder */
+  int32_t levels, res_per_level;                /* 4 x 3 (decoder: layers_per_block + 1) or 4 x 2 (encoder) */
+  int32_t groups, has_attn;                     /* GroupNorm groups (32); mid_block_add_attention */
+  rf_vae_conv conv_in;
+  rf_vae_resnet mid0, mid1; rf_vae_attn attn;   /* mid block: resnet, attention, resnet */
+  rf_vae_resnet res[4][3];                      /* [level][resnet] in execution order */
+  rf_vae_conv resample[4];                      /* after level i: decoder = upsampler conv (3x3 on the nearest-2x image),
+                                                   encoder = downsampler conv (3x3, stride 2, pad (0,1,0,1)); w NULL = none */
+  rf_vae_norm norm_out; rf_vae_conv conv_out;
+} rf_vae_weights;
+/* workspace (caller-owned, 256-byte aligned) for an input of h x w pixels (decode: latent size, encode: image size) */
+int64_t rf_vae_workspace_bytes(const rf_vae_weights* w, int32_t encode, int32_t h, int32_t w_in);
+/* z: zero-halo [(h+2)(w+2)][conv_in.cin]  ->  out: [(8h+2)(8w+2)][conv_out.cout]: only the INTERIOR of `out` is defined (its top /
+ * bottom halo rows are never written, its halo columns receive garbage); the caller slices channels 0..2 of the interior */
+int rf_vae_decode(const rf_vae_weights* w, const void* z, int32_t h, int32_t w_in, void* out, const rf_workspace* ws, void* stream);
+/* img: zero-halo [(H+2)(W+2)][conv_in.cin] -> out: [(H/8+2)(W/8+2)][conv_out.cout] = (mean | logvar) moments, interior valid */
+int rf_vae_encode(const rf_vae_weights* w, const void* img, int32_t H, int32_t W, void* out, const rf_workspace* ws, void* stream);
+
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
  * shape with hipEvents on `stream`; returns average microseconds in *us. */
 int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);

@@ -98,6 +98,31 @@ class rf_flux_model(C.Structure):
                 ("in_ch", C.c_int32), ("joint_dim", C.c_int32)]
 
 
+class rf_vae_conv(C.Structure):
+    _fields_ = [("w", _P), ("b", _P), ("cin", C.c_int32), ("cout", C.c_int32)]
+
+
+class rf_vae_norm(C.Structure):
+    _fields_ = [("gamma", _P), ("beta", _P)]
+
+
+class rf_vae_resnet(C.Structure):
+    _fields_ = [("norm1", rf_vae_norm), ("conv1", rf_vae_conv), ("norm2", rf_vae_norm), ("conv2", rf_vae_conv),
+                ("shortcut", rf_vae_conv)]
+
+
+class rf_vae_attn(C.Structure):
+    _fields_ = [("norm", rf_vae_norm), ("w_qk", _P), ("b_qk", _P), ("w_v", _P), ("w_out", _P), ("b_out", _P),
+                ("C", C.c_int32), ("_pad", C.c_int32)]
+
+
+class rf_vae_weights(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("res_per_level", C.c_int32), ("groups", C.c_int32), ("has_attn", C.c_int32),
+                ("conv_in", rf_vae_conv), ("mid0", rf_vae_resnet), ("mid1", rf_vae_resnet), ("attn", rf_vae_attn),
+                ("res", (rf_vae_resnet * 3) * 4), ("resample", rf_vae_conv * 4),
+                ("norm_out", rf_vae_norm), ("conv_out", rf_vae_conv)]
+
+
 # every symbol include/rf_flux.h declares: (restype, argtypes)
 _SIGS = {
     "rf_last_error": (C.c_char_p, []),
@@ -131,6 +156,9 @@ _SIGS = {
     "rf_flux_denoise": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_flux_model), _P, _P, _P, _P, C.c_int64, _P,
                                   _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.POINTER(rf_workspace), _P]),
     "rf_time_gemm": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
+    "rf_vae_workspace_bytes": (C.c_int64, [C.POINTER(rf_vae_weights), C.c_int32, C.c_int32, C.c_int32]),
+    "rf_vae_decode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
+    "rf_vae_encode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),
     "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int32)]),

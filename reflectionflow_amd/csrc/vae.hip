@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void im2col_s2_kernel(const bf16_t* __restrict
     if (xp >= 1 && xp <= Wo) {
       const int dy = c / (3 * C / 8), rem = c - dy * (3 * C / 8);       // rem: chunk inside the 3C run
       const int yi = 2 * (yp - 1) + dy + 1, xi = 2 * (xp - 1) + 1;     // padded input coordinates of tap (dy, 0)
-      o = *(const u32x4*)(x + ((int64_t)yi * Wip + xi) * C + rem * 8);
+      // the input is a residual stream: its halo is NOT clean (conv outputs leave garbage there) -- the pad (0,1,0,1) taps
+      // that fall on the bottom row / right column are zero by construction here, not by reading them
+      if (yi <= Hi && xi + (rem * 8) / C <= Wi) o = *(const u32x4*)(x + ((int64_t)yi * Wip + xi) * C + rem * 8);
     }
     *(u32x4*)(col + r * (int64_t)(9 * C) + c * 8) = o;
   }
@@ -634,11 +636,8 @@ extern "C" int rf_vae_encode(const rf_vae_weights* w, const void* img, int32_t H
         hipLaunchKernelGGL(im2col_s2_kernel, dim3(grid_for(M * (9 * Ci / 8))), dim3(256), 0, st, c.X, c.col, H, W, Ci);
         RF_LAUNCH_CHECK();
       }
-      // the output image's top / bottom halo rows must be zero for the next convolution: clear the buffer's first and last rows
-      RF_CHECK_HIP(hipMemsetAsync(c.T1, 0, (size_t)(Wo + 3) * Co * 2, st));
-      RF_CHECK_HIP(hipMemsetAsync(c.T1 + ((int64_t)(Ho + 1) * (Wo + 2) - 1) * Co, 0, (size_t)(Wo + 3) * Co * 2, st));
       RF_TRY(linear(c, c.col, 9 * Ci, cv.w, cv.b, (int)M, Co, 9 * Ci, c.T1 + (int64_t)(Wo + 3) * Co, Co));
-      // (halo-column rows of the GEMM were fed zeros: they hold the bias, not zero -- the next GroupNorm re-zeroes what a conv reads)
+      // (the result is a residual stream: nobody reads its halo -- GroupNorm / im2col skip it and write clean halos for what a conv reads)
       bf16_t* t = c.X; c.X = c.T1; c.T1 = t;
       H = Ho; W = Wo;
     }

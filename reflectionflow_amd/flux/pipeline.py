@@ -132,6 +132,18 @@ class FluxPipeline:
         E.invalidate(self.transformer)
         return self
 
+    def enable_hip_vae(self):
+        """Run `vae.decode` / `vae.encode` on the HIP path (librf_flux.so rf_vae_decode / rf_vae_encode)
+        instead of the PyTorch-ROCm / MIOpen modules: wraps the AutoencoderKL already on this pipeline (bf16, on the GPU).
+        `generate(output_type="pil")`, `Condition.encode` and the runner's decode -> resize -> encode hand-off then launch no
+        MIOpen kernel.  Idempotent."""
+        from .vae_hip import HipVAE
+        if self.vae is None:
+            raise ValueError("enable_hip_vae(): this pipeline has no VAE")
+        if not isinstance(self.vae, HipVAE):
+            self.vae = HipVAE(self.vae)
+        return self
+
     def set_progress_bar_config(self, **kw):
         self._progress = kw
 
