@@ -373,7 +373,15 @@ int rf_flux_denoise(const rf_flux_dims* dims, const rf_flux_model* m,
  * 3x3 convolutions run on the library's grouped MFMA GEMM (three K-segments of 3*Cin contiguous taps), weights repacked once:
  *   conv 3x3 : w bf16 [cout][3 (dy)][3 (dx)][cin], b bf16 [cout]          conv 1x1 / linear : w bf16 [cout][cin]
  * ---------------------------------------------------------------------------------- */
-typedef struct rf_vae_conv { const void* w; const void* b; int32_t cin, cout; } rf_vae_conv;     /* w == NULL: layer absent */
+typedef struct rf_vae_conv {                    /* w == NULL: layer absent */
+  const void* w; const void* b; int32_t cin, cout;
+  /* optional FOLDED copy for narrow outputs (cout < 256): `fold` = g adjacent output pixels share one GEMM row, so the launch
+   * is N = g*cout wide (a full 256-column MFMA tile instead of a half / 1/32 empty one) over K = 3 x (g+2)*cin:
+   *   wf bf16 [g*cout][3][(g+2)*cin],  wf[j*cout + o][dy][(j+dx)*cin + i] = w[o][dy][dx][i] (zero elsewhere),  bf = b tiled g times.
+   * The output memory is unchanged ([pixels][cout] row-major IS [pixels/g][g*cout]).  Used when the image is wide enough
+   * (g <= W + 3); wf == NULL: never. */
+  const void* wf; const void* bf; int32_t fold; int32_t _pad;
+} rf_vae_conv;
 typedef struct rf_vae_norm { const void* gamma; const void* beta; } rf_vae_norm;                 /* GroupNorm affine, bf16 [C] */
 typedef struct rf_vae_resnet {                  /* ResnetBlock2D: x' = shortcut(x) + conv2(silu(norm2(conv1(silu(norm1(x)))))) */
   rf_vae_norm norm1; rf_vae_conv conv1; rf_vae_norm norm2; rf_vae_conv conv2;

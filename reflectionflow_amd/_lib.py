@@ -99,7 +99,8 @@ class rf_flux_model(C.Structure):
 
 
 class rf_vae_conv(C.Structure):
-    _fields_ = [("w", _P), ("b", _P), ("cin", C.c_int32), ("cout", C.c_int32)]
+    _fields_ = [("w", _P), ("b", _P), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("wf", _P), ("bf", _P), ("fold", C.c_int32), ("_pad", C.c_int32)]
 
 
 class rf_vae_norm(C.Structure):

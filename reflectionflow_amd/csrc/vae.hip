@@ -37,18 +37,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = 0.f, s2[e] = 0.f;
-  for (int64_t p = p0 + pl; p < p1; p += PPI) {
+  auto inside = [&](const int64_t p) {
     const int yp = (int)(p / Wp), xp = (int)(p - (int64_t)yp * Wp);
-    if (yp >= 1 && yp <= H && xp >= 1 && xp <= W) {
-      float v[8];
-      unpack8(*(const u32x4*)(x + p * C + cs * 8), v);
+    return p < p1 && yp >= 1 && yp <= H && xp >= 1 && xp <= W;
+  };
+  auto acc = [&](const u32x4 raw) {
+    float v[8];
+    unpack8(raw, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[e] - sh[e];
-        s1[e] += d;
-        s2[e] += d * d;
-      }
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[e] - sh[e];
+      s1[e] += d;
+      s2[e] += d * d;
     }
+  };
+  for (int64_t p = p0 + pl; p < p1; p += 4 * PPI) {     // four independent 16-byte loads in flight per thread
+    u32x4 r[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      in[u] = inside(p + u * PPI);
+      if (in[u]) r[u] = *(const u32x4*)(x + (p + u * PPI) * C + cs * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (in[u]) acc(r[u]);
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -64,41 +77,57 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-// pass 2 (one block): block partials -> per-group mean / rstd (fp64) -> per-channel affine  y = x * a[c] + b[c]
-__global__ __launch_bounds__(512) void gn_finalize_kernel(const float* __restrict__ part, int nblk, const bf16_t* __restrict__ x_first,
+// pass 2 (one workgroup per GROUP): block partials -> the group's mean / rstd (fp64) -> per-channel affine y = x * a[c] + b[c].
+// 256 threads = cpg channel lanes x (256 / cpg) block lanes; fixed-order tree reductions (bit-reproducible).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nblk, const bf16_t* __restrict__ x_first,
                                                           int C, int groups, double count, float eps,
                                                           const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
                                                           float* __restrict__ ab /* [2][C] */) {
-  __shared__ double cs1[512], cs2[512], gm[64], gr[64];
-  const int cpg = C / groups;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double a = 0.0, b = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-      a += (double)part[((int64_t)i * C + c) * 2 + 0];
-      b += (double)part[((int64_t)i * C + c) * 2 + 1];
+  __shared__ double r1[256], r2[256];
+  const int cpg = C / groups;                  // 2, 4, 8 or 16
+  const int g = blockIdx.x;
+  const int tpc = 256 / cpg;                   // threads per channel
+  const int ci = threadIdx.x / tpc, bl = threadIdx.x % tpc;
+  const int c = g * cpg + ci;
+  double a = 0.0, b = 0.0;
+  for (int i = bl; i < nblk; i += tpc) {
+    const float* q = part + ((int64_t)i * C + c) * 2;
+    a += (double)q[0];
+    b += (double)q[1];
+  }
+  r1[threadIdx.x] = a;
+  r2[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = tpc >> 1; o >= 1; o >>= 1) {    // per-channel segments are power-of-two aligned
+    if (bl < o) {
+      r1[threadIdx.x] += r1[threadIdx.x + o];
+      r2[threadIdx.x] += r2[threadIdx.x + o];
     }
-    // un-shift: sum x = a + n s;  sum x^2 = b + 2 s a + n s^2
-    const double s = (double)bf2f(x_first[c]);
-    const double n = count / cpg;                       // interior pixels
-    cs1[c] = a + n * s;
-    cs2[c] = b + 2.0 * s * a + n * s * s;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-    double a = 0.0, b = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) a += cs1[c], b += cs2[c];
-    const double mean = a / count;
-    double var = b / count - mean * mean;
+  __shared__ double gs1, gs2;
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    const double n = count / cpg;              // interior pixels
+    for (int j = 0; j < cpg; ++j) {
+      // un-shift: sum x = a + n s;  sum x^2 = b + 2 s a + n s^2
+      const double sj = (double)bf2f(x_first[g * cpg + j]);
+      const double aj = r1[j * tpc], bj = r2[j * tpc];
+      t1 += aj + n * sj;
+      t2 += bj + 2.0 * sj * aj + n * sj * sj;
+    }
+    const double mean = t1 / count;
+    double var = t2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
-    gm[g] = mean;
-    gr[g] = 1.0 / sqrt(var + (double)eps);
+    gs1 = mean;
+    gs2 = 1.0 / sqrt(var + (double)eps);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const double ga = (double)bf2f(gamma[c]), be = (double)bf2f(beta[c]);
-    ab[c] = (float)(gr[g] * ga);
-    ab[C + c] = (float)(be - gm[g] * gr[g] * ga);
+  if (threadIdx.x < cpg) {
+    const int cc = g * cpg + threadIdx.x;
+    const double ga = (double)bf2f(gamma[cc]), be = (double)bf2f(beta[cc]);
+    ab[cc] = (float)(gs2 * ga);
+    ab[C + cc] = (float)(be - gs1 * gs2 * ga);
   }
 }
 
@@ -210,27 +239,34 @@ __global__ __launch_bounds__(256) void fill_bf16_kernel(bf16_t* __restrict__ p, 
 // ---- mid-block attention: ONE head, head_dim = C = 512, non-causal, S = H W tokens -----------------------------------------
 // qk: [S][2C] bf16 (q | k, bias included), vt: [C][S] bf16 (V^T WITHOUT its bias: softmax rows sum to 1, so the bias is added
 // after the product -- folded into the out-projection bias by the packer), out: [S][C].
-// Workgroup = 4 waves x 16 queries (one wave per SIMD: 128 O^T accumulator + 64 Q registers per lane); key tile = 32 keys:
-// K tile [32][C] (1 KB rows, 16-byte chunk c of row r stored at c ^ (r & 15): the 16-lane groups of ds_read_b128 hit 16
-// distinct slots) and V^T tile [C][32] (80-byte row pitch: conflict-free ds_read_b64 pairs), double buffered, staged through
-// registers (the next tile's global loads are issued before the current tile's MFMAs and written after them).
+// Workgroup = 64 queries, 8 waves (two per SIMD, 256 registers each): wave w serves the 16 queries of group w & 3 and the HALF
+// w >> 2 of the 512 output channels -- 64 O^T accumulator + 64 Q registers per lane, no accumulator-file spilling (a first build
+// with 4 waves x all 512 channels needed 128 + 64 + fragments > 256 registers: hipcc moved ~350 registers per key tile between
+// the VGPR and AGPR halves and ran 6500 clocks per tile for 1024 clocks of MFMA).  Both waves of a query group compute the same
+// scores (+50 % score MFMAs -- the price of keeping every wave inside 256 registers) and hence the same softmax.
+// Key tile = 32 keys: K tile [32][C] (1 KB rows, 16-byte chunk c of row r stored at c ^ (r & 15): the 16-lane groups of
+// ds_read_b128 hit 16 distinct slots) and V^T tile [C][32] (64-byte rows, chunk c of row d stored at c ^ ((d >> 2) & 3): the two
+// ds_read_b64 of a fragment hit 64 distinct banks per half-wave), double buffered, filled by LDS-DMA (buffer_load_dwordx4 ... lds:
+// the DMA writes lane-linearly, so both swizzles sit on the per-lane SOURCE offset).
 // Scores are computed transposed (S^T = K Q^T) so a lane owns one query: tile T (16 keys) leaves keys 4g..4g+3 of query l15
 // in lane group g; the PV product's B operand (P^T) of lane group g is {T0 keys 4g.., T1 keys 16 + 4g..} -- so its A operand
-// (V^T fragment) reads exactly those two 4-key runs of a row (2 x ds_read_b64).
+// (V^T fragment) reads exactly those two 4-key runs of a row (2 x ds_read_b64).  Fragment reads run one group of four ahead of
+// their MFMAs through a register double buffer fenced by sched_barrier(0) (left alone, hipcc sinks every ds_read to its use).
 constexpr int VA_C = 512;
 constexpr int VA_KT = 32;                       // keys per tile
 constexpr int VA_KBYTES = VA_KT * VA_C * 2;     // 32 KiB
-constexpr int VA_VPITCH = 80;
-constexpr int VA_VBYTES = VA_C * VA_VPITCH;     // 40 KiB
+constexpr int VA_VPITCH = 64;
+constexpr int VA_VBYTES = VA_C * VA_VPITCH;     // 32 KiB
 constexpr int VA_LDS = 2 * (VA_KBYTES + VA_VBYTES);
 
-__global__ __launch_bounds__(256) void vae_attn_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(512) void vae_attn_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                        int S, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qg = w & 3, hh = w >> 2;                     // query group, channel half
   const int l15 = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64 + w * 16;
+  const int q0 = blockIdx.x * 64 + qg * 16;
   const int64_t ldqk = 2 * VA_C;
 
   // Q B-operand fragments: query q0 + l15, d = 32 ds + 8 g .. +8
@@ -240,58 +276,70 @@ __global__ __launch_bounds__(256) void vae_attn_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int ds = 0; ds < 16; ++ds) qf[ds] = *(const bf16x8*)(qp + ds * 32);
   }
-  f32x4 oacc[32];
+  f32x4 oacc[16];                                        // O^T tiles of this wave's channel half: d = (hh*16 + dt)*16 + 4g + r
 #pragma unroll
-  for (int dt = 0; dt < 32; ++dt)
+  for (int dt = 0; dt < 16; ++dt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) oacc[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
 
-  // staging: 2048 + 2048 16-byte chunks per tile, 8 + 8 per thread
-  u32x4 kst[8], vst[8];
-  auto load_tile = [&](const int t) {
-    const int key0 = t * VA_KT;
+  // LDS-DMA pieces of a tile, 4 + 4 per wave: K piece i = key row 8 i + w (1 KB: lane = physical chunk, fetches logical chunk
+  // lane ^ (row & 15)); V^T piece i = rows 16 (8 i + w) .. + 15 (lane = (row, physical chunk): fetches logical chunk pc ^ ((row >> 2) & 3))
+  const rsrc_t rsK = RF_MAKE_RSRC(qk + VA_C), rsV = RF_MAKE_RSRC(vt);
+  uint32_t k_src[4], v_src[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * 256 + tid;                 // K: row = c / 64 (key), chunk = c % 64
-      const int row = c >> 6, ch = c & 63;
-      kst[i] = *(const u32x4*)(qk + (int64_t)(key0 + row) * ldqk + VA_C + ch * 8);
-      const int d = c >> 2, part = c & 3;          // V^T: row d, 8 keys per chunk
-      vst[i] = *(const u32x4*)(vt + (int64_t)d * S + key0 + part * 8);
-    }
-  };
-  auto store_tile = [&](const int buf) {
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * i + w;
+    k_src[i] = (uint32_t)(row * (int)ldqk * 2 + ((lane ^ (row & 15)) << 4));
+    const int d = 16 * (8 * i + w) + (lane >> 2);
+    v_src[i] = (uint32_t)(((int64_t)d * S) * 2 + (((lane & 3) ^ ((d >> 2) & 3)) << 4));
+  }
+  auto dma_tile = [&](const int t, const int buf) {
     char* kb = smem + buf * (VA_KBYTES + VA_VBYTES);
     char* vb = kb + VA_KBYTES;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = i * 256 + tid;
-      const int row = c >> 6, ch = c & 63;
-      *(u32x4*)(kb + row * 1024 + ((ch ^ (row & 15)) << 4)) = kst[i];
-      const int d = c >> 2, part = c & 3;
-      *(u32x4*)(vb + d * VA_VPITCH + part * 16) = vst[i];
+    for (int i = 0; i < 4; ++i) {
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kb + (8 * i + w) * 1024), k_src[i], t * (VA_KT * (int)ldqk * 2));
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vb + (8 * i + w) * 1024), v_src[i], t * (VA_KT * 2));
     }
   };
 
   const int nt = S / VA_KT;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // per-lane V^T fragment offsets: row l15 of a d-tile, 8-byte units g and 4 + g of the row -> chunks (g >> 1), 2 + (g >> 1), swizzled
+  const int vsw = (l15 >> 2) & 3;
+  const int v_off0 = (hh * 256 + l15) * VA_VPITCH + (((g >> 1) ^ vsw) << 4) + (g & 1) * 8;
+  const int v_off1 = (hh * 256 + l15) * VA_VPITCH + (((2 + (g >> 1)) ^ vsw) << 4) + (g & 1) * 8;
   for (int t = 0; t < nt; ++t) {
     const char* kb = smem + (t & 1) * (VA_KBYTES + VA_VBYTES);
     const char* vb = kb + VA_KBYTES;
-    if (t + 1 < nt) load_tile(t + 1);              // in flight under this tile's MFMAs
-    // ---- S^T = K Q^T: two 16-key tiles x 16 d-steps
+    if (t + 1 < nt) dma_tile(t + 1, (t + 1) & 1);  // lands under this tile's MFMAs; that buffer's readers passed the barrier below
+    // ---- S^T = K Q^T: two 16-key tiles x 16 d-steps, fragment reads one group of four ahead
     f32x4 sc[2];
 #pragma unroll
-    for (int T = 0; T < 2; ++T) {
+    for (int T = 0; T < 2; ++T)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sc[T][r] = 0.f;
-      const int row = T * 16 + l15;
+    {
+      bf16x8 kfr[2][4];
+      auto rd_k = [&](const int G, bf16x8 (&dst)[4]) {       // group G: tile T = G / 4, d-steps 4 (G % 4) .. + 3
+        const int row = (G >> 2) * 16 + l15;
 #pragma unroll
-      for (int ds = 0; ds < 16; ++ds) {
-        const bf16x8 kf = *(const bf16x8*)(kb + row * 1024 + (((ds * 4 + g) ^ (row & 15)) << 4));
-        sc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ds], sc[T], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          const int ds = (G & 3) * 4 + e;
+          dst[e] = *(const bf16x8*)(kb + row * 1024 + (((ds * 4 + g) ^ (row & 15)) << 4));
+        }
+      };
+      rd_k(0, kfr[0]);
+#pragma unroll
+      for (int G = 0; G < 8; ++G) {
+        if (G + 1 < 8) rd_k(G + 1, kfr[(G + 1) & 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sc[G >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[G & 1][e], qf[(G & 3) * 4 + e], sc[G >> 2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- online softmax for query l15 (its 8 keys of this tile in this lane; the rest in lanes l15 + 16 g')
@@ -321,35 +369,48 @@ __global__ __launch_bounds__(256) void vae_attn_kernel(const bf16_t* __restrict_
     l_run = l_run * alpha + psum;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int dt = 0; dt < 32; ++dt)
+      for (int dt = 0; dt < 16; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
     }
     bf16x8 pb;
 #pragma unroll
     for (int e = 0; e < 8; ++e) pb[e] = f2bf(pv[e]);
-    // ---- O^T += V^T P^T: 32 d-tiles, k = this tile's 32 keys in the operand order {4g.., 16 + 4g..}
+    // ---- O^T += V^T P^T: this wave's 16 d-tiles, k = this tile's 32 keys in the operand order {4g.., 16 + 4g..}
+    {
+      u32x4 vfr[2][4];
+      auto rd_v = [&](const int G, u32x4 (&dst)[4]) {
 #pragma unroll
-    for (int dt = 0; dt < 32; ++dt) {
-      const char* vr = vb + (dt * 16 + l15) * VA_VPITCH + g * 8;
-      const u32x2 lo = *(const u32x2*)vr, hi = *(const u32x2*)(vr + 32);
-      u32x4 v4 = {lo[0], lo[1], hi[0], hi[1]};
-      oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v4), pb, oacc[dt], 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          const char* vr = vb + (G * 4 + e) * 16 * VA_VPITCH;
+          const u32x2 lo = *(const u32x2*)(vr + v_off0), hi = *(const u32x2*)(vr + v_off1);
+          dst[e] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      };
+      rd_v(0, vfr[0]);
+#pragma unroll
+      for (int G = 0; G < 4; ++G) {
+        if (G + 1 < 4) rd_v(G + 1, vfr[(G + 1) & 1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          oacc[G * 4 + e] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vfr[G & 1][e]), pb, oacc[G * 4 + e], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (t + 1 < nt) {
-      store_tile((t + 1) & 1);                     // the other buffer: its last readers passed the barrier below one iteration ago
-      __syncthreads();
-    }
+    // tile t + 1 has landed for this wave (counted explicitly: never rely on hipcc's bookkeeping for LDS-DMA across a back edge),
+    // then for every wave; and every wave is done reading tile t's buffer (its fragment reads were waited for by their MFMAs)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-  // ---- normalise and store: lane holds d = dt*16 + 4g + r of query q0 + l15
+  // ---- normalise and store: lane holds d = (hh*16 + dt)*16 + 4g + r of query q0 + l15
   float l_tot = l_run;
   l_tot += __shfl_xor(l_tot, 16);
   l_tot += __shfl_xor(l_tot, 32);
   const float inv = 1.0f / l_tot;
   if (q0 + l15 < S) {
-    bf16_t* orow = out + (int64_t)(q0 + l15) * VA_C + 4 * g;
+    bf16_t* orow = out + (int64_t)(q0 + l15) * VA_C + hh * 256 + 4 * g;
 #pragma unroll
-    for (int dt = 0; dt < 32; ++dt) {
+    for (int dt = 0; dt < 16; ++dt) {
       u32x2 o;
       o[0] = pack2(oacc[dt][0] * inv, oacc[dt][1] * inv);
       o[1] = pack2(oacc[dt][2] * inv, oacc[dt][3] * inv);
@@ -377,7 +438,7 @@ struct VaeCtx {
   bf16_t* col;                 // encoder: im2col buffer
   void* sk; int64_t sk_bytes;  // GEMM scratch (stream-K flags + partial tiles)
 };
-constexpr int GN_BLOCKS = 512;
+constexpr int GN_BLOCKS = 2048;
 
 static inline int64_t padded_elems(int H, int W, int C) { return (int64_t)(H + 2) * (W + 2) * C; }
 
@@ -389,8 +450,10 @@ static inline int64_t padded_elems(int H, int W, int C) { return (int64_t)(H + 2
 
 static int group_norm(VaeCtx& c, const rf_vae_norm& n, const bf16_t* x, bf16_t* y, int H, int W, int C, bool silu, bool compact) {
   RF_REQUIRE(n.gamma && n.beta, RF_ERR_NULL, "rf_vae: GroupNorm weights NULL");
-  RF_REQUIRE(C % 8 == 0 && 256 % (C / 8) == 0 && C <= 512 && c.w->groups > 0 && c.w->groups <= 64 && C % c.w->groups == 0, RF_ERR_SHAPE,
-             "rf_vae: GroupNorm over C=%d channels, %d groups is not supported (C in {64,128,256,512})", C, c.w->groups);
+  const int cpg = c.w->groups > 0 ? C / c.w->groups : 0;
+  RF_REQUIRE(C % 8 == 0 && 256 % (C / 8) == 0 && C <= 512 && c.w->groups > 0 && C % c.w->groups == 0 &&
+                 (cpg == 2 || cpg == 4 || cpg == 8 || cpg == 16), RF_ERR_SHAPE,
+             "rf_vae: GroupNorm over C=%d channels, %d groups is not supported (C in {64,128,256,512}, 2..16 channels per group)", C, c.w->groups);
   const int64_t npix = (int64_t)(H + 2) * (W + 2);
   const int nblk = (int)(npix < GN_BLOCKS * 64 ? cdiv64(npix, 64) : GN_BLOCKS);
   const int ppb = (int)cdiv64(npix, nblk);
@@ -402,7 +465,7 @@ static int group_norm(VaeCtx& c, const rf_vae_norm& n, const bf16_t* x, bf16_t* 
     case 64: hipLaunchKernelGGL(gn_stats_kernel<64>, dim3(nblk), dim3(256), 0, c.st, x, H, W, C, ppb, c.part); break;
     default: RF_REQUIRE(false, RF_ERR_SHAPE, "rf_vae: GroupNorm channel count %d", C);
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(512), 0, c.st, c.part, nblk, x + (int64_t)(W + 3) * C, C, c.w->groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(c.w->groups), dim3(256), 0, c.st, c.part, nblk, x + (int64_t)(W + 3) * C, C, c.w->groups,
                      (double)H * W * (C / c.w->groups), 1e-6f, (const bf16_t*)n.gamma, (const bf16_t*)n.beta, c.ab);
   const int grid = grid_for(npix * (C / 8));
   if (compact) {
@@ -420,35 +483,65 @@ static void set_seg(rf_kseg& s, const void* A, int64_t lda, const void* W, int64
   s.A = A; s.lda = lda; s.W = W; s.ldw = ldw; s.K = K; s._pad = 0;
 }
 
-// 3x3 / stride 1 / pad 1 convolution of a zero-halo image as a 3-segment GEMM (see the file header); residual != NULL: out = residual + conv
+// 3x3 / stride 1 / pad 1 convolution of a zero-halo image as a 3-segment GEMM (see the file header); residual != NULL: out = residual + conv.
+// Narrow outputs run FOLDED when the packer provided the copy (rf_vae_conv.wf) and the image is wide enough: g adjacent output
+// pixels are one GEMM row -- A rows of (g+2) Cin taps at a pitch of g Cin, N = g Cout -- so a cout = 128 layer fills the 256-column
+// MFMA tile (1.5x fewer MFMAs than half-empty tiles) and the 8-channel conv_out 2.8x fewer.  The last row may run up to g-1
+// pixels past the last interior pixel: those land in the bottom halo row (g <= W + 3), whose content nobody reads.
 static int conv3x3(VaeCtx& c, const rf_vae_conv& cv, const bf16_t* x, bf16_t* y, int H, int W, const bf16_t* residual) {
   RF_REQUIRE(cv.w && cv.cin % 64 == 0 && cv.cout % 8 == 0 && cv.cout <= 1024, RF_ERR_SHAPE, "rf_vae: conv3x3 %d -> %d (need cin %% 64 == 0, cout %% 8 == 0)",
              cv.cin, cv.cout);
   RF_REQUIRE(padded_elems(H, W, cv.cin > cv.cout ? cv.cin : cv.cout) * 2 <= c.cap, RF_ERR_WORKSPACE, "rf_vae: activation %dx%dx%d exceeds the workspace buffers",
              H, W, cv.cin > cv.cout ? cv.cin : cv.cout);
   const int Wp = W + 2, Ci = cv.cin, Co = cv.cout;
-  rf_gemm_desc d;
-  memset(&d, 0, sizeof(d));
-  d.N = Co; d.num_groups = 1; d.epilogue = residual ? RF_EPI_GATE_RES : RF_EPI_STORE;
-  d.splitk_ws = c.sk; d.splitk_ws_bytes = c.sk_bytes;
-  rf_gemm_group& g = d.g[0];
-  g.M = (H - 1) * Wp + W;
-  for (int dy = 0; dy < 3; ++dy) set_seg(g.seg[dy], x + (int64_t)dy * Wp * Ci, Ci, (const bf16_t*)cv.w + (int64_t)dy * 3 * Ci, 9 * Ci, 3 * Ci);
-  g.bias = cv.b;
-  g.out = y + (int64_t)(Wp + 1) * Co; g.ldo = Co;
-  if (residual) { g.residual = residual + (int64_t)(Wp + 1) * Co; g.ldr = Co; g.gate = c.ones; }
-  return rf_gemm_bf16(&d, c.st);
+  const int g = (cv.wf != nullptr && cv.fold > 1 && cv.fold <= W + 3) ? cv.fold : 1;
+  const int M = (H - 1) * Wp + W;
+  const bf16_t* wsel = (const bf16_t*)(g > 1 ? cv.wf : cv.w);
+  const int Kseg = (g + 2) * Ci;
+  const int64_t lda = (int64_t)g * Ci, ldo = (int64_t)g * Co;
+  const int rows = cdiv(M, g);
+  // the GEMM addresses an operand through a 2 GiB buffer window (32-bit byte offsets): cut the rows into launches that fit
+  // (2048^2 images: 4.2 M rows x 1 KiB).  Chunks are multiples of 256 rows: whole tiles, bit-identical to one launch.
+  int64_t max_rows = ((0x7fffffffll - 4096 - (int64_t)Kseg * 2) / (lda * 2)) / 256 * 256;
+  if (max_rows < 256) max_rows = 256;
+  for (int64_t r0 = 0; r0 < rows; r0 += max_rows) {
+    rf_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = g * Co; d.num_groups = 1; d.epilogue = residual ? RF_EPI_GATE_RES : RF_EPI_STORE;
+    d.splitk_ws = c.sk; d.splitk_ws_bytes = c.sk_bytes;
+    rf_gemm_group& G = d.g[0];
+    G.M = (int)(rows - r0 < max_rows ? rows - r0 : max_rows);
+    // the bottleneck-resolution layers (128^2 x 512 channels: 130 tiles of 256^2 with 72 K-tiles each) neither fill the chip with
+    // whole 256^2 tiles nor run well on the 128^2-tile kernel AUTO would pick for < 200 tiles: stream-K cuts their K-tile
+    // iterations evenly over the CUs
+    {
+      const int64_t t256 = (int64_t)cdiv(G.M, 256) * cdiv(d.N, 256);
+      if (t256 >= 32 && t256 < 200 && 3 * Kseg / 64 >= 16) d.schedule = RF_SCHED_STREAMK;
+    }
+    for (int dy = 0; dy < 3; ++dy)
+      set_seg(G.seg[dy], x + (int64_t)dy * Wp * Ci + r0 * lda, lda, wsel + (int64_t)dy * Kseg, 3 * Kseg, Kseg);
+    G.bias = g > 1 ? cv.bf : cv.b;
+    G.out = y + (int64_t)(Wp + 1) * Co + r0 * ldo; G.ldo = ldo;
+    if (residual) { G.residual = residual + (int64_t)(Wp + 1) * Co + r0 * ldo; G.ldr = ldo; G.gate = c.ones; }
+    RF_TRY(rf_gemm_bf16(&d, c.st));
+  }
+  return RF_OK;
 }
 
 // plain GEMM  y[M x N] = x[M x K] . w[N x K]^T + b   (1x1 convolutions over ALL padded pixels, the attention projections)
 static int linear(VaeCtx& c, const bf16_t* x, int64_t ldx, const void* w, const void* b, int M, int N, int K, bf16_t* y, int64_t ldy) {
-  rf_gemm_desc d;
-  memset(&d, 0, sizeof(d));
-  d.N = N; d.num_groups = 1; d.epilogue = RF_EPI_STORE;
-  d.splitk_ws = c.sk; d.splitk_ws_bytes = c.sk_bytes;
-  set_seg(d.g[0].seg[0], x, ldx, w, K, K);
-  d.g[0].bias = b; d.g[0].M = M; d.g[0].out = y; d.g[0].ldo = ldy;
-  return rf_gemm_bf16(&d, c.st);
+  int64_t max_rows = ((0x7fffffffll - 4096 - (int64_t)K * 2) / (ldx * 2)) / 256 * 256;   // 2 GiB operand window, see conv3x3
+  if (max_rows < 256) max_rows = 256;
+  for (int64_t r0 = 0; r0 < M; r0 += max_rows) {
+    rf_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.N = N; d.num_groups = 1; d.epilogue = RF_EPI_STORE;
+    d.splitk_ws = c.sk; d.splitk_ws_bytes = c.sk_bytes;
+    set_seg(d.g[0].seg[0], x + r0 * ldx, ldx, w, K, K);
+    d.g[0].bias = b; d.g[0].M = (int)(M - r0 < max_rows ? M - r0 : max_rows); d.g[0].out = y + r0 * ldy; d.g[0].ldo = ldy;
+    RF_TRY(rf_gemm_bf16(&d, c.st));
+  }
+  return RF_OK;
 }
 
 // ResnetBlock2D: x <- shortcut(x) + conv2(silu(gn2(conv1(silu(gn1(x))))))   (in place on c.X; channel count may change)
@@ -486,7 +579,7 @@ static int attention(VaeCtx& c, const rf_vae_attn& a, int H, int W) {
       attr_set = true;
     }
     ProfScope prof(RF_KC_ATTN, 4.0 * (double)S * S * C, c.st);
-    hipLaunchKernelGGL(vae_attn_kernel, dim3(S / 64), dim3(256), VA_LDS, c.st, c.aqk, c.avt, c.ao, S,
+    hipLaunchKernelGGL(vae_attn_kernel, dim3(S / 64), dim3(512), VA_LDS, c.st, c.aqk, c.avt, c.ao, S,
                        1.4426950408889634f / sqrtf((float)C));
     RF_LAUNCH_CHECK();
   }
@@ -537,7 +630,7 @@ static VaeSizes vae_sizes(const rf_vae_weights* w, int encode, int h, int wd) {
   const int Hm = encode ? H : h, Wm = encode ? W : wd;
   const int Cm = w->mid0.conv1.cin;
   see(Hm, Wm, Cm);
-  z.cap = round_up(cap, 256);
+  z.cap = round_up(cap + 64 * 512 * 2, 256);   // + 64 pixels of slack: a folded convolution's last row reads up to fold - 1 pixels past the image
   if (w->has_attn) {
     const int64_t S = (int64_t)Hm * Wm;
     z.attn_qk = round_up(S * 2 * Cm * 2, 256);

@@ -17,6 +17,8 @@ Weight repacking (once, at construction):
     attention to_q | to_k -> [2C][C];  to_v stays [C][C] and is used as the A operand (V^T = W_v . x^T);  to_v.bias is folded
               into the out-projection bias: softmax rows sum to 1, so P (V + 1 b_v^T) W_o^T = P V W_o^T + (W_o b_v)^T.
 Channel padding: latent 16 -> 64 and RGB 3 -> 64 on the input side (zero weights for the padding), RGB 3 -> 8 on the output side.
+Narrow layers (cout = 128 at the 1024^2 level, the 8-channel conv_out) additionally get a FOLDED weight copy: g = 256 / cout
+adjacent output pixels become one GEMM row (N = 256: a full MFMA tile instead of a half- or 31/32-empty one).
 """
 from __future__ import annotations
 
@@ -57,6 +59,13 @@ class _Packer:
         bp = torch.zeros(cop)
         bp[:co] = m.bias.detach().float().cpu()
         out.w, out.b, out.cin, out.cout = self.t(wp.reshape(cop, 9 * cip)), self.t(bp), cip, cop
+        # narrow outputs: fold g = 256 / cout adjacent output pixels into one GEMM row (rf_vae_conv.wf): a full 256-column tile
+        if cop < 256 and 256 % cop == 0:
+            g = 256 // cop
+            wf = torch.zeros(g, cop, 3, g + 2, cip)
+            for j in range(g):
+                wf[j, :, :, j:j + 3, :] = wp
+            out.wf, out.bf, out.fold = self.t(wf.reshape(g * cop, 3 * (g + 2) * cip)), self.t(bp.repeat(g)), g
 
     def conv1(self, out: "L.rf_vae_conv", m):
         w = m.weight.detach()
