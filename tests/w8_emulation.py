@@ -36,9 +36,15 @@ def fq_weight(W: torch.Tensor) -> torch.Tensor:
 
 
 class FakeQuantLinear(nn.Module):
-    def __init__(self, base: nn.Linear, lengths):
+    """`stored_bf16`: the product keeps this linear's INPUT in HBM as bf16 before it quantises it (the attention output ATT
+    and the FF hidden HID go through rf_quant_rows_fp8 from bf16 rows; the LayerNorm+modulate outputs are quantised straight
+    from fp32 registers).  With `emulate_storage` the emulation rounds such inputs to bf16 first, so that product and
+    emulation quantise (almost) the same numbers and far fewer e4m3 codes flip between them."""
+    emulate_storage = False
+
+    def __init__(self, base: nn.Linear, lengths, stored_bf16: bool = False):
         super().__init__()
-        self.base, self.lengths = base, set(lengths)
+        self.base, self.lengths, self.stored_bf16 = base, set(lengths), stored_bf16
         self.in_features, self.out_features = base.in_features, base.out_features
 
     @property
@@ -52,12 +58,15 @@ class FakeQuantLinear(nn.Module):
     def forward(self, x):
         if x.shape[-2] not in self.lengths:
             return self.base(x)
+        if self.stored_bf16 and FakeQuantLinear.emulate_storage:
+            x = x.to(torch.bfloat16).to(x.dtype)
         return F.linear(fq_rows(x), fq_weight(self.base.weight), self.base.bias)
 
 
 _DOUBLE = ("attn.to_q", "attn.to_k", "attn.to_v", "attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_out.0",
            "attn.to_add_out", "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2")
 _SINGLE = ("attn.to_q", "attn.to_k", "attn.to_v", "proj_mlp", "proj_out")
+_STORED_BF16 = ("attn.to_out.0", "attn.to_add_out", "ff.net.2", "ff_context.net.2", "proj_out")   # inputs: ATT / HID rows in bf16
 
 
 def _wrap(block: nn.Module, names, lengths):
@@ -66,14 +75,14 @@ def _wrap(block: nn.Module, names, lengths):
         mod = parent[int(leaf)] if leaf.isdigit() else getattr(parent, leaf)
         if isinstance(mod, O.LoraLinear):                      # quantise underneath the LoRA wrapper
             if not isinstance(mod.base_layer, FakeQuantLinear):
-                mod.base_layer = FakeQuantLinear(mod.base_layer, lengths)
+                mod.base_layer = FakeQuantLinear(mod.base_layer, lengths, name in _STORED_BF16)
             else:
                 mod.base_layer.lengths = set(lengths)
             continue
         if isinstance(mod, FakeQuantLinear):
             mod.lengths = set(lengths)
             continue
-        w = FakeQuantLinear(mod, lengths)
+        w = FakeQuantLinear(mod, lengths, name in _STORED_BF16)
         if leaf.isdigit():
             parent[int(leaf)] = w
         else:
