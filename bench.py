@@ -421,8 +421,14 @@ def main():
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (plumbing check, not a scaling measurement)")
     ap.add_argument("--no-attention-table", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay of each candidate's denoise loop (RF_DENOISE_GRAPH=1; the default for T >= 16)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (RF_DENOISE_GRAPH=0)")
     args = ap.parse_args()
 
+    if args.graph:
+        os.environ["RF_DENOISE_GRAPH"] = "1"
+    if args.no_graph:
+        os.environ["RF_DENOISE_GRAPH"] = "0"
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
@@ -521,6 +527,8 @@ def main():
                        "parallelism": f"candidate-parallel x{shard.world_size}, weights replicated"},
             "whole_path": {"tflop_per_forward": round(f_fwd / 1e12, 2), "achieved_tflops_per_gpu": round(step_tflops / shard.world_size, 1),
                            "frac_of_bf16_mfma_peak": round(step_tflops / shard.world_size / PEAK_BF16_TFLOPS, 4)},
+            "denoise_loop": "eager launches" if os.environ.get("RF_DENOISE_GRAPH", "") == "0" or (os.environ.get("RF_DENOISE_GRAPH", "") == "" and T < 16)
+                            else "one hipGraph per (geometry, T) replayed per candidate",
             "selected_candidate": best[0], "selected_seed": 7919 * best[0] + 13,
             "round_boundary_ms": round(round_boundary_s * 1e3, 2),
             "dist": {"backend": backend, "ranks_share_gpu": bool(args.ranks_share_gpu)} if shard.world_size > 1 else None,

@@ -14,6 +14,7 @@ MI355X-first choices made here:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional, Tuple
 
@@ -230,6 +231,8 @@ def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
 
 class FluxEngine:
     def __init__(self, transformer: M.FluxTransformer2DModel):
+        self._graphs = {}      # hipGraphs of whole denoise loops, see denoise(use_graph=True)
+        self._eager_done = False
         self.lib = L.load()
         self.tr = transformer
         self.fp8 = bool(getattr(transformer, "_rf_fp8", False))     # BASELINE cfg5: fp8 weights + activations (W8A8)
@@ -355,21 +358,61 @@ class FluxEngine:
         return out
 
     def denoise(self, latents, ctx, mod_steps, dts, cos, sin, cond_latents=None, mod_cond=None, model_config=None,
-                c_factor=None) -> torch.Tensor:
+                c_factor=None, use_graph: Optional[bool] = None) -> torch.Tensor:
         """T-step loop in ONE C call, latents [S_img, in_ch] updated in place.
-        mod_steps [T, mod_cols] (row i = modulation table of timestep i), dts = sigma_{i+1}-sigma_i."""
+        mod_steps [T, mod_cols] (row i = modulation table of timestep i), dts = sigma_{i+1}-sigma_i.
+        use_graph (default: on for T >= 16 unless RF_DENOISE_GRAPH=0; RF_DENOISE_GRAPH=1 forces it for any T): replay the whole
+        T-step loop (T x ~300 launches) as ONE hipGraph captured per (geometry, T, schedule) over static buffers -- bit-identical to
+        the eager launches (tests/test_round3_gpu.py) and worth +0.4..1.0 % at cfg2 (profiles/r03_graph.md: the device-side cost of
+        a dependent kernel boundary is the same 1.1-1.9 us eager or replayed, MI355X_MICROARCH.md 'boundary'; what goes away is the
+        host-side enqueue jitter between the 15 000 launches of a candidate).  Never used while the timing hook is open."""
         Sc = 0 if cond_latents is None else cond_latents.shape[0]
         d = self.dims(ctx.shape[0], latents.shape[0], Sc, model_config, c_factor)
         ws = self.workspace(d)
         T = len(dts)
         if mod_steps.shape != (T, self.mod_cols) or not mod_steps.is_contiguous():
             raise ops.RFError("FluxEngine.denoise: mod_steps must be contiguous [T, mod_cols]")
-        vel = torch.empty_like(latents)
+        if use_graph is None:
+            env = os.environ.get("RF_DENOISE_GRAPH", "")
+            use_graph = (env not in ("", "0")) if env != "" else T >= 16
+        if ops.profile.open_count > 0:
+            use_graph = False                                # the hook records one event per launch: needs the eager launches
         arr = (C.c_float * T)(*[float(x) for x in dts])
-        L.check(self.lib.rf_flux_denoise(
-            C.byref(d), C.byref(self.model), latents.data_ptr(), ops.ptr(cond_latents), ctx.data_ptr(),
-            mod_steps.data_ptr(), mod_steps.stride(0), ops.ptr(mod_cond), cos.data_ptr(), sin.data_ptr(),
-            arr, T, vel.data_ptr(), C.byref(ws), ops.stream_ptr()), "rf_flux_denoise")
+
+        def launch(lat, cx, mod, cs, sn, cond, mc, vel):
+            L.check(self.lib.rf_flux_denoise(
+                C.byref(d), C.byref(self.model), lat.data_ptr(), ops.ptr(cond), cx.data_ptr(),
+                mod.data_ptr(), mod.stride(0), ops.ptr(mc), cs.data_ptr(), sn.data_ptr(),
+                arr, T, vel.data_ptr(), C.byref(ws), ops.stream_ptr()), "rf_flux_denoise")
+
+        if not use_graph or not self._eager_done:
+            # (the first launch of a process runs eagerly even under use_graph: one-time hipFuncSetAttribute / device queries of
+            #  the library must not happen inside a stream capture)
+            launch(latents, ctx, mod_steps, cos, sin, cond_latents, mod_cond, torch.empty_like(latents))
+            self._eager_done = True
+            return latents
+        key = (bytes(d), T, tuple(float(x) for x in dts), ws.base, tuple(cos.shape))
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 2:                       # a captured 50-step loop holds ~110 MB of static tables
+                self._graphs.pop(next(iter(self._graphs)))
+            st = dict(lat=torch.empty_like(latents), ctx=torch.empty_like(ctx), mod=torch.empty_like(mod_steps), cos=torch.empty_like(cos),
+                      sin=torch.empty_like(sin), vel=torch.empty_like(latents),
+                      cond=None if cond_latents is None else torch.empty_like(cond_latents),
+                      mc=None if mod_cond is None else torch.empty_like(mod_cond))
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(graph, stream=side):
+                launch(st["lat"], st["ctx"], st["mod"], st["cos"], st["sin"], st["cond"], st["mc"], st["vel"])
+            torch.cuda.current_stream().wait_stream(side)
+            ent = self._graphs[key] = (graph, st)
+        graph, st = ent
+        for k_, src in (("lat", latents), ("ctx", ctx), ("mod", mod_steps), ("cos", cos), ("sin", sin), ("cond", cond_latents), ("mc", mod_cond)):
+            if src is not None:
+                st[k_].copy_(src)
+        graph.replay()
+        latents.copy_(st["lat"])
         return latents
 
 

@@ -58,16 +58,20 @@ class profile:
     pair on its own launch stream (rf_profile_begin / rf_profile_end).  After the block, `pr.classes` maps
     kernel class -> {"launches", "us", "work"} (work = algorithmic FLOPs, bytes for row kernels)."""
 
+    open_count = 0          # > 0 while a profile is open (FluxEngine.denoise then launches eagerly, never through a hipGraph)
+
     def __init__(self, max_launches: int = 4096):
         self.max_launches, self.classes, self.dropped = max_launches, {}, 0
 
     def __enter__(self):
         L.check(L.load().rf_profile_begin(self.max_launches), "rf_profile_begin")
+        profile.open_count += 1
         return self
 
     def __exit__(self, et, ev, tb):
         n = len(L.RF_KC_NAMES)
         us, cnt, work, dropped = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), C.c_int32(0)
+        profile.open_count = max(0, profile.open_count - 1)
         rc = L.load().rf_profile_end(us, cnt, work, C.byref(dropped))
         if et is None:
             L.check(rc, "rf_profile_end")

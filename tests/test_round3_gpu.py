@@ -216,6 +216,37 @@ def test_engine_with_norm_weights_beyond_the_bound(dev):
     print(f"  qk bound {bound:.0f}: hip {e[0]:.3e}  torch-bf16 {e[1]:.3e}")
 
 
+@torch.no_grad()
+def test_denoise_loop_as_one_hipgraph_equals_eager(dev, monkeypatch):
+    """FluxEngine.denoise(use_graph=True): the whole T-step loop captured once per (geometry, T, schedule) over static buffers
+    and replayed per candidate -- bit-identical to the eager launches, also for later candidates and with a condition + LoRA."""
+    from oracle import flux_oracle as O
+    from reflectionflow_amd.flux.condition import Condition
+    from reflectionflow_amd.flux.generate import generate
+    from tests.golden_util import SHAPES, T, build, load
+    from tests.test_model_gpu import g, to_product
+    z = load("loop_hd128")
+    s_ = SHAPES["hd128"]
+    om = build("hd128", lora=True)
+    pipe = to_product(om, dev)
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+
+    def run(seed, use_c):
+        lat = O.get_noises([seed], s_["gh"] * 16, s_["gw"] * 16, dtype=torch.float32)[seed]
+        conds = [Condition("cot", tokens=g(T(z["cond"]), dev), ids=T(z["cond_ids"]).to(dev))] if use_c else None
+        return generate(pipe, conditions=conds, model_config=cfg, default_lora=True, height=s_["gh"] * 16, width=s_["gw"] * 16,
+                        num_inference_steps=4, guidance_scale=3.5, latents=g(lat, dev), prompt_embeds=g(T(z["pe"]), dev),
+                        pooled_prompt_embeds=g(T(z["pooled"]), dev), output_type="latent").images.clone()
+    eager = {(sd, c): run(sd, c) for sd in (1, 2, 3) for c in (False, True)}
+    monkeypatch.setenv("RF_DENOISE_GRAPH", "1")
+    for rep in range(2):                      # capture on first use, replay afterwards
+        for (sd, c), ref in eager.items():
+            out = run(sd, c)
+            assert torch.equal(out, ref), f"graph replay differs from eager (seed {sd}, condition {c}, pass {rep})"
+    from reflectionflow_amd import engine as E
+    assert len(E.engine_for(pipe.transformer)._graphs) == 2
+
+
 def test_rccl_world1_allgather_of_the_round_message(dev):
     """backend="nccl" IS RCCL on ROCm: initialise it once on the GPU box (world size 1, dmabuf IPC mode) and run the
     round-boundary exchange of tts/search.py -- two all_gather_into_tensor calls, f32 scores and i32 labels."""
