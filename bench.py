@@ -141,6 +141,30 @@ def isolated_shapes(dev, S_txt, S_img, D, mlp, heads, nd, ns):
 NOMINAL_MHZ = 2400.0   # the clock the 2.5 PFLOP/s dense bf16 peak is quoted at
 
 
+def vae_table(dev, res):
+    """the metric's latent excludes the VAE ("reported separately").  Decode of one res x res candidate and encode of a
+    512 x 512 condition image through the HIP path (rf_vae_decode / rf_vae_encode, FLUX.1-dev VAE shape, random-init weights)."""
+    from reflectionflow_amd.flux.vae import AutoencoderKL, init_synthetic_vae_
+    from reflectionflow_amd.flux.vae_hip import HipVAE
+    hv = HipVAE(init_synthetic_vae_(AutoencoderKL(), seed=0).to(dev).to(torch.bfloat16).eval())
+    out = {"path": "HIP (librf_flux.so rf_vae_decode / rf_vae_encode): convolutions = 3-K-segment launches of the bf16 MFMA GEMM"}
+    for name, shape, fn in ((f"decode_{res}_ms", (1, 16, res // 8, res // 8), lambda t: hv.decode(t).sample),
+                            ("encode_512_ms", (1, 3, 512, 512), lambda t: hv.encode_moments(t))):
+        x = torch.randn(*shape, device=dev).to(torch.bfloat16)
+        with torch.no_grad():
+            fn(x); fn(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn(x)
+            torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / 10 * 1e3, 2)
+    out["decode_frac_of_a_candidate"] = round(out[f"decode_{res}_ms"] / 1e3 / 3.1, 4)
+    del hv
+    torch.cuda.empty_cache()
+    return out
+
+
 def attention_table(dev, pipe, S, heads):
     """Which attention kernel the timed run used and what the alternatives cost (VERDICT r2 / ADVICE r2: the headline must
     carry its floor).  The engine hands the bounded-score kernel the bound it derives from the checkpoint's norm_q / norm_k
@@ -421,6 +445,7 @@ def main():
     ap.add_argument("--ranks-share-gpu", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (plumbing check, not a scaling measurement)")
     ap.add_argument("--no-attention-table", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (separately reported) VAE decode / encode timings")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay of each candidate's denoise loop (RF_DENOISE_GRAPH=1; the default for T >= 16)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (RF_DENOISE_GRAPH=0)")
     args = ap.parse_args()
@@ -545,6 +570,8 @@ def main():
                     res["roofline"]["isolated_shapes"] = isolated_shapes(dev, S_txt, S_img, D, 4 * D, heads, nd, ns)
             if not args.no_attention_table:
                 res["attention"] = attention_table(dev, pipe, S_txt + S_img, heads)
+            if not args.no_vae:
+                res["vae"] = vae_table(dev, args.res)
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(S_txt, S_img, T, D, heads, nd, ns)
         print(json.dumps(res), flush=True)

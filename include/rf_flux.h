@@ -163,7 +163,7 @@ int rf_qk_rmsnorm_rope(void* q, void* k, int32_t heads, int32_t S, int32_t s_pad
  *   score_bound: 0 = unknown (online softmax with a running row maximum).  > 0: the caller GUARANTEES
  *         |q.k * scale * log2(e)| <= score_bound for every query/key pair.  FLUX RMS-normalises q and k per head
  *         (block.py:38-41,60-67), so sqrt(128) * max|norm_q.weight| * max|norm_k.weight| * log2(e) is such a bound
- *         whatever the activations are (rf_*_block_weights.qk_bound).  With a bound <= 100, no bias/mask, S % 64 == 0
+ *         whatever the activations are (rf_*_block_weights.qk_bound).  With a bound <= 100, mode 0 (no bias/mask), S % 256 == 0
  *         and a prescaled q the library runs the bounded-score kernel: softmax is shift invariant, so P = exp2(s)
  *         needs no running maximum, no exchange and no rescaling of O (bf16 P / fp32 O,l have the exponent range).
  *         A violated guarantee gives inf/NaN -- pass 0 when in doubt.  Without a usable bound (0, or > 100) the same

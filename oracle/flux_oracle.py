@@ -787,7 +787,12 @@ def denoise(transformer, latents, prompt_embeds, pooled_prompt_embeds, num_infer
     (generate.py:86-90, removed again :312-316).
     `image_guidance_scale` != 1: the second forward of generate.py:250-272 with guidance = 1 and the
     "unconditional" condition tokens -- which the reference's Condition.encode(empty=True) overwrites with the
-    REAL condition's tokens (condition.py:114-121), so both passes see the same condition latents."""
+    REAL condition's tokens (condition.py:114-121), so both passes see the same condition latents.
+    DEVIATION, stated: the reference calls condition.encode(self, empty=True) EVERY step, and with a real VAE
+    that re-runs vae.encode(...).latent_dist.sample() from the global RNG -- fresh posterior noise per step, and the RNG
+    advances.  This restatement (and the goldens final_cond_imgcfg) works on PRE-ENCODED condition tokens, i.e. the
+    deterministic limit of that call; the product's per-step path does call condition.encode(pipe, empty=True) per step
+    like the reference, so with a VAE on the pipeline it consumes the RNG the same way."""
     if condition_scale != 1:
         for name, module in transformer.named_modules():                     # :86-90
             if name.endswith(".attn"):

