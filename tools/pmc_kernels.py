@@ -33,4 +33,7 @@ q.normal_(); k.normal_(); vt.normal_(); q.mul_(ops.QK_PRESCALE)
 BOUND = float(q.float().norm(dim=-1).max() * k.float().norm(dim=-1).max()) * 1.01
 for _ in range(2):
     ops.attention(q, k, vt, S, out=att, q_prescaled=True, score_bound=BOUND); torch.cuda.synchronize()
+# round 3: the lagged-max form (no bound: what a checkpoint with qk_bound > 100 runs)
+for _ in range(2):
+    ops.attention(q, k, vt, S, out=att, q_prescaled=True, score_bound=0.0); torch.cuda.synchronize()
 print("done")

@@ -13,7 +13,7 @@ import collections, csv, glob, json, os, sys
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"     # output prefix under profiles/
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = collections.OrderedDict()
-names = ['dbl_qkv', 'dbl_out', 'dbl_ff1', 'dbl_ff2', 'sgl_in', 'sgl_out', 'attn']
+names = ['dbl_qkv', 'dbl_out', 'dbl_ff1', 'dbl_ff2', 'sgl_in', 'sgl_out', 'attn', 'attn_lag']
 for pth in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out/pmc/p*/p*_counter_collection.csv'))):
     per = collections.OrderedDict()
     for r in csv.DictReader(open(pth)):
@@ -23,7 +23,7 @@ for pth in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out/pmc/p*/p*_counter_col
         d = per.setdefault(int(r['Dispatch_Id']), {'name': kn, 'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
         d[r['Counter_Name']] = float(r['Counter_Value'])
     disp = [per[k] for k in sorted(per)]
-    assert len(disp) == 14, (pth, len(disp))
+    assert len(disp) == 16, (pth, len(disp))
     tag = pth.split('/')[-2]
     for i, n in enumerate(names):
         d = disp[2 * i + 1]                       # second launch of each pair = measured
@@ -35,7 +35,8 @@ S, D, mlp = 4608, 3072, 12288
 alg = {'dbl_qkv': (S*D*2 + 2*3*D*D*2 + S*3*D*2, 2.0*S*3*D*D, 19), 'dbl_out': (S*D*2 + 2*D*D*2 + 2*S*D*2, 2.0*S*D*D, 19),
        'dbl_ff1': (S*D*2 + 2*mlp*D*2 + S*mlp*2, 2.0*S*mlp*D, 19), 'dbl_ff2': (S*mlp*2 + 2*D*mlp*2 + 2*S*D*2, 2.0*S*D*mlp, 19),
        'sgl_in': (S*D*2 + (3*D+mlp)*D*2 + S*(3*D+mlp)*2, 2.0*S*(3*D+mlp)*D, 38),
-       'sgl_out': (S*(D+mlp)*2 + D*(D+mlp)*2 + 2*S*D*2, 2.0*S*D*(D+mlp), 38), 'attn': (4*S*D*2, 4.0*S*S*D, 57)}
+       'sgl_out': (S*(D+mlp)*2 + D*(D+mlp)*2 + 2*S*D*2, 2.0*S*D*(D+mlp), 38), 'attn': (4*S*D*2, 4.0*S*S*D, 57),
+       'attn_lag': (4*S*D*2, 4.0*S*S*D, 0)}
 out = collections.OrderedDict()
 md = [f"# {ROUND} -- PMC counters of the dominant kernels (MI355X, rocprofv3 --pmc, one measured launch each)", "",
       "Command: `bash tools/pmc_collect.sh` (5 separate `rocprofv3 --kernel-trace --pmc ...` passes over `tools/pmc_kernels.py`), parsed by `tools/pmc_parse.py`.",
@@ -55,7 +56,7 @@ for n, e in rows.items():
                   algorithmic_bytes=ab, flops=fl, traffic_over_algorithmic=round((fetch + write) / ab, 2), mfma_busy_pct=round(util, 1),
                   clock_ghz=round(clk, 2), lds_bank_conflict_pct=round(ldsc, 3))
     md.append(f"| {n} (x{cnt}) | `{e['kernel'][:48]}` | {us:.1f} | {fetch/1e6:.0f} | {write/1e6:.0f} | {ab/1e6:.0f} | {(fetch+write)/ab:.2f} | {util:.1f} | {clk:.2f} | {ldsc:.3f} |")
-gem = [v for k, v in out.items() if k != 'attn']
+gem = [v for k, v in out.items() if not k.startswith('attn')]
 tot_n = sum(v['launches_per_forward'] for v in gem)
 summary = dict(gemm_traffic_bytes_per_launch_avg=sum(v['launches_per_forward'] * (v['fabric_read_bytes'] + v['write_bytes']) for v in gem) / tot_n,
                gemm_algorithmic_bytes_per_launch_avg=sum(v['launches_per_forward'] * v['algorithmic_bytes'] for v in gem) / tot_n,
