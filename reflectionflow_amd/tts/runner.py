@@ -69,6 +69,21 @@ def candidate_condition(pipe: FluxPipeline, latents: torch.Tensor, height: int, 
     return Condition(condition=img, condition_type="cot", position_delta=[0, -condition_size // 16])   # as the reference: -size // 16
 
 
+@torch.no_grad()
+def decode_candidates(pipe: FluxPipeline, latents: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """Verifier input without a PNG round trip (the reference saves every candidate as PNG and the verifier
+    re-opens it one by one, tts_reflectionflow.py:145,160,328-332): packed latents [N, S, 64] of a round's candidates ->
+    images [N, 3, H, W] in [0, 1] ON THE DEVICE, decoded by the pipeline's VAE (the HIP path after pipe.enable_hip_vae()).
+    A batched on-device verifier (`score_batch` contract of tts/search.py) takes this tensor directly."""
+    if pipe.vae is None:
+        raise ValueError("decode_candidates(): this pipeline has no VAE")
+    lat = latents if latents.dim() == 3 else latents.reshape(-1, latents.shape[-2], latents.shape[-1])
+    z = pipe._unpack_latents(lat, height, width, pipe.vae_scale_factor)
+    z = z / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor
+    img = pipe.vae.decode(z.to(pipe.vae.dtype), return_dict=False)[0]
+    return (img.float() / 2 + 0.5).clamp(0, 1)
+
+
 def latent_to_condition(latents: torch.Tensor, height: int, width: int, condition_size: int) -> Condition:
     """STAND-IN (used only when the pipeline has no VAE) for `resize(decoded image, condition_size) -> VAE encode`
     (tts_reflectionflow.py:273-279 + condition.py:96-132): area-downsample the candidate's latent grid to the
