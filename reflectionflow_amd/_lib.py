@@ -226,10 +226,13 @@ def load_experiments():
     import torch  # noqa: F401
     lib = C.CDLL(EXP_LIB_PATH)
     for name, (res, args) in {**_SIGS, **_EXTRA_SIGS, **_EXP_SIGS}.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise RFError(f"{EXP_LIB_PATH} is stale (no symbol {name}): rebuild with `make -C reflectionflow_amd/csrc EXPERIMENTS=1`") from None
         fn.restype, fn.argtypes = res, args
     if lib.rf_abi_version() != ABI_VERSION:
-        raise RFError(f"librf_flux_exp ABI {lib.rf_abi_version()} != binding {ABI_VERSION}: rebuild")
+        raise RFError(f"{EXP_LIB_PATH} is stale (ABI {lib.rf_abi_version()} != binding {ABI_VERSION}): rebuild")
     lib._rf_exp = True
     _product, _lib = _lib, lib
     return lib
