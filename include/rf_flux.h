@@ -200,7 +200,9 @@ typedef enum rf_attn_kernel {
   RF_ATTN_BOUNDED16 = 5,        /* bounded score, 16x16x32 MFMAs                                           */
   RF_ATTN_BOUNDED16_SPLIT = 6,  /* ... as one persistent workgroup per CU + combine launch (needs ws)      */
   RF_ATTN_LAGGED16 = 8,         /* lagged-max, 16x16x32 MFMAs: no bound needed                             */
-  RF_ATTN_LAGGED16_SPLIT = 9    /* ... split launch (needs ws)                                             */
+  RF_ATTN_LAGGED16_SPLIT = 9,   /* ... split launch (needs ws)                                             */
+  RF_ATTN_BOUNDED16_MIX = 10,   /* bounded score, workgroups of 256 AND 192 queries sized to fill the CUs  */
+  RF_ATTN_LAGGED16_MIX = 11     /* lagged-max, the same launch                                             */
 } rf_attn_kernel;
 typedef struct rf_attn_desc {
   const void *q, *k, *vt; void* out;  /* as rf_attention_fwd */
@@ -211,7 +213,9 @@ typedef struct rf_attn_desc {
   float lag_thresh;                   /* lagged-max kernels: re-centre a row when a lane's 16-key sum of P exceeds this;
                                          0 = 2^30.  (Tests sweep it: any value gives the same softmax to rounding.) */
   int32_t kernel;                     /* rf_attn_kernel */
-  int32_t _pad;
+  int32_t mix_small;                  /* RF_ATTN_*_MIX only: 192-query workgroups per head, b % 4 == 0 and 12 b <= S / 16 (the
+                                         other S / 256 - 3 b / 4 workgroups of a head take 256 queries); 0 = sized by the
+                                         library for the device's CU count (S = 4608 x 24 heads on 256 CUs: 12) */
   void* ws; int64_t ws_bytes;         /* optional scratch, see rf_attention_fwd_ws */
 } rf_attn_desc;
 int rf_attention(const rf_attn_desc* d, void* stream);

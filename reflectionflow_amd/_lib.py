@@ -19,6 +19,7 @@ RF_SCHED_AUTO, RF_SCHED_TILE128, RF_SCHED_TILE256, RF_SCHED_STREAMK, RF_SCHED_PE
 # rf_attn_kernel (rf_attn_desc.kernel)
 RF_ATTN_AUTO, RF_ATTN_ONLINE128, RF_ATTN_ONLINE256 = 0, 1, 2
 RF_ATTN_BOUNDED32, RF_ATTN_BOUNDED16, RF_ATTN_BOUNDED16_SPLIT, RF_ATTN_LAGGED16, RF_ATTN_LAGGED16_SPLIT = 4, 5, 6, 8, 9
+RF_ATTN_BOUNDED16_MIX, RF_ATTN_LAGGED16_MIX = 10, 11
 
 
 class RFError(RuntimeError):
@@ -50,7 +51,7 @@ class rf_attn_desc(C.Structure):
                 ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("n_main", C.c_int32),
                 ("ldo", C.c_int64), ("mode", C.c_int32), ("q_prescaled", C.c_int32),
                 ("cross_bias", C.c_float), ("scale", C.c_float), ("score_bound", C.c_float), ("lag_thresh", C.c_float),
-                ("kernel", C.c_int32), ("_pad", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("kernel", C.c_int32), ("mix_small", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
 
 
 class rf_w8(C.Structure):
@@ -175,6 +176,7 @@ _EXP_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2
              "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
              "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_attn_knock": (C.c_int, [C.c_int]),
              "rf_debug_attn_v6": (C.c_int, [C.c_int]), "rf_debug_attn_lag": (C.c_int, [C.c_int]),
+             "rf_debug_attn_stamps": (C.c_int, [C.c_void_p]), "rf_debug_attn_mix": (C.c_int, [C.c_int]),
              "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
              "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]), "rf_debug_gemm_mi16": (C.c_int, [C.c_int]),
              "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]),

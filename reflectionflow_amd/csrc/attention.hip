@@ -29,8 +29,10 @@
 // CALLER per launch (rf_attn_desc.kernel) -- no process-global switch.  Knock-out and one-wave-per-SIMD variants:
 // experiments/attention_exp.inc (-DRF_EXPERIMENTS only).  profiles/r02_attention.md / r03_attention.md have the story.
 #include "common.hpp"
+#include <algorithm>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace rf {
 
@@ -508,6 +510,9 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 }
 
 __device__ unsigned long long g_attn_clk_probe[4];   // see ClkProbe (common.hpp)
+#ifdef RF_EXPERIMENTS
+__device__ unsigned long long g_attn_stamps[8][8];   // VAR & 16: s_memtime of block 0's waves around the halves of key tile 40
+#endif
 
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -730,20 +735,44 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
 //     the K fragment read;
 //   * K ring swizzle: chunk ^ ((row & 7) | ((row >> 1) & 8)) -- the 16 rows of a T tile get 16 different chunk slots
 //     (for every fragment the term is just lane & 15).  VT ring: v4's (row >> 1) & 7.
-// normalise a block's O^T accumulators by its row sums and store the 256 x 128 output rows (v5 accumulator layout)
-__device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[8][2], float (&l_run)[2], const int lane, const int w,
-                                             const int head, const int qb) {
+// normalise a wave's O^T accumulators by its row sums and store its NQT x 16 output rows (v5 accumulator layout); q0w = the
+// wave's first query row
+template <int NQT, bool NARROW = false>
+__device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[8][NQT], float (&l_run)[NQT], const int lane, const int head,
+                                             const int q0w) {
   const int l15 = lane & 15, g = lane >> 4;
   const int S = p.S;
+  const bool wide = !NARROW && (p.ldo & 7) == 0;   // 16-byte stores need 16-byte aligned rows
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < NQT; ++qt) {
     // a query's keys are spread over the four lane groups: lanes l15, l15 + 16, + 32, + 48
     float l_tot = l_run[qt];
     l_tot += __shfl_xor(l_tot, 16);
     l_tot += __shfl_xor(l_tot, 32);
     const float inv = 1.0f / l_tot;
-    const int q_row = qb * 256 + w * 32 + qt * 16 + l15;
-    if (q_row < S) {
+    const int q_row = q0w + qt * 16 + l15;
+    if (wide) {
+      // The store tail is store-ISSUE-bound (cdna_hip_programming.md T21): 4 x 16 bytes per lane and q-tile instead of 8 x 8.  A lane
+      // holds d = 4g .. 4g+3 of every d tile; lane groups g and g ^ 1 trade so that the even group owns d = 8 (g >> 1) .. +7 of
+      // the even d tile of a pair and the odd group the same columns of the odd one.
+      bf16_t* orow = p.out + (int64_t)(q_row < S ? q_row : 0) * p.ldo + head * 128 + 8 * (g >> 1);
+#pragma unroll
+      for (int dp = 0; dp < 4; ++dp) {
+        u32x2 ev, od;
+        ev[0] = pack2(oacc[2 * dp][qt][0] * inv, oacc[2 * dp][qt][1] * inv);
+        ev[1] = pack2(oacc[2 * dp][qt][2] * inv, oacc[2 * dp][qt][3] * inv);
+        od[0] = pack2(oacc[2 * dp + 1][qt][0] * inv, oacc[2 * dp + 1][qt][1] * inv);
+        od[1] = pack2(oacc[2 * dp + 1][qt][2] * inv, oacc[2 * dp + 1][qt][3] * inv);
+        const u32x2 send = (g & 1) ? ev : od;
+        u32x2 recv;
+        recv[0] = (uint32_t)__shfl_xor((int)send[0], 16);
+        recv[1] = (uint32_t)__shfl_xor((int)send[1], 16);
+        u32x4 v;
+        if (g & 1) { v[0] = recv[0]; v[1] = recv[1]; v[2] = od[0]; v[3] = od[1]; }
+        else { v[0] = ev[0]; v[1] = ev[1]; v[2] = recv[0]; v[3] = recv[1]; }
+        if (q_row < S) *(u32x4*)(orow + (2 * dp + (g & 1)) * 16) = v;
+      }
+    } else if (q_row < S) {
       bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
@@ -772,9 +801,16 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
 // scale is scaled exactly once (cdna_hip_programming.md T13 hazard) -- and re-exponentiates the tile against m_new.  fp32 l / O
 // and bf16 P hold 2^30 * S * |V| with room to spare, so between re-centrings nothing is lost; on i.i.d. data the slow path
 // never runs after the first tile.  With LAG = false, m == 0 throughout (the caller's proven bound |s| <= 100 makes that safe).
-template <bool PROBE, bool LAG, int KNOCK = 0>   // KNOCK (timing diagnostics, wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing
+//
+// NQT = q-tiles (16 queries) of THIS wave: 2 everywhere except in waves 4-7 of the 192-query workgroups of the mixed-size launch
+// (attn_fwd_kernel_v5mix), which carry one.  q0w = the wave's first query row.  Every wave of a workgroup executes the same
+// barriers and issues the same DMA pieces whatever its NQT.
+// VAR (experiments; 1 and 2 give wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing, 4 = fragment
+// reads ONE group ahead of their MFMAs instead of two (32 = three), 8 = 8-byte epilogue stores, 16 = s_memtime stamps around the
+// halves of key tile 40 (rf_debug_attn_stamps)
+template <bool PROBE, bool LAG, int KNOCK = 0, int NQT = 2, bool ROT = false>
 __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
-                                           const int head, const int qb, const int t0, const int nt, float* partial, ClkProbe& clk) {
+                                           const int head, const int q0w, const int t0, const int nt, float* partial, ClkProbe& clk) {
   const int l15 = lane & 15, g = lane >> 4;
   const int S = p.S;
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
@@ -784,10 +820,10 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   char* const vring = smem + ATT4_RING * 16384;
 
   // Q B-operand fragments: [q-tile][d step of 32]: lane -> query qt*16 + l15, d = 32 ds + 8g .. +8
-  bf16x8 qf[2][4];
+  bf16x8 qf[NQT][4];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int q_row = qb * 256 + w * 32 + qt * 16 + l15;
+  for (int qt = 0; qt < NQT; ++qt) {
+    const int q_row = q0w + qt * 16 + l15;
     const bf16_t* qp = p.q + ((int64_t)head * p.s_pad + (q_row < S ? q_row : S - 1)) * 128 + g * 8;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *(const bf16x8*)(qp + ds * 32);
@@ -824,24 +860,26 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   // K fragment (32-key block b, tile T, d step ds): k_rd[ds] + slot*16384 + b*32*256 + T*8*256
   // V fragment (d tile dt, block b):               v_rd[b] + slot*16384 + dt*16*128
 
-  f32x4 oacc[8][2];   // O^T tiles [d tile][q tile]: d = dt*16 + 4g + r, q = l15
+  f32x4 oacc[8][NQT];   // O^T tiles [d tile][q tile]: d = dt*16 + 4g + r, q = l15
 #pragma unroll
   for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[dt][qt][r] = 0.f;
-  float l_run[2] = {0.f, 0.f};
-  // score tiles, index ti = b*4 + T*2 + qt: this lane holds keys b*32 + T*8 + {0-3 | 4-7 | 16-19 | 20-23}[g] of query l15
-  f32x4 s_cur[8], s_nxt[8];
-  bf16x8 pf[4];   // P(t-1): B-operand fragments [b*2 + qt] of the pending PV product: words T*2, T*2+1 from tile (b, T, qt)
+  float l_run[NQT];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) l_run[qt] = 0.f;
+  // score tiles, index ti = (b*2 + T)*NQT + qt: this lane holds keys b*32 + T*8 + {0-3 | 4-7 | 16-19 | 20-23}[g] of query l15
+  f32x4 s_cur[4 * NQT], s_nxt[4 * NQT];
+  bf16x8 pf[2 * NQT];   // P(t-1): B-operand fragments [b*NQT + qt] of the pending PV product: words T*2, T*2+1 from tile (b, T, qt)
 
   {  // V ring slot 3 stands in for V(-1): tile 0 multiplies it with P(-1) = 0, so it must be finite
     const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < 2; ++i) *(u32x4*)(vring + 3 * 16384 + (i * 8 + w) * 1024 + lane * 16) = z;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2 * NQT; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[i][j] = (bf16_t)0.f;
   }
@@ -854,112 +892,182 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
   for (int bt = 0; bt < 4; ++bt) {   // (b, T) = (bt >> 1, bt & 1)
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_cur[bt * 2 + qt][r] = 0.f;
+      for (int r = 0; r < 4; ++r) s_cur[bt * NQT + qt][r] = 0.f;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
       const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) s_cur[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * 2 + qt], 0, 0, 0);
+      for (int qt = 0; qt < NQT; ++qt) s_cur[bt * NQT + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * NQT + qt], 0, 0, 0);
     }
   }
   // -m of the two q-tiles, as the C operand of the score MFMAs (LAG); a query's four lanes (l15 + 16 g) hold the same value
-  f32x4 negm[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 negm[NQT];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) negm[qt][r] = 0.f;
   if constexpr (LAG) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < NQT; ++qt) {
       float mx = s_cur[qt][0];
 #pragma unroll
       for (int bt = 0; bt < 4; ++bt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_cur[bt * 2 + qt][r]);
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s_cur[bt * NQT + qt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
 #pragma unroll
-      for (int bt = 0; bt < 4; ++bt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_cur[bt * 2 + qt][r] -= mx;
-#pragma unroll
       for (int r = 0; r < 4; ++r) negm[qt][r] = -mx;
     }
+    // S(0) - m exactly as every later tile forms it: the chain starts from -m in the C operand (subtracting afterwards rounds
+    // differently, and a row must not depend on which wave of which launch shape computes it)
+    if constexpr (!ROT) {
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt) {
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) s_cur[bt * NQT + qt] = negm[qt];
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) s_cur[bt * NQT + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s_cur[bt * NQT + qt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if constexpr (ROT) {   // the rotated order computes S(0) itself, as G(-1) of interval 0, which also packs P(-1) = 0 from here
+#pragma unroll
+    for (int i = 0; i < 4 * NQT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_cur[i][r] = 0.f;
   }
 
   auto tile = [&](const int t, auto ts_tag) {
     constexpr int TS = decltype(ts_tag)::value;
-    constexpr int KSLOT = (TS + 1) % 4, VSLOT = (TS + 3) % 4;
+    // between two barriers a wave runs F(t) = [pending PV(t-1) | P(t) = exp2(S(t)) + row sums] and G = [scores of the next tile |
+    // pack P into the PV operand].  ROT = false: F(t), G(t) -- G reads K(t+1) in ring slot (TS+1) % 4.  ROT = true: G(t-1), F(t) --
+    // G reads K(t) in slot TS.  Both read V(t-1) in slot (TS+3) % 4 and both leave the rings alone until the next barrier.
+    constexpr int KSLOT = ROT ? TS : (TS + 1) % 4, VSLOT = (TS + 3) % 4;
+    [[maybe_unused]] unsigned long long stamps[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](const int i) {
+#ifdef RF_EXPERIMENTS
+      if constexpr ((KNOCK & 16) != 0)
+        if (t == 40 && blockIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps[i])::"memory");
+#endif
+    };
+    stamp(0);
     // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t)
     RF_ATT4_WAIT_BARRIER(2 * ((t + 2 < nt) + 1));
+    stamp(1);
     if (t + 3 < nt) issue_k(t + 3, (TS + 3) % 4);
-    if (t + 1 < nt) issue_v(t + 1, KSLOT);
+    if (t + 1 < nt) issue_v(t + 1, (TS + 1) % 4);
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 fr[2][2];   // fragment double buffer: group G multiplies fr[G & 1][0..1]
-    float psum[2] = {0.f, 0.f};
-    // fragment pair of group G: G < 8 -> V^T(t-1) [d tile G, key blocks 0, 1], else K(t+1) [(b, T) = (G-8)/2, d steps ((G-8)%2)*2 + 0, 1]
-    auto load_group = [&](auto gtag) {
-      constexpr int G = decltype(gtag)::value;
+    constexpr int AHEAD = (KNOCK & 36) == 36 ? 4 : (KNOCK & 32) ? 3 : (KNOCK & 4) ? 1 : 2;   // fragment reads run AHEAD groups in front of their MFMAs (2: -2.3 % vs 1, profiles/r03_kb_attn_mix_v1.log)
+    constexpr int NFR = AHEAD + 1;
+    bf16x8 fr[NFR][2];   // fragment ring: group G multiplies fr[G % NFR][0..1]
+    // SUMG: the row sums of P(t) are formed in G (beside the MFMA-only score groups) instead of F (beside exp2).  Not for LAG,
+    // whose overflow test needs them before P(t) is packed.
+    constexpr bool SUMG = !LAG && (KNOCK & 128) != 0;
+    float psum[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) psum[qt] = 0.f;
+    // The 16 groups of an interval sit at positions P = 0 .. 15 (ROT = false: P = G; ROT = true: the G groups 8 .. 15 first).
+    // fragment pair of group G, held in fr[P % NFR]: G < 8 -> V^T(t-1) [d tile G, key blocks 0, 1], else K [(b, T) = (G-8)/2,
+    // d steps ((G-8)%2)*2 + 0, 1]
+    auto load_pos = [&](auto ptag) {
+      constexpr int P = decltype(ptag)::value;
+      constexpr int G = ROT ? (P + 8) % 16 : P;
       if constexpr (KNOCK & 1) {
         if (t > 0) return;
       }
-      if constexpr (G < 8) {
+      if constexpr (P >= 16) {
+      } else if constexpr (G < 8) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) fr[G & 1][e] = *(const bf16x8*)(v_rd[e] + VSLOT * 16384 + G * 16 * 128);
-      } else if constexpr (G < 16) {
+        for (int e = 0; e < 2; ++e) fr[P % NFR][e] = *(const bf16x8*)(v_rd[e] + VSLOT * 16384 + G * 16 * 128);
+      } else {
         constexpr int bt = (G - 8) / 2;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
-          fr[G & 1][e] = *(const bf16x8*)(k_rd[((G - 8) % 2) * 2 + e] + KSLOT * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
+          fr[P % NFR][e] = *(const bf16x8*)(k_rd[((G - 8) % 2) * 2 + e] + KSLOT * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
       }
     };
-    load_group(std::integral_constant<int, 0>{});
-    // ---- first half: pending PV product (8 groups of 4 MFMA: d tile G) | P = exp2(S) in place + row sums (tile G) ----
+    load_pos(std::integral_constant<int, 0>{});
+    if constexpr (AHEAD >= 2) load_pos(std::integral_constant<int, 1>{});
+    if constexpr (AHEAD >= 3) load_pos(std::integral_constant<int, 2>{});
+    if constexpr (AHEAD >= 4) load_pos(std::integral_constant<int, 3>{});
+    // ---- F: pending PV product (8 groups of 4 MFMA: d tile G) | P = exp2(S) in place + row sums (tile G) ----
+    auto half_F = [&]() {
     static_for(std::make_integer_sequence<int, 8>{}, [&](auto gtag) {
       constexpr int G = decltype(gtag)::value;
-      load_group(std::integral_constant<int, G + 1>{});
+      constexpr int P = ROT ? G + 8 : G;
+      load_pos(std::integral_constant<int, P + AHEAD>{});
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-          oacc[G][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][b], pf[b * 2 + qt], oacc[G][qt], 0, 0, 0);
+        for (int qt = 0; qt < NQT; ++qt)
+          oacc[G][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[P % NFR][b], pf[b * NQT + qt], oacc[G][qt], 0, 0, 0);
       if constexpr (!(KNOCK & 2)) {
-        float e4[4];
+        if constexpr (NQT == 2) {   // score tile G = (b*2 + T)*2 + qt
+          float e4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e4[j] = __builtin_amdgcn_exp2f(s_cur[G][j]);
-        RF_PIN4(e4[0], e4[1], e4[2], e4[3]);
+          for (int j = 0; j < 4; ++j) e4[j] = __builtin_amdgcn_exp2f(s_cur[G][j]);
+          RF_PIN4(e4[0], e4[1], e4[2], e4[3]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s_cur[G][j] = e4[j];
-          psum[G & 1] += e4[j];
+          for (int j = 0; j < 4; ++j) {
+            s_cur[G][j] = e4[j];
+            if constexpr (!SUMG) psum[G & 1] += e4[j];
+          }
+        } else {                    // four score tiles over eight groups: half a tile each
+          float e0 = __builtin_amdgcn_exp2f(s_cur[G >> 1][(G & 1) * 2]), e1 = __builtin_amdgcn_exp2f(s_cur[G >> 1][(G & 1) * 2 + 1]);
+          asm volatile("" : "+v"(e0), "+v"(e1));
+          s_cur[G >> 1][(G & 1) * 2] = e0;
+          s_cur[G >> 1][(G & 1) * 2 + 1] = e1;
+          if constexpr (!SUMG) {
+            psum[0] += e0;   // (the summation order of the two-q-tile form: bit-identical row sums)
+            psum[0] += e1;
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    asm volatile("" : "+v"(psum[0]), "+v"(psum[1]));
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) asm volatile("" : "+v"(psum[qt]));
     if constexpr (LAG) {
       // a P above ~2^30 shows in its lane's row sum (inf included; the negated compare also catches NaN)
-      const bool hot = !(psum[0] <= p.lag_thresh) || !(psum[1] <= p.lag_thresh);
+      bool hot = false;
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) hot = hot || !(psum[qt] <= p.lag_thresh);
       if (__builtin_expect(__any(hot), 0)) {
         // ---- re-centre (rare, wave-uniform, no barrier): K(t) is still in ring slot TS --------------------------------
-        float mx[2] = {-__builtin_huge_valf(), -__builtin_huge_valf()};
-        auto raw_tile = [&](const int bt, f32x4 (&a)[2]) {   // a += K(t)[(b, T) = bt] Q^T for both q-tiles
+        float mx[NQT];
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) mx[qt] = -__builtin_huge_valf();
+        auto raw_tile = [&](const int bt, f32x4 (&a)[NQT]) {   // a += K(t)[(b, T) = bt] Q^T for the wave's q-tiles
 #pragma unroll
           for (int ds = 0; ds < 4; ++ds) {
             const bf16x8 kf = *(const bf16x8*)(k_rd[ds] + TS * 16384 + (bt >> 1) * 32 * 256 + (bt & 1) * 8 * 256);
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) a[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], a[qt], 0, 0, 0);
+            for (int qt = 0; qt < NQT; ++qt) a[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], a[qt], 0, 0, 0);
           }
         };
 #pragma unroll
         for (int bt = 0; bt < 4; ++bt) {
-          f32x4 a[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          f32x4 a[NQT];
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[qt][r] = 0.f;
           raw_tile(bt, a);
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
+          for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx[qt] = fmaxf(mx[qt], a[qt][r]);
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < NQT; ++qt) {
           float m = mx[qt];
           m = fmaxf(m, __shfl_xor(m, 16));
           m = fmaxf(m, __shfl_xor(m, 32));
@@ -977,52 +1085,65 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
         }
 #pragma unroll
         for (int bt = 0; bt < 4; ++bt) {
-          f32x4 a[2] = {negm[0], negm[1]};
+          f32x4 a[NQT];
+#pragma unroll
+          for (int qt = 0; qt < NQT; ++qt) a[qt] = negm[qt];
           raw_tile(bt, a);
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
+          for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float e = __builtin_amdgcn_exp2f(a[qt][r]);
-              s_cur[bt * 2 + qt][r] = e;
+              s_cur[bt * NQT + qt][r] = e;
               psum[qt] += e;
             }
         }
       }
     }
-    l_run[0] += psum[0];
-    l_run[1] += psum[1];
-    // ---- second half: next tile's scores (8 groups of 4 MFMA) | pack P tile G-8 into the PV operand ----------------
+    if constexpr (!SUMG) {
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) l_run[qt] += psum[qt];
+    }
+    };   // half_F
+    // ---- G: the next tile's scores (8 groups of 4 MFMA) | pack P tile G-8 into the PV operand ----------------
+    auto half_G = [&]() {
     static_for(std::make_integer_sequence<int, 8>{}, [&](auto gtag) {
       constexpr int G = decltype(gtag)::value + 8;
-      load_group(std::integral_constant<int, G + 1>{});
+      constexpr int P = ROT ? G - 8 : G;
+      load_pos(std::integral_constant<int, P + AHEAD>{});
       constexpr int bt = (G - 8) / 2;
       constexpr int dsb = ((G - 8) % 2) * 2;
       if constexpr (dsb == 0 && !LAG) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s_nxt[bt * 2 + qt][r] = 0.f;
+          for (int r = 0; r < 4; ++r) s_nxt[bt * NQT + qt][r] = 0.f;
       }
 #pragma unroll
       for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < NQT; ++qt) {
           // LAG: the chain of a score tile starts from -m (C operand = the persistent negm registers, D = the tile)
           if constexpr (LAG && dsb == 0) {
             if (e == 0) {
-              s_nxt[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][e], qf[qt][dsb + e], negm[qt], 0, 0, 0);
+              s_nxt[bt * NQT + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[P % NFR][e], qf[qt][dsb + e], negm[qt], 0, 0, 0);
               continue;
             }
           }
-          s_nxt[bt * 2 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[G & 1][e], qf[qt][dsb + e], s_nxt[bt * 2 + qt], 0, 0, 0);
+          s_nxt[bt * NQT + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[P % NFR][e], qf[qt][dsb + e], s_nxt[bt * NQT + qt], 0, 0, 0);
         }
-      if constexpr (!(KNOCK & 2)) {
-        constexpr int ti = G - 8;                       // score tile (b, T, qt) = (ti >> 2, (ti >> 1) & 1, ti & 1)
+      if constexpr (!(KNOCK & 2) && (NQT == 2 || ((G - 8) & 1) == 0)) {
+        // NQT == 2: score tile ti = G - 8 = (b*2 + T)*2 + qt; NQT == 1: tile (G - 8) / 2 = b*2 + T on the even groups
+        constexpr int ti = NQT == 2 ? G - 8 : (G - 8) / 2;
+        constexpr int bT = ti / NQT, qt_ = ti % NQT;
+        if constexpr (SUMG) {   // the row sums ride here, beside the score MFMAs (same order of additions as in F)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) psum[qt_] += s_cur[ti][j];
+        }
         uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
         uint32_t w1 = pack2(s_cur[ti][2], s_cur[ti][3]);
         asm volatile("" : "+v"(w0), "+v"(w1));
-        constexpr int pi = (ti >> 2) * 2 + (ti & 1), wi = ((ti >> 1) & 1) * 2;
+        constexpr int pi = (bT >> 1) * NQT + qt_, wi = (bT & 1) * 2;
         u32x4 t4 = __builtin_bit_cast(u32x4, pf[pi]);
         t4[wi] = w0;
         t4[wi + 1] = w1;
@@ -1031,7 +1152,27 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
       __builtin_amdgcn_sched_barrier(0);
     });
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s_cur[i] = s_nxt[i];
+    for (int i = 0; i < 4 * NQT; ++i) s_cur[i] = s_nxt[i];
+    if constexpr (SUMG) {
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) l_run[qt] += psum[qt];
+    }
+    };   // half_G
+    if constexpr (ROT) {
+      half_G();
+      stamp(2);
+      half_F();
+    } else {
+      half_F();
+      stamp(2);
+      half_G();
+    }
+    stamp(3);
+#ifdef RF_EXPERIMENTS
+    if constexpr ((KNOCK & 16) != 0)
+      if (t == 40 && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 4; ++i) g_attn_stamps[w][i] = stamps[i];
+#endif
   };
   for (int t = 0; t < nt; t += 4) {   // unrolled by the ring size (dispatch guarantees nt % 4 == 0): one exit
     tile(t, std::integral_constant<int, 0>{});
@@ -1043,6 +1184,22 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   if (PROBE) clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
   RF_ATT4_WAIT_BARRIER(0);
+  if constexpr (ROT) {   // the rotated order has not packed P(nt-1) yet
+#pragma unroll
+    for (int ti = 0; ti < 4 * NQT; ++ti) {
+      const int bT = ti / NQT, qt_ = ti % NQT;
+      if constexpr (!LAG && (KNOCK & 128) != 0) {
+        float ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ps += s_cur[ti][j];
+        l_run[qt_] += ps;   // (experiment: not the summation order of the loop)
+      }
+      u32x4 t4 = __builtin_bit_cast(u32x4, pf[(bT >> 1) * NQT + qt_]);
+      t4[(bT & 1) * 2] = pack2(s_cur[ti][0], s_cur[ti][1]);
+      t4[(bT & 1) * 2 + 1] = pack2(s_cur[ti][2], s_cur[ti][3]);
+      pf[(bT >> 1) * NQT + qt_] = __builtin_bit_cast(bf16x8, t4);
+    }
+  }
   {
     const int vslot = (nt - 1) % ATT4_RING;
 #pragma unroll
@@ -1051,9 +1208,10 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
       for (int b = 0; b < 2; ++b) {
         const bf16x8 vf = *(const bf16x8*)(v_rd[b] + vslot * 16384 + dt * 16 * 128);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * 2 + qt], oacc[dt][qt], 0, 0, 0);
+        for (int qt = 0; qt < NQT; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * NQT + qt], oacc[dt][qt], 0, 0, 0);
       }
   }
+  if constexpr (NQT == 2)   // (the mixed-size launch never splits the key axis)
   if (partial != nullptr) {
     float* dst = partial + tid * 4;
 #pragma unroll
@@ -1066,7 +1224,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     partial[16 * 2048 + 1536 + tid] = -negm[1][0];
     return;
   }
-  attn5_finish(p, oacc, l_run, lane, w, head, qb);
+  attn5_finish<NQT, (KNOCK & 8) != 0>(p, oacc, l_run, lane, head, q0w);
 }
 
 template <bool LAG>
@@ -1077,12 +1235,95 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  attn5_body<true, LAG>(p, smem, tid, lane, w, blockIdx.x % p.heads, blockIdx.x / p.heads, 0, p.S / ATT_KV, nullptr, clk);
+  // waves w and w + 4 share a SIMD: the second one runs the halves of an interval in the rotated order, so that one of the pair is in
+  // its exp2-heavy half while the other is in its MFMA-only half (see attn5_body)
+  const int head = blockIdx.x % p.heads, q0w = (int)(blockIdx.x / p.heads) * 256 + w * 32;
+  if (w < 4) attn5_body<true, LAG, 0, 2, false>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
+  else attn5_body<false, LAG, 0, 2, true>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
 }
 
 #ifdef RF_EXPERIMENTS
 #include "experiments/attention_exp.inc"
 #endif
+
+// Mixed-size launch.  heads x S / 256 workgroups of 256 queries rarely come out as whole rounds of the 256 CUs (S = 4608: 432 =
+// 1.69 rounds run as 2; the split launch above fixes that at the price of ~70 MB of partial (O, l) through HBM and a second
+// launch: break-even at 84 % fill).  This launch changes the SIZE of some workgroups instead: `n_big` workgroups of 256 queries
+// (dispatched first) and the rest of 192 -- waves 0-3 carry two q-tiles as everywhere, waves 4-7 ONE (waves w and w + 4 share a
+// SIMD, so every SIMD does 3/4 of the MFMAs of a full workgroup; K / V^T tiles, DMA pieces and barriers are those of the full
+// one).  S = 4608: per head 9 x 256 + 12 x 192 queries -> 216 + 288 workgroups; a CU runs a big and a small one or two small
+// ones: 16 + 12 = 28 q-tile units instead of 2 x 16 = 32.  Nothing is split along the key axis: no scratch, no second launch,
+// and every output row is computed by exactly the code of the plain launch (bit-identical results).
+struct AttnMixParams {
+  int n_big;          // workgroups of 256 queries = heads * big_per_head
+  int big_per_head;
+};
+
+template <bool LAG>
+__global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p, const AttnMixParams mx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ClkProbe clk;
+  clk.begin();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x;
+  // (n_big % 8 == 0 when heads % 8 == 0: workgroup b of either kind runs on XCD b % 8 = head % 8, as in the plain launch)
+  const bool big = b < mx.n_big;
+  const int b2 = big ? b : b - mx.n_big;
+  const int head = b2 % p.heads;
+  const int q0 = big ? (b2 / p.heads) * 256 : mx.big_per_head * 256 + (b2 / p.heads) * 192;
+  if (w < 4) attn5_body<true, LAG, 0, 2, false>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+  else if (big) attn5_body<false, LAG, 0, 2, true>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+  else attn5_body<false, LAG, 0, 1, true>(p, smem, tid, lane, w, head, q0 + 128 + (w - 4) * 16, 0, p.S / ATT_KV, nullptr, clk);
+}
+
+// Sizes of the mixed launch for `units` = S / 16 q-tiles per head: units = 16 a + 12 b.  Greedy in-order dispatch of the a * heads
+// big workgroups, then the b * heads small ones, onto P CUs, with a small workgroup costing `small_cost` of a big one (measured
+// 0.75-0.8); returns the makespan in big-workgroup units and the best (a, b), or a = units / 16, b = 0 if nothing beats the
+// plain launch.
+constexpr float ATT5_SMALL_COST = 0.9f;   // a 192-query workgroup's time / a 256-query one's: the MFMAs are 3/4, but a tile takes as long as
+                                          // its slowest wave (S = 4608: 216 -> 206 us = 1.9 instead of 2 rounds; profiles/r03_kb_attn_mix_v1.log)
+static float attn_mix_plan(const int units, const int heads, const int P, const float small_cost, int* a_out, int* b_out) {
+  float best = 1e30f;
+  int best_a = units / 16, best_b = 0;
+  std::vector<float> cu((size_t)P);
+  for (int b = 0; 12 * b <= units; b += 4) {
+    if ((units - 12 * b) % 16 != 0) continue;
+    const int a = (units - 12 * b) / 16;
+    // in-order dispatch = always to the CU that frees first: a min-heap over P finish times
+    std::fill(cu.begin(), cu.end(), 0.f);
+    auto cmp = [](float x, float y) { return x > y; };
+    std::make_heap(cu.begin(), cu.end(), cmp);
+    auto push = [&](const int n, const float cost) {
+      for (int i = 0; i < n; ++i) {
+        std::pop_heap(cu.begin(), cu.end(), cmp);
+        cu.back() += cost;
+        std::push_heap(cu.begin(), cu.end(), cmp);
+      }
+    };
+    push(a * heads, 1.f);
+    push(b * heads, small_cost);
+    const float span = *std::max_element(cu.begin(), cu.end());
+    if (span < best - 1e-4f) { best = span; best_a = a; best_b = b; }
+  }
+  *a_out = best_a;
+  *b_out = best_b;
+  return best;
+}
+// the plan of the last (S, heads, P) of this thread (the simulation costs ~50 us of host time: not per launch)
+static float attn_mix_plan_cached(const int units, const int heads, const int P, int* a_out, int* b_out) {
+  thread_local int key[3] = {0, 0, 0}, ab[2] = {0, 0};
+  thread_local float span = 0.f;
+  if (key[0] != units || key[1] != heads || key[2] != P) {
+    span = attn_mix_plan(units, heads, P, ATT5_SMALL_COST, &ab[0], &ab[1]);
+    key[0] = units; key[1] = heads; key[2] = P;
+  }
+  *a_out = ab[0];
+  *b_out = ab[1];
+  return span;
+}
+
 
 // Split launch (rf_attention_fwd_ws with scratch): 432 workgroups at S = 4608 are 1.69 rounds of 256 CUs run as 2, 528 at
 // S = 5632 are 2.06 run as 3.  One persistent workgroup per CU takes an equal share of the (block, 4-tile quad) space
@@ -1122,7 +1363,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5sk(const AttnParams p, 
     // across the loop and spill)
     int tid_i = tid;
     asm volatile("" : "+v"(tid_i));
-    attn5_body<false, LAG>(p, smem, tid_i, tid_i & 63, w, head, qb, 4 * q0, 4 * len, partial, clk);
+    if (w < 4) attn5_body<false, LAG, 0, 2, false>(p, smem, tid_i, tid_i & 63, w, head, qb * 256 + w * 32, 4 * q0, 4 * len, partial, clk);
+    else attn5_body<false, LAG, 0, 2, true>(p, smem, tid_i, tid_i & 63, w, head, qb * 256 + w * 32, 4 * q0, 4 * len, partial, clk);
     cur += len;
   }
 }
@@ -1170,7 +1412,7 @@ __global__ __launch_bounds__(512) void attn5_combine_kernel(const AttnParams p, 
     l_run[0] += src[16 * 2048 + tid] * f[0];
     l_run[1] += src[16 * 2048 + 512 + tid] * f[1];
   }
-  attn5_finish(p, oacc, l_run, lane, w, head, qb);
+  attn5_finish<2>(p, oacc, l_run, lane, head, qb * 256 + w * 32);
 }
 
 int read_clk_probe_attn(unsigned long long* h) {
@@ -1191,17 +1433,19 @@ struct AttnTuning {
   int knock;   // experiments: timing knock-outs
   int sk;      // split launch: -1 = heuristic, 0 = never, 1 = whenever possible
   int lag;     // -1 = lagged-max kernel only without a usable bound, 0 = never, 1 = always
+  int mix;     // mixed-size launch: -1 = when the dispatch simulation predicts >= 4 %, 0 = never
 };
 #ifdef RF_EXPERIMENTS
-static AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1};
+static AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1};
 #else
-static constexpr AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1};
+static constexpr AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1};
 #endif
 static int g_last_attn_path = 0;
 
 }  // namespace rf
 
-// read-only introspection: 1 / 2 / 4 / 5 = kernel version, 6 = v5 split launch, 8 = v5 lagged-max, 9 = its split launch (7 = v6, experiments)
+// read-only introspection: 1 / 2 / 4 / 5 = kernel version, 6 = v5 split launch, 8 = v5 lagged-max, 9 = its split launch, 10 / 11 = the
+// mixed-size launch of the bounded / lagged-max kernel (7 = v6, experiments)
 extern "C" int rf_debug_last_attn_path(void) { return rf::g_last_attn_path; }
 
 #ifdef RF_EXPERIMENTS
@@ -1212,6 +1456,10 @@ extern "C" int rf_debug_attn_v6(int on) { rf::g_at.v6 = on ? 1 : 0; return RF_OK
 extern "C" int rf_debug_attn_knock(int k) { rf::g_at.knock = k; return RF_OK; }
 extern "C" int rf_debug_attn_sk(int mode) { rf::g_at.sk = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
 extern "C" int rf_debug_attn_lag(int mode) { rf::g_at.lag = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
+extern "C" int rf_debug_attn_mix(int mode) { rf::g_at.mix = mode < 0 ? -1 : 0; return RF_OK; }
+extern "C" int rf_debug_attn_stamps(unsigned long long* out64) {   // [8 waves][8]
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(rf::g_attn_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
+}
 #endif
 
 extern "C" int64_t rf_attention_ws_bytes(void) {
@@ -1269,11 +1517,25 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
 #ifdef RF_EXPERIMENTS
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v6, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<12>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<20>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<80>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<68>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<96>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<36>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
 #endif
     attr_set = true;
   }
@@ -1328,18 +1590,33 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       // run as 3, 69 %) 399 -> 328 us; S = 4608 (1.69 as 2, 84 %) break-even -- the part is power-limited, idle CUs in the
       // last round let the busy ones clock higher; S = 17920 (6.56 as 7, 94 %) 8 % slower.
       const int blocks = heads * (S / 256), rounds = cdiv(blocks, P);
-      const bool split = use5 && can_split && g_at.sk != 0 && (g_at.sk == 1 || (double)blocks / ((double)rounds * P) < 0.80);
-      kern = !use5 ? RF_ATTN_BOUNDED32 : lag ? (split ? RF_ATTN_LAGGED16_SPLIT : RF_ATTN_LAGGED16)
-                                             : (split ? RF_ATTN_BOUNDED16_SPLIT : RF_ATTN_BOUNDED16);
+      // mixed-size launch first: no scratch, no second launch, bit-identical rows.  Taken when the simulated dispatch beats the
+      // plain grid's rounds by >= 4 % (S = 4608: 1.9 vs 2 -> 216 -> 206 us; S = 5632: 2.7 vs 3 -> 392 -> 325 us, the split
+      // launch's 321-325 us without its scratch traffic; S = 17920: 6.9 vs 7 measured 1-4 % SLOWER, not taken)
+      bool mix = false;
+      if (use5 && g_at.sk != 1 && g_at.mix != 0) {
+        int a = 0, b = 0;
+        const float span = attn_mix_plan_cached(S / 16, heads, P, &a, &b);
+        mix = b > 0 && span <= 0.96f * (float)rounds;
+      }
+      const bool split = !mix && use5 && can_split && g_at.sk != 0 && (g_at.sk == 1 || (double)blocks / ((double)rounds * P) < 0.80);
+      kern = !use5 ? RF_ATTN_BOUNDED32
+             : mix ? (lag ? RF_ATTN_LAGGED16_MIX : RF_ATTN_BOUNDED16_MIX)
+             : lag ? (split ? RF_ATTN_LAGGED16_SPLIT : RF_ATTN_LAGGED16)
+                   : (split ? RF_ATTN_BOUNDED16_SPLIT : RF_ATTN_BOUNDED16);
     }
   } else {
     // an explicit request must be runnable as asked: fail loudly instead of substituting another kernel
     const bool want_fast = kern == RF_ATTN_BOUNDED32 || kern == RF_ATTN_BOUNDED16 || kern == RF_ATTN_BOUNDED16_SPLIT ||
-                           kern == RF_ATTN_LAGGED16 || kern == RF_ATTN_LAGGED16_SPLIT;
+                           kern == RF_ATTN_LAGGED16 || kern == RF_ATTN_LAGGED16_SPLIT || kern == RF_ATTN_BOUNDED16_MIX ||
+                           kern == RF_ATTN_LAGGED16_MIX;
     RF_REQUIRE(kern == RF_ATTN_ONLINE128 || kern == RF_ATTN_ONLINE256 || want_fast, RF_ERR_SHAPE, "rf_attention: kernel=%d", kern);
     if (want_fast) RF_REQUIRE(fast_ok, RF_ERR_UNSUPPORTED, "rf_attention: kernel %d needs mode 0, S %% 256 == 0 and a prescaled q", kern);
-    if (kern == RF_ATTN_BOUNDED32 || kern == RF_ATTN_BOUNDED16 || kern == RF_ATTN_BOUNDED16_SPLIT)
+    if (kern == RF_ATTN_BOUNDED32 || kern == RF_ATTN_BOUNDED16 || kern == RF_ATTN_BOUNDED16_SPLIT || kern == RF_ATTN_BOUNDED16_MIX)
       RF_REQUIRE(bound_ok, RF_ERR_UNSUPPORTED, "rf_attention: kernel %d needs 0 < score_bound <= 100 (got %g)", kern, (double)d->score_bound);
+    if (kern == RF_ATTN_BOUNDED16_MIX || kern == RF_ATTN_LAGGED16_MIX)
+      RF_REQUIRE(d->mix_small >= 0 && d->mix_small % 4 == 0 && 12 * d->mix_small <= S / 16, RF_ERR_SHAPE,
+                 "rf_attention: mix_small=%d must be a multiple of 4 with 12 * mix_small <= S / 16", d->mix_small);
     if (kern == RF_ATTN_BOUNDED16_SPLIT || kern == RF_ATTN_LAGGED16_SPLIT)
       RF_REQUIRE(can_split, RF_ERR_WORKSPACE, "rf_attention: the split launch needs heads %% 8 == 0 and %lld bytes of 16-byte aligned scratch",
                  (long long)((int64_t)2 * P * ATT5_SLOT * 4));
@@ -1361,6 +1638,21 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       hipLaunchKernelGGL(attn_fwd_kernel_v5<true>, grid2, blk, ATT4_LDS, st, p);
       g_last_attn_path = 8;
       break;
+    case RF_ATTN_BOUNDED16_MIX:
+    case RF_ATTN_LAGGED16_MIX: {
+      // (an explicit request runs the best mixed plan even if it is the plain grid: a = S / 256, b = 0)
+      int a = 0, b = d->mix_small;
+      if (b == 0) attn_mix_plan_cached(S / 16, heads, P, &a, &b);
+      else a = (S / 16 - 12 * b) / 16;
+      AttnMixParams mx;
+      mx.n_big = a * heads;
+      mx.big_per_head = a;
+      const dim3 gridm((a + b) * heads);
+      if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v5mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
+      else hipLaunchKernelGGL(attn_fwd_kernel_v5mix<false>, gridm, blk, ATT4_LDS, st, p, mx);
+      g_last_attn_path = kern == RF_ATTN_LAGGED16_MIX ? 11 : 10;
+      break;
+    }
     case RF_ATTN_BOUNDED16:
 #ifdef RF_EXPERIMENTS
       if (g_at.v6 && !g_at.knock) {
@@ -1371,6 +1663,18 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       if (g_at.knock) {
         if (g_at.knock == 1) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 4) hipLaunchKernelGGL(attn_fwd_kernel_v5k<4>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 8) hipLaunchKernelGGL(attn_fwd_kernel_v5k<8>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 12) hipLaunchKernelGGL(attn_fwd_kernel_v5k<12>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 16) hipLaunchKernelGGL(attn_fwd_kernel_v5k<16>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 20) hipLaunchKernelGGL(attn_fwd_kernel_v5k<20>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 32) hipLaunchKernelGGL(attn_fwd_kernel_v5k<32>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 64) hipLaunchKernelGGL(attn_fwd_kernel_v5k<64>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 80) hipLaunchKernelGGL(attn_fwd_kernel_v5k<80>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 68) hipLaunchKernelGGL(attn_fwd_kernel_v5k<68>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 100) hipLaunchKernelGGL(attn_fwd_kernel_v5k<100>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 96) hipLaunchKernelGGL(attn_fwd_kernel_v5k<96>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 36) hipLaunchKernelGGL(attn_fwd_kernel_v5k<36>, grid2, blk, ATT4_LDS, st, p);
         else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;
         break;

@@ -335,7 +335,7 @@ def qk_score_bound(*norm_weights_qk) -> float:
 
 def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
               cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False,
-              score_bound: float = 0.0, scratch: bool = True, kernel: Optional[int] = None,
+              score_bound: float = 0.0, scratch: bool = True, kernel: Optional[int] = None, mix_small: int = 0,
               lag_thresh: float = 0.0) -> torch.Tensor:
     """scratch=True attaches the per-(device, stream) scratch that lets the library split a poorly filling grid
     (rf_attention_fwd_ws); scratch=False is rf_attention_fwd.  kernel: rf_attn_kernel for THIS launch (an unrunnable
@@ -356,6 +356,7 @@ def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Opti
     d.heads, d.S, d.s_pad, d.n_main, d.ldo = heads, S, s_pad, S if n_main is None else n_main, out.stride(0)
     d.mode, d.q_prescaled, d.cross_bias, d.scale = mode, 1 if q_prescaled else 0, cross_bias, scale
     d.score_bound, d.lag_thresh, d.kernel = float(score_bound), float(lag_thresh), _ATTN_KERNEL.get() if kernel is None else kernel
+    d.mix_small = int(mix_small)
     d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4 if ws is not None else 0
     L.check(lib.rf_attention(C.byref(d), stream_ptr()), "rf_attention")
     return out

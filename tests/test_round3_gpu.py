@@ -58,13 +58,18 @@ def test_lagged_max_matches_fp64_and_the_other_kernels(dev, S, H):
     o = {}
     can_split = H % 8 == 0 and (H // 8) * (S // 256) ** 2 >= 64       # >= 2 key quads per persistent workgroup of an XCD
     kernels = [("lag", L.RF_ATTN_LAGGED16, 8), ("lag again", L.RF_ATTN_LAGGED16, 8), ("bounded", L.RF_ATTN_BOUNDED16, 5), ("online", L.RF_ATTN_ONLINE256, 2)]
+    # the mixed-size launch (workgroups of 256 and 192 queries; waves 4-7 of the small ones carry ONE q-tile): same rows, same code
+    kernels += [("lag mix", L.RF_ATTN_LAGGED16_MIX, 11), ("bounded mix", L.RF_ATTN_BOUNDED16_MIX, 10)]
     if can_split:
         kernels += [("lag split", L.RF_ATTN_LAGGED16_SPLIT, 9), ("lag split again", L.RF_ATTN_LAGGED16_SPLIT, 9)]
     else:
         with pytest.raises(ops.RFError):       # an unrunnable request fails loudly
             ops.attention(q, k, vt, S, q_prescaled=True, kernel=L.RF_ATTN_LAGGED16_SPLIT)
+    with pytest.raises(ops.RFError):
+        ops.attention(q, k, vt, S, q_prescaled=True, kernel=L.RF_ATTN_LAGGED16_MIX, mix_small=S // 16)      # more q-tiles than the head has
+    ms = 4 * min(3, S // 768)                 # 192-query workgroups per head, forced (the library's own plan needs > 256 workgroups)
     for name, kern, path in kernels:
-        o[name] = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=60.0, kernel=kern)
+        o[name] = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=60.0, kernel=kern, mix_small=ms if "mix" in name else 0)
         assert lib.rf_debug_last_attn_path() == path, (name, lib.rf_debug_last_attn_path())
     # AUTO without a bound -> the lagged-max kernel (plain or split by the fill heuristic), never the online-softmax ones
     ops.attention(q, k, vt, S, q_prescaled=True, score_bound=0.0)
@@ -74,6 +79,7 @@ def test_lagged_max_matches_fp64_and_the_other_kernels(dev, S, H):
     for name, t in o.items():
         assert_close(t, ref, f"attention {name} S={S}", atol=2e-3)
     assert torch.equal(o["lag"], o["lag again"]), "not bit-stable"
+    assert torch.equal(o["lag mix"], o["lag"]) and torch.equal(o["bounded mix"], o["bounded"]), "mixed-size launch differs from the plain one"
     if can_split:
         assert torch.equal(o["lag split"], o["lag split again"]), "split launch not bit-stable"
     e = {n: rel_l2(t, ref) for n, t in o.items()}
@@ -81,7 +87,7 @@ def test_lagged_max_matches_fp64_and_the_other_kernels(dev, S, H):
     assert all(v <= 1.3 * e["online"] + 1e-4 for n, v in e.items() if n.startswith("lag"))
 
 
-@pytest.mark.parametrize("kern_name", ["LAGGED16", "LAGGED16_SPLIT"])
+@pytest.mark.parametrize("kern_name", ["LAGGED16", "LAGGED16_SPLIT", "LAGGED16_MIX"])
 def test_lagged_max_forced_recentring(dev, kern_name):
     """Spike one key row against chosen query rows: raw scores of +180 / +400 / +3000 (exp2 domain) appear at key tiles 0,
     5, 37 and at the last tile -- far outside the bounded kernel's contract, P = exp2(s - m_old) overflows to inf -- while
@@ -108,8 +114,9 @@ def test_lagged_max_forced_recentring(dev, kern_name):
     q[:, :S], k[:, :S] = qp, kf
     ref = softmax_ref64(qp, kf, vf)
     kern = getattr(L, "RF_ATTN_" + kern_name)
-    o = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=0.0, kernel=kern)
-    o2 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=0.0, kernel=kern)
+    ms = 12 if kern_name.endswith("MIX") else 0          # 9 x 256 + 12 x 192 queries per head: rows 2304.. are in small workgroups
+    o = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=0.0, kernel=kern, mix_small=ms)
+    o2 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=0.0, kernel=kern, mix_small=ms)
     on = ops.attention(q, k, vt, S, q_prescaled=True, kernel=L.RF_ATTN_ONLINE256)
     assert torch.isfinite(o.float()).all()
     assert_close(o, ref, f"lagged-max with spikes ({kern_name})", atol=3e-3)
