@@ -813,11 +813,13 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
                                            const int head, const int q0w, const int t0, const int nt, float* partial, ClkProbe& clk) {
   const int l15 = lane & 15, g = lane >> 4;
   const int S = p.S;
+  constexpr int PRIO = (KNOCK >> 7) & 7;
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
   const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
   const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
   char* const kring = smem;
   char* const vring = smem + ATT4_RING * 16384;
+  if constexpr (PRIO == 4) __builtin_amdgcn_s_setprio(ROT ? 1 : 0);
 
   // Q B-operand fragments: [q-tile][d step of 32]: lane -> query qt*16 + l15, d = 32 ds + 8g .. +8
   bf16x8 qf[NQT][4];
@@ -967,10 +969,21 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     __builtin_amdgcn_sched_barrier(0);
     constexpr int AHEAD = (KNOCK & 36) == 36 ? 4 : (KNOCK & 32) ? 3 : (KNOCK & 4) ? 1 : 2;   // fragment reads run AHEAD groups in front of their MFMAs (2: -2.3 % vs 1, profiles/r03_kb_attn_mix_v1.log)
     constexpr int NFR = AHEAD + 1;
+    // (experiments) s_setprio schemes, PRIO = (KNOCK >> 7) & 7.  The SIMD's arbiter favours the OLDER wave of a pair whenever both
+    // have an MFMA ready (tools/ubench/attn_group.py: wave 0 runs at its solo speed, its partner gets the gaps); the schemes shift
+    // that: 1: F = 2, G = 0   2: F = 0, G = 2   3: plain waves F = 0, G = 2, rotated waves G = 2, F = 1   4: rotated waves 1, plain 0
+    // 5: alternating per group, opposite phase in the rotated waves   6: plain F = 1, G = 2, rotated G = 2, F = 0
+    auto prio_F = [&]() {
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(2);
+      if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+      if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(ROT ? 1 : 0);
+      if constexpr (PRIO == 6) __builtin_amdgcn_s_setprio(ROT ? 0 : 1);
+    };
+    auto prio_G = [&]() {
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+      if constexpr (PRIO == 2 || PRIO == 3 || PRIO == 6) __builtin_amdgcn_s_setprio(2);
+    };
     bf16x8 fr[NFR][2];   // fragment ring: group G multiplies fr[G % NFR][0..1]
-    // SUMG: the row sums of P(t) are formed in G (beside the MFMA-only score groups) instead of F (beside exp2).  Not for LAG,
-    // whose overflow test needs them before P(t) is packed.
-    constexpr bool SUMG = !LAG && (KNOCK & 128) != 0;
     float psum[NQT];
 #pragma unroll
     for (int qt = 0; qt < NQT; ++qt) psum[qt] = 0.f;
@@ -1000,9 +1013,11 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     if constexpr (AHEAD >= 4) load_pos(std::integral_constant<int, 3>{});
     // ---- F: pending PV product (8 groups of 4 MFMA: d tile G) | P = exp2(S) in place + row sums (tile G) ----
     auto half_F = [&]() {
+    prio_F();
     static_for(std::make_integer_sequence<int, 8>{}, [&](auto gtag) {
       constexpr int G = decltype(gtag)::value;
       constexpr int P = ROT ? G + 8 : G;
+      if constexpr (PRIO == 5) __builtin_amdgcn_s_setprio(((G & 1) != 0) == ROT ? 2 : 0);
       load_pos(std::integral_constant<int, P + AHEAD>{});
 #pragma unroll
       for (int b = 0; b < 2; ++b)
@@ -1018,17 +1033,15 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             s_cur[G][j] = e4[j];
-            if constexpr (!SUMG) psum[G & 1] += e4[j];
+            psum[G & 1] += e4[j];
           }
         } else {                    // four score tiles over eight groups: half a tile each
           float e0 = __builtin_amdgcn_exp2f(s_cur[G >> 1][(G & 1) * 2]), e1 = __builtin_amdgcn_exp2f(s_cur[G >> 1][(G & 1) * 2 + 1]);
           asm volatile("" : "+v"(e0), "+v"(e1));
           s_cur[G >> 1][(G & 1) * 2] = e0;
           s_cur[G >> 1][(G & 1) * 2 + 1] = e1;
-          if constexpr (!SUMG) {
-            psum[0] += e0;   // (the summation order of the two-q-tile form: bit-identical row sums)
-            psum[0] += e1;
-          }
+          psum[0] += e0;   // (the summation order of the two-q-tile form: bit-identical row sums)
+          psum[0] += e1;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1100,16 +1113,16 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
         }
       }
     }
-    if constexpr (!SUMG) {
 #pragma unroll
-      for (int qt = 0; qt < NQT; ++qt) l_run[qt] += psum[qt];
-    }
+    for (int qt = 0; qt < NQT; ++qt) l_run[qt] += psum[qt];
     };   // half_F
     // ---- G: the next tile's scores (8 groups of 4 MFMA) | pack P tile G-8 into the PV operand ----------------
     auto half_G = [&]() {
+    prio_G();
     static_for(std::make_integer_sequence<int, 8>{}, [&](auto gtag) {
       constexpr int G = decltype(gtag)::value + 8;
       constexpr int P = ROT ? G - 8 : G;
+      if constexpr (PRIO == 5) __builtin_amdgcn_s_setprio(((G & 1) != 0) == ROT ? 2 : 0);
       load_pos(std::integral_constant<int, P + AHEAD>{});
       constexpr int bt = (G - 8) / 2;
       constexpr int dsb = ((G - 8) % 2) * 2;
@@ -1136,10 +1149,6 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
         // NQT == 2: score tile ti = G - 8 = (b*2 + T)*2 + qt; NQT == 1: tile (G - 8) / 2 = b*2 + T on the even groups
         constexpr int ti = NQT == 2 ? G - 8 : (G - 8) / 2;
         constexpr int bT = ti / NQT, qt_ = ti % NQT;
-        if constexpr (SUMG) {   // the row sums ride here, beside the score MFMAs (same order of additions as in F)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) psum[qt_] += s_cur[ti][j];
-        }
         uint32_t w0 = pack2(s_cur[ti][0], s_cur[ti][1]);
         uint32_t w1 = pack2(s_cur[ti][2], s_cur[ti][3]);
         asm volatile("" : "+v"(w0), "+v"(w1));
@@ -1153,10 +1162,6 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     });
 #pragma unroll
     for (int i = 0; i < 4 * NQT; ++i) s_cur[i] = s_nxt[i];
-    if constexpr (SUMG) {
-#pragma unroll
-      for (int qt = 0; qt < NQT; ++qt) l_run[qt] += psum[qt];
-    }
     };   // half_G
     if constexpr (ROT) {
       half_G();
@@ -1180,6 +1185,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     tile(t + 2, std::integral_constant<int, 2>{});
     tile(t + 3, std::integral_constant<int, 3>{});
   }
+  if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
 
   if (PROBE) clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
@@ -1188,12 +1194,6 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
     for (int ti = 0; ti < 4 * NQT; ++ti) {
       const int bT = ti / NQT, qt_ = ti % NQT;
-      if constexpr (!LAG && (KNOCK & 128) != 0) {
-        float ps = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ps += s_cur[ti][j];
-        l_run[qt_] += ps;   // (experiment: not the summation order of the loop)
-      }
       u32x4 t4 = __builtin_bit_cast(u32x4, pf[(bT >> 1) * NQT + qt_]);
       t4[(bT & 1) * 2] = pack2(s_cur[ti][0], s_cur[ti][1]);
       t4[(bT & 1) * 2 + 1] = pack2(s_cur[ti][2], s_cur[ti][3]);
@@ -1523,19 +1523,22 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v6, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<12>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<20>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<80>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<68>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<100>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<96>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<36>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<256>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<384>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<512>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<640>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<768>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<144>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<272>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<400>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
 #endif
     attr_set = true;
   }
@@ -1665,16 +1668,19 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
         else if (g_at.knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 4) hipLaunchKernelGGL(attn_fwd_kernel_v5k<4>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 8) hipLaunchKernelGGL(attn_fwd_kernel_v5k<8>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 12) hipLaunchKernelGGL(attn_fwd_kernel_v5k<12>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 16) hipLaunchKernelGGL(attn_fwd_kernel_v5k<16>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 20) hipLaunchKernelGGL(attn_fwd_kernel_v5k<20>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 32) hipLaunchKernelGGL(attn_fwd_kernel_v5k<32>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 64) hipLaunchKernelGGL(attn_fwd_kernel_v5k<64>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 80) hipLaunchKernelGGL(attn_fwd_kernel_v5k<80>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 68) hipLaunchKernelGGL(attn_fwd_kernel_v5k<68>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 100) hipLaunchKernelGGL(attn_fwd_kernel_v5k<100>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 96) hipLaunchKernelGGL(attn_fwd_kernel_v5k<96>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 36) hipLaunchKernelGGL(attn_fwd_kernel_v5k<36>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 128) hipLaunchKernelGGL(attn_fwd_kernel_v5k<128>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 256) hipLaunchKernelGGL(attn_fwd_kernel_v5k<256>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 384) hipLaunchKernelGGL(attn_fwd_kernel_v5k<384>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 512) hipLaunchKernelGGL(attn_fwd_kernel_v5k<512>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 640) hipLaunchKernelGGL(attn_fwd_kernel_v5k<640>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 768) hipLaunchKernelGGL(attn_fwd_kernel_v5k<768>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 144) hipLaunchKernelGGL(attn_fwd_kernel_v5k<144>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 272) hipLaunchKernelGGL(attn_fwd_kernel_v5k<272>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 400) hipLaunchKernelGGL(attn_fwd_kernel_v5k<400>, grid2, blk, ATT4_LDS, st, p);
         else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;
         break;
