@@ -165,6 +165,70 @@ def vae_table(dev, res):
     return out
 
 
+def synthetic_t5_xxl_state(dev, layers=24, d_model=4096, heads=64, d_ff=10240, vocab=32128, seed=0):
+    """T5-v1.1-XXL-shaped encoder weights (4.7 B parameters), drawn on the device in bf16 (transformers key names)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    bf = torch.bfloat16
+    r = lambda *shape, sc=1.0: (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * sc).to(bf)  # noqa: E731
+    inner = 64 * heads
+    sd = {"shared.weight": r(vocab, d_model), "encoder.final_layer_norm.weight": torch.ones(d_model, device=dev, dtype=bf),
+          "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": r(32, heads)}
+    s = d_model ** -0.5
+    for i in range(layers):
+        p = f"encoder.block.{i}.layer."
+        for x in "qk":
+            sd[p + f"0.SelfAttention.{x}.weight"] = r(inner, d_model, sc=s * 0.7)
+        sd[p + "0.SelfAttention.v.weight"] = r(inner, d_model, sc=s)
+        sd[p + "0.SelfAttention.o.weight"] = r(d_model, inner, sc=inner ** -0.5)
+        sd[p + "0.layer_norm.weight"] = torch.ones(d_model, device=dev, dtype=bf)
+        sd[p + "1.DenseReluDense.wi_0.weight"] = r(d_ff, d_model, sc=s)
+        sd[p + "1.DenseReluDense.wi_1.weight"] = r(d_ff, d_model, sc=s)
+        sd[p + "1.DenseReluDense.wo.weight"] = r(d_model, d_ff, sc=d_ff ** -0.5)
+        sd[p + "1.layer_norm.weight"] = torch.ones(d_model, device=dev, dtype=bf)
+    return sd
+
+
+def text_table(dev):
+    """the two encoder calls FluxPipeline.encode_prompt makes per prompt (per candidate and round in the reflection
+    loop), on the HIP path: T5-v1.1-XXL shape at 512 tokens (24 layers, 4.7 B parameters) and CLIP-L shape at 77 tokens, random-init."""
+    from reflectionflow_amd.flux.text_hip import HipClipTextEncoder, HipT5Encoder
+    bf = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(1)
+    r = lambda *shape, sc=1.0: (torch.randn(*shape, generator=g, device=dev, dtype=torch.float32) * sc).to(bf)  # noqa: E731
+    t5 = HipT5Encoder(synthetic_t5_xxl_state(dev), 64, dev)
+    D, F, V = 768, 3072, 49408
+    csd = {"embeddings.token_embedding.weight": r(V, D, sc=0.02), "embeddings.position_embedding.weight": r(77, D, sc=0.01),
+           "final_layer_norm.weight": torch.ones(D, device=dev, dtype=bf), "final_layer_norm.bias": torch.zeros(D, device=dev, dtype=bf)}
+    for i in range(12):
+        p = f"encoder.layers.{i}."
+        for x in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            csd[p + f"self_attn.{x}.weight"], csd[p + f"self_attn.{x}.bias"] = r(D, D, sc=D ** -0.5), r(D, sc=0.02)
+        for n in ("layer_norm1", "layer_norm2"):
+            csd[p + n + ".weight"], csd[p + n + ".bias"] = torch.ones(D, device=dev, dtype=bf), torch.zeros(D, device=dev, dtype=bf)
+        csd[p + "mlp.fc1.weight"], csd[p + "mlp.fc1.bias"] = r(F, D, sc=D ** -0.5), r(F, sc=0.02)
+        csd[p + "mlp.fc2.weight"], csd[p + "mlp.fc2.bias"] = r(D, F, sc=F ** -0.5), r(D, sc=0.02)
+    clip = HipClipTextEncoder(csd, 12, dev)
+    t5_ids = torch.randint(0, 32128, (1, 512), device=dev)
+    clip_ids = torch.randint(0, 49406, (1, 77), device=dev)
+    clip_ids[0, 20:] = 49407
+    out = {"path": "HIP (librf_flux.so rf_t5_encode / rf_clip_text_encode): projections = launches of the bf16 MFMA GEMM, attention = one kernel "
+                   "with K and V^T of a head resident in LDS"}
+    for name, fn in (("t5_xxl_512_tokens_ms", lambda: t5.encode(t5_ids)), ("clip_l_77_tokens_ms", lambda: clip.encode(clip_ids))):
+        fn(); fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / 10 * 1e3, 2)
+    out["t5_weight_bytes_gb"] = 9.4
+    out["t5_tflops"] = round(2 * 512 * (24 * (4 * 4096 * 4096 + 3 * 4096 * 10240)) / (out["t5_xxl_512_tokens_ms"] * 1e-3) / 1e12, 1)
+    out["frac_of_a_candidate"] = round((out["t5_xxl_512_tokens_ms"] + out["clip_l_77_tokens_ms"]) / 1e3 / 3.1, 4)
+    del t5, clip, csd
+    torch.cuda.empty_cache()
+    return out
+
+
 def attention_table(dev, pipe, S, heads):
     """Which attention kernel the timed run used and what the alternatives cost (VERDICT r2 / ADVICE r2: the headline must
     carry its floor).  The engine hands the bounded-score kernel the bound it derives from the checkpoint's norm_q / norm_k
@@ -454,6 +518,7 @@ def main():
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (plumbing check, not a scaling measurement)")
     ap.add_argument("--no-attention-table", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (separately reported) VAE decode / encode timings")
+    ap.add_argument("--no-text", action="store_true", help="skip the (separately reported) T5-XXL / CLIP-L text-encoder timings")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay of each candidate's denoise loop (RF_DENOISE_GRAPH=1; the default for T >= 16)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (RF_DENOISE_GRAPH=0)")
     args = ap.parse_args()
@@ -580,6 +645,8 @@ def main():
                 res["attention"] = attention_table(dev, pipe, S_txt + S_img, heads)
             if not args.no_vae:
                 res["vae"] = vae_table(dev, args.res)
+            if not args.no_text:
+                res["text_encoders"] = text_table(dev)
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(S_txt, S_img, T, D, heads, nd, ns)
         print(json.dumps(res), flush=True)

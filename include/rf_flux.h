@@ -416,6 +416,61 @@ int rf_vae_decode(const rf_vae_weights* w, const void* z, int32_t h, int32_t w_i
 /* img: zero-halo [(H+2)(W+2)][conv_in.cin] -> out: [(H/8+2)(W/8+2)][conv_out.cout] = (mean | logvar) moments, interior valid */
 int rf_vae_encode(const rf_vae_weights* w, const void* img, int32_t H, int32_t W, void* out, const rf_workspace* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Text encoders: what FluxPipeline.encode_prompt runs for every candidate's prompt
+ * (train_flux/flux/generate.py:148-161; per candidate and round in tts/tts_reflectionflow.py:286-294):
+ *   prompt_embeds        = T5EncoderModel(t5_ids [512])[0]              -> rf_t5_encode
+ *   pooled_prompt_embeds = CLIPTextModel(clip_ids [77]).pooler_output   -> rf_clip_text_encode
+ * One sequence per call, token ids (int32, device) in; no attention mask, as in the reference's calls (T5 attends over all padded
+ * positions, CLIP is causal).  All weights bf16, head dim 64, S <= 512.  Every projection is an rf_gemm_bf16 launch (residual adds in
+ * its epilogue); attention is one kernel with the head's K and V^T resident in LDS and an additive fp32 bias.  The algorithm is
+ * transformers' (requirements.txt:2); parity is pinned against transformers 5.15.0 (oracle/text_oracle.py, tests/golden/text_encoders.npz).
+ * ---------------------------------------------------------------------------------- */
+typedef struct rf_t5_layer {
+  const void* ln0;    /* layer.0.layer_norm.weight [d_model] (RMS norm: no mean subtraction, no bias) */
+  const void* w_qk;   /* cat(SelfAttention.q, .k) [2 * heads * 64][d_model]; T5 does not scale q.k */
+  const void* w_v;    /* SelfAttention.v [heads * 64][d_model]: used as the A operand (V^T = W_v x^T) */
+  const void* w_o;    /* SelfAttention.o [d_model][heads * 64] */
+  const void* ln1;    /* layer.1.layer_norm.weight */
+  const void* w_wi;   /* cat(DenseReluDense.wi_0, .wi_1) [2 * d_ff][d_model]: gelu_new(wi_0 x) * (wi_1 x) */
+  const void* w_wo;   /* DenseReluDense.wo [d_model][d_ff] */
+} rf_t5_layer;
+typedef struct rf_t5_weights {
+  int32_t layers, d_model, heads, d_kv;   /* d_kv must be 64 */
+  int32_t d_ff, vocab;
+  float eps; int32_t bias_S;              /* layer_norm_epsilon (1e-6); pos_bias is built for S_pad = bias_S */
+  const void* embed;                      /* shared.weight [vocab][d_model] */
+  const float* pos_bias;                  /* [heads][bias_S][bias_S] fp32: relative_attention_bias of layer 0 gathered through the
+                                             bidirectional buckets (32 buckets, max distance 128), -inf in columns >= S */
+  const void* final_ln;                   /* encoder.final_layer_norm.weight */
+  const rf_t5_layer* layer;               /* HOST array [layers] */
+} rf_t5_weights;
+int64_t rf_t5_workspace_bytes(const rf_t5_weights* w, int32_t S);
+/* out [S][ld_out] bf16 = last hidden state (final norm applied) */
+int rf_t5_encode(const rf_t5_weights* w, const int32_t* ids, int32_t S, void* out, int64_t ld_out, const rf_workspace* ws, void* stream);
+
+typedef struct rf_clip_layer {
+  const void *ln1_scale, *ln1_shift;      /* layer_norm1 as (weight - 1, bias): LN(x) * (1 + scale) + shift */
+  const void *w_qk, *b_qk;                /* cat(q_proj / 8, k_proj) [2 * hidden][hidden] (+ biases; 1/sqrt(64) folded into q) */
+  const void* w_v;                        /* v_proj.weight [hidden][hidden] (A operand); its bias is folded into b_o */
+  const void *w_o, *b_o;                  /* out_proj; b_o = out_proj.bias + out_proj.weight . v_proj.bias */
+  const void *ln2_scale, *ln2_shift;
+  const void *w_fc1, *b_fc1, *w_fc2, *b_fc2;   /* mlp: fc2(quick_gelu(fc1 x)) */
+} rf_clip_layer;
+typedef struct rf_clip_weights {
+  int32_t layers, hidden, heads, inter;
+  int32_t vocab, max_pos;
+  float eps; int32_t mask_S;              /* layer_norm_eps (1e-5); mask is built for S_pad = mask_S */
+  const void *tok_embed, *pos_embed;      /* [vocab][hidden], [max_pos][hidden] */
+  const float* mask;                      /* [mask_S][mask_S] fp32: 0 on / below the diagonal, -inf above and in columns >= S */
+  const void *final_ln_scale, *final_ln_shift;
+  const rf_clip_layer* layer;             /* HOST array [layers] */
+} rf_clip_weights;
+int64_t rf_clip_text_workspace_bytes(const rf_clip_weights* w, int32_t S);
+/* last_hidden [S][hidden] (may be NULL) and pooled [hidden] (may be NULL) = final-normed row eos_pos */
+int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t S, int32_t eos_pos, void* last_hidden, void* pooled,
+                        const rf_workspace* ws, void* stream);
+
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
  * shape with hipEvents on `stream`; returns average microseconds in *us. */
 int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);

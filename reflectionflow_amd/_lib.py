@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -125,6 +125,27 @@ class rf_vae_weights(C.Structure):
                 ("norm_out", rf_vae_norm), ("conv_out", rf_vae_conv)]
 
 
+class rf_t5_layer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln0", "w_qk", "w_v", "w_o", "ln1", "w_wi", "w_wo")]
+
+
+class rf_t5_weights(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("d_model", C.c_int32), ("heads", C.c_int32), ("d_kv", C.c_int32), ("d_ff", C.c_int32), ("vocab", C.c_int32),
+                ("eps", C.c_float), ("bias_S", C.c_int32), ("embed", C.c_void_p), ("pos_bias", C.c_void_p), ("final_ln", C.c_void_p),
+                ("layer", C.POINTER(rf_t5_layer))]
+
+
+class rf_clip_layer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_scale", "ln1_shift", "w_qk", "b_qk", "w_v", "w_o", "b_o", "ln2_scale", "ln2_shift",
+                                          "w_fc1", "b_fc1", "w_fc2", "b_fc2")]
+
+
+class rf_clip_weights(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("inter", C.c_int32), ("vocab", C.c_int32), ("max_pos", C.c_int32),
+                ("eps", C.c_float), ("mask_S", C.c_int32), ("tok_embed", C.c_void_p), ("pos_embed", C.c_void_p), ("mask", C.c_void_p),
+                ("final_ln_scale", C.c_void_p), ("final_ln_shift", C.c_void_p), ("layer", C.POINTER(rf_clip_layer))]
+
+
 # every symbol include/rf_flux.h declares: (restype, argtypes)
 _SIGS = {
     "rf_last_error": (C.c_char_p, []),
@@ -161,6 +182,10 @@ _SIGS = {
     "rf_vae_workspace_bytes": (C.c_int64, [C.POINTER(rf_vae_weights), C.c_int32, C.c_int32, C.c_int32]),
     "rf_vae_decode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
     "rf_vae_encode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
+    "rf_t5_workspace_bytes": (C.c_int64, [C.POINTER(rf_t5_weights), C.c_int32]),
+    "rf_t5_encode": (C.c_int, [C.POINTER(rf_t5_weights), _P, C.c_int32, _P, C.c_int64, C.POINTER(rf_workspace), _P]),
+    "rf_clip_text_workspace_bytes": (C.c_int64, [C.POINTER(rf_clip_weights), C.c_int32]),
+    "rf_clip_text_encode": (C.c_int, [C.POINTER(rf_clip_weights), _P, C.c_int32, C.c_int32, _P, _P, C.POINTER(rf_workspace), _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),
     "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int32)]),

@@ -144,6 +144,37 @@ class FluxPipeline:
             self.vae = HipVAE(self.vae)
         return self
 
+    def enable_hip_text_encoders(self, t5_state_dict=None, clip_state_dict=None, tokenize=None, root: str = None, t5_heads: int = 64,
+                                 clip_heads: int = 12, clip_eos_token_id: int = 2):
+        """Run FluxPipeline.encode_prompt's two encoder calls (generate.py:148-161) on the HIP path (rf_t5_encode / rf_clip_text_encode,
+        SURVEY 8f row 2).  Weights: transformers-layout state dicts, or `root` = a diffusers FLUX directory whose `text_encoder_2/` and
+        `text_encoder/` sub-directories hold the safetensors (+ config.json for the head counts).  `tokenize(prompt, max_sequence_length)
+        -> (t5_ids [B, L], clip_ids [B, 77])` is the caller's: the SentencePiece / BPE vocabularies are not part of this repo."""
+        from .text_hip import HipClipTextEncoder, HipT5Encoder, HipTextEncoders
+        if tokenize is None:
+            raise ValueError("enable_hip_text_encoders(): a tokenize(prompt, max_sequence_length) callable is required")
+        if root is not None:
+            import json
+            from safetensors.torch import load_file
+
+            def load_dir(d):
+                sd = {}
+                for f in sorted(os.listdir(d)):
+                    if f.endswith(".safetensors"):
+                        sd.update(load_file(os.path.join(d, f)))
+                cfg = json.load(open(os.path.join(d, "config.json"))) if os.path.exists(os.path.join(d, "config.json")) else {}
+                return sd, cfg
+            t5_state_dict, c2 = load_dir(os.path.join(root, "text_encoder_2"))
+            clip_state_dict, c1 = load_dir(os.path.join(root, "text_encoder"))
+            t5_heads, clip_heads = c2.get("num_heads", t5_heads), c1.get("num_attention_heads", clip_heads)
+            clip_eos_token_id = c1.get("eos_token_id", clip_eos_token_id)
+        if t5_state_dict is None or clip_state_dict is None:
+            raise ValueError("enable_hip_text_encoders(): state dicts or a checkpoint root are required")
+        dev = self.device
+        self.text_encoder = HipTextEncoders(HipT5Encoder(t5_state_dict, t5_heads, dev), HipClipTextEncoder(clip_state_dict, clip_heads, dev,
+                                                                                                          eos_token_id=clip_eos_token_id), tokenize)
+        return self
+
     def set_progress_bar_config(self, **kw):
         self._progress = kw
 
@@ -238,9 +269,14 @@ class FluxPipeline:
             prompts = [prompt] if isinstance(prompt, str) else list(prompt)
             prompts_2 = prompts if prompt_2 is None else ([prompt_2] if isinstance(prompt_2, str) else list(prompt_2))
             pes, pools = [], []
+            split = hasattr(self.text_encoder, "encode_t5") and hasattr(self.text_encoder, "encode_clip")
             for p1, p2 in zip(prompts, prompts_2):
-                pe, _ = self.text_encoder(p2, max_sequence_length, self.dtype, device)    # T5 sees prompt_2
-                _, pooled = self.text_encoder(p1, max_sequence_length, self.dtype, device)  # CLIP sees prompt
+                if split:   # (HipTextEncoders: each tower runs once, on the prompt it sees)
+                    pe = self.text_encoder.encode_t5(p2, max_sequence_length, self.dtype, device)
+                    pooled = self.text_encoder.encode_clip(p1, self.dtype, device)
+                else:
+                    pe, _ = self.text_encoder(p2, max_sequence_length, self.dtype, device)    # T5 sees prompt_2
+                    _, pooled = self.text_encoder(p1, max_sequence_length, self.dtype, device)  # CLIP sees prompt
                 pes.append(pe)
                 pools.append(pooled)
             prompt_embeds, pooled_prompt_embeds = torch.stack(pes), torch.stack(pools)

@@ -42,7 +42,7 @@ def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
     from reflectionflow_amd import _lib
     structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_attn_desc", "rf_lora_seg", "rf_double_block_weights",
                "rf_single_block_weights", "rf_flux_dims", "rf_workspace", "rf_flux_model"] + \
-        [n for n in ("rf_vae_conv", "rf_vae_norm", "rf_vae_resnet", "rf_vae_attn", "rf_vae_weights") if hasattr(_lib, n)]
+        ["rf_vae_conv", "rf_vae_norm", "rf_vae_resnet", "rf_vae_attn", "rf_vae_weights", "rf_t5_layer", "rf_t5_weights", "rf_clip_layer", "rf_clip_weights"]
     src = '#include "rf_flux.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){\n' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));\n' for s in structs) + \
         'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\n' \
