@@ -421,7 +421,7 @@ int rf_vae_encode(const rf_vae_weights* w, const void* img, int32_t H, int32_t W
  * (train_flux/flux/generate.py:148-161; per candidate and round in tts/tts_reflectionflow.py:286-294):
  *   prompt_embeds        = T5EncoderModel(t5_ids [512])[0]              -> rf_t5_encode
  *   pooled_prompt_embeds = CLIPTextModel(clip_ids [77]).pooler_output   -> rf_clip_text_encode
- * One sequence per call, token ids (int32, device) in; no attention mask, as in the reference's calls (T5 attends over all padded
+ * B sequences of S token ids (int32, device) per call -- a rank's candidates of a round share every GEMM launch; no attention mask, as in the reference's calls (T5 attends over all padded
  * positions, CLIP is causal).  All weights bf16, head dim 64, S <= 512.  Every projection is an rf_gemm_bf16 launch (residual adds in
  * its epilogue); attention is one kernel with the head's K and V^T resident in LDS and an additive fp32 bias.  The algorithm is
  * transformers' (requirements.txt:2); parity is pinned against transformers 5.15.0 (oracle/text_oracle.py, tests/golden/text_encoders.npz).
@@ -445,9 +445,9 @@ typedef struct rf_t5_weights {
   const void* final_ln;                   /* encoder.final_layer_norm.weight */
   const rf_t5_layer* layer;               /* HOST array [layers] */
 } rf_t5_weights;
-int64_t rf_t5_workspace_bytes(const rf_t5_weights* w, int32_t S);
-/* out [S][ld_out] bf16 = last hidden state (final norm applied) */
-int rf_t5_encode(const rf_t5_weights* w, const int32_t* ids, int32_t S, void* out, int64_t ld_out, const rf_workspace* ws, void* stream);
+int64_t rf_t5_workspace_bytes(const rf_t5_weights* w, int32_t B, int32_t S);
+/* ids [B][S] -> out [B][S][ld_out] bf16 = last hidden state (final norm applied); 1 <= B <= 64 sequences share every GEMM launch */
+int rf_t5_encode(const rf_t5_weights* w, const int32_t* ids, int32_t B, int32_t S, void* out, int64_t ld_out, const rf_workspace* ws, void* stream);
 
 typedef struct rf_clip_layer {
   const void *ln1_scale, *ln1_shift;      /* layer_norm1 as (weight - 1, bias): LN(x) * (1 + scale) + shift */
@@ -466,9 +466,10 @@ typedef struct rf_clip_weights {
   const void *final_ln_scale, *final_ln_shift;
   const rf_clip_layer* layer;             /* HOST array [layers] */
 } rf_clip_weights;
-int64_t rf_clip_text_workspace_bytes(const rf_clip_weights* w, int32_t S);
-/* last_hidden [S][hidden] (may be NULL) and pooled [hidden] (may be NULL) = final-normed row eos_pos */
-int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t S, int32_t eos_pos, void* last_hidden, void* pooled,
+int64_t rf_clip_text_workspace_bytes(const rf_clip_weights* w, int32_t B, int32_t S);
+/* ids [B][S] -> last_hidden [B][S][hidden] (may be NULL) and pooled [B][hidden] (may be NULL) = final-normed row eos_pos[b] of
+ * sequence b (eos_pos: HOST array [B]) */
+int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t B, int32_t S, const int32_t* eos_pos, void* last_hidden, void* pooled,
                         const rf_workspace* ws, void* stream);
 
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM

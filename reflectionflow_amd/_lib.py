@@ -182,10 +182,10 @@ _SIGS = {
     "rf_vae_workspace_bytes": (C.c_int64, [C.POINTER(rf_vae_weights), C.c_int32, C.c_int32, C.c_int32]),
     "rf_vae_decode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
     "rf_vae_encode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
-    "rf_t5_workspace_bytes": (C.c_int64, [C.POINTER(rf_t5_weights), C.c_int32]),
-    "rf_t5_encode": (C.c_int, [C.POINTER(rf_t5_weights), _P, C.c_int32, _P, C.c_int64, C.POINTER(rf_workspace), _P]),
-    "rf_clip_text_workspace_bytes": (C.c_int64, [C.POINTER(rf_clip_weights), C.c_int32]),
-    "rf_clip_text_encode": (C.c_int, [C.POINTER(rf_clip_weights), _P, C.c_int32, C.c_int32, _P, _P, C.POINTER(rf_workspace), _P]),
+    "rf_t5_workspace_bytes": (C.c_int64, [C.POINTER(rf_t5_weights), C.c_int32, C.c_int32]),
+    "rf_t5_encode": (C.c_int, [C.POINTER(rf_t5_weights), _P, C.c_int32, C.c_int32, _P, C.c_int64, C.POINTER(rf_workspace), _P]),
+    "rf_clip_text_workspace_bytes": (C.c_int64, [C.POINTER(rf_clip_weights), C.c_int32, C.c_int32]),
+    "rf_clip_text_encode": (C.c_int, [C.POINTER(rf_clip_weights), _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, _P, C.POINTER(rf_workspace), _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),
     "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int32)]),

@@ -1,7 +1,8 @@
 // Text encoders of the FLUX pipeline on the HIP path: T5-v1.1 encoder (prompt_embeds) and CLIP text tower
 // (pooled_prompt_embeds), reference call site train_flux/flux/generate.py:148-161 -> FluxPipeline.encode_prompt, run per candidate
-// and round by tts/tts_reflectionflow.py:286-294.  One sequence per call; token ids in, hidden states out; tokenisation is the
-// caller's (vocabulary files are host-side data).
+// and round by tts/tts_reflectionflow.py:286-294.  B sequences of S tokens per call (a rank's candidates of a round: the projections
+// then run as ONE GEMM over B * S rows instead of B skinny ones); token ids in, hidden states out; tokenisation is the caller's
+// (vocabulary files are host-side data).
 //
 // Every matrix product is a launch of the bf16 MFMA GEMM that already exists (rf_gemm_bf16): q|k projection, V^T = W_v x^T with the
 // operands swapped (the attention kernel wants V transposed), out projection and FFN down-projection with the residual add in the
@@ -24,16 +25,17 @@ namespace rf {
 static inline int grid_for(int64_t n, int per_block = 256) { return (int)((n + per_block - 1) / per_block); }
 
 // ---- row kernels -------------------------------------------------------------------------------------------------------------
-// out[i][:] = table[ids[i]][:] (+ pos[i][:]); rows >= n_real are zero-filled; D % 8 == 0
+// out[b * S_pad + i][:] = table[ids[b * S + i]][:] (+ pos[i][:]); rows i >= S of a sequence are zero-filled; D % 8 == 0
 __global__ __launch_bounds__(256) void embed_rows_kernel(const bf16_t* __restrict__ table, const bf16_t* __restrict__ pos, const int32_t* __restrict__ ids,
-                                                         bf16_t* __restrict__ out, int n_real, int n_rows, int D, int vocab) {
+                                                         bf16_t* __restrict__ out, int S, int S_pad, int n_rows, int D, int vocab) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int d8 = D >> 3;
   if (idx >= (int64_t)n_rows * d8) return;
-  const int row = (int)(idx / d8), c = (int)(idx % d8) * 8;
+  const int grow = (int)(idx / d8), c = (int)(idx % d8) * 8;
+  const int b = grow / S_pad, row = grow - b * S_pad;
   u32x4 v = {0u, 0u, 0u, 0u};
-  if (row < n_real) {
-    int id = ids[row];
+  if (row < S) {
+    int id = ids[b * S + row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     v = *(const u32x4*)(table + (int64_t)id * D + c);
     if (pos != nullptr) {
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const bf16_t* __restric
       v = pack8(a);
     }
   }
-  *(u32x4*)(out + (int64_t)row * D + c) = v;
+  *(u32x4*)(out + (int64_t)grow * D + c) = v;
 }
 
 // T5LayerNorm: y = w * x * rsqrt(mean(x^2) + eps), statistics in fp32; one wave per row, D % 8 == 0, D <= 8 * 64 * 8 = 4096
@@ -119,6 +121,7 @@ static inline int ta_lds_bytes(int S_pad) { return S_pad * 128 + 64 * (S_pad * 2
 // q [S_pad][ldq], k [S_pad][ldk] (this head's 64 columns start at head * 64), vt [heads * 64][ldvt] (V transposed: row = channel,
 // column = key), bias [.][S_pad][S_pad] fp32 with head stride bias_hs (0: shared by the heads) or NULL, out [S][ldo].
 // scores = scale * q.k + bias; S_pad % 32 == 0; rows / keys >= S must be masked by the bias (-inf) and are not written.
+// blockIdx.z = sequence: its rows of q / k / out start at z * S_pad, its columns of vt at z * S_pad (out: z * S_pad as well).
 __global__ __launch_bounds__(256) void attn64_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
                                                      const bf16_t* __restrict__ vt, int64_t ldvt, const float* __restrict__ bias, int64_t bias_hs,
                                                      bf16_t* __restrict__ out, int64_t ldo, int S, int S_pad, float scale) {
@@ -129,6 +132,10 @@ __global__ __launch_bounds__(256) void attn64_kernel(const bf16_t* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int head = blockIdx.y, qb = blockIdx.x;
+  {
+    const int64_t r0 = (int64_t)blockIdx.z * S_pad;
+    q += r0 * ldq; k += r0 * ldk; vt += r0; out += r0 * ldo;
+  }
   // ---- stage the head's K and V^T --------------------------------------------------------------------------------------------
   for (int idx = tid; idx < S_pad * 8; idx += 256) {
     const int r = idx >> 3, c = idx & 7;
@@ -229,38 +236,38 @@ struct TextCtx {
   hipStream_t st;
   bf16_t *X, *Xn, *QK, *VT, *AO, *HID, *G, *ones;
   void* sk; int64_t sk_bytes;
-  int S, S_pad;
+  int S, S_pad, B;
 };
 
 struct TextSizes { int64_t x, qk, vt, ao, hid, g, total; };
 constexpr int64_t TEXT_SK = 4096 + (64ll << 20);
 
-static TextSizes text_sizes(int S_pad, int D, int inner, int F, int hid_cols) {
+static TextSizes text_sizes(int rows, int D, int inner, int F, int hid_cols) {   // rows = B * S_pad
   TextSizes z;
-  z.x = round_up((int64_t)S_pad * D * 2, 256);
-  z.qk = round_up((int64_t)S_pad * 2 * inner * 2, 256);
-  z.vt = round_up((int64_t)inner * S_pad * 2, 256);
-  z.ao = round_up((int64_t)S_pad * inner * 2, 256);
-  z.hid = round_up((int64_t)S_pad * hid_cols * 2, 256);
-  z.g = round_up((int64_t)S_pad * F * 2, 256);
+  z.x = round_up((int64_t)rows * D * 2, 256);
+  z.qk = round_up((int64_t)rows * 2 * inner * 2, 256);
+  z.vt = round_up((int64_t)inner * rows * 2, 256);
+  z.ao = round_up((int64_t)rows * inner * 2, 256);
+  z.hid = round_up((int64_t)rows * hid_cols * 2, 256);
+  z.g = round_up((int64_t)rows * F * 2, 256);
   z.total = 2 * z.x + z.qk + z.vt + z.ao + z.hid + z.g + round_up(16384 * 2, 256) + TEXT_SK;
   return z;
 }
 
-static int text_ctx(TextCtx& c, const TextSizes& z, int S, int S_pad, const rf_workspace* ws, hipStream_t st, const char* who) {
+static int text_ctx(TextCtx& c, const TextSizes& z, int B, int S, int S_pad, const rf_workspace* ws, hipStream_t st, const char* who) {
   RF_REQUIRE(ws && ws->base && aligned16(ws->base) && ws->bytes >= z.total, RF_ERR_WORKSPACE, "%s: workspace %lld < required %lld bytes", who,
              (long long)(ws ? ws->bytes : 0), (long long)z.total);
   char* p = (char*)ws->base;
   auto take = [&](int64_t bytes) { char* q = p; p += round_up(bytes, 256); return q; };
-  c.st = st; c.S = S; c.S_pad = S_pad;
+  c.st = st; c.S = S; c.S_pad = S_pad; c.B = B;
   c.X = (bf16_t*)take(z.x); c.Xn = (bf16_t*)take(z.x); c.QK = (bf16_t*)take(z.qk); c.VT = (bf16_t*)take(z.vt);
   c.AO = (bf16_t*)take(z.ao); c.HID = (bf16_t*)take(z.hid); c.G = (bf16_t*)take(z.g);
   c.ones = (bf16_t*)take(16384 * 2);
   c.sk = take(TEXT_SK); c.sk_bytes = TEXT_SK;
   hipLaunchKernelGGL(fill_bf16_rows_kernel, dim3(64), dim3(256), 0, st, c.ones, (int64_t)16384, 1.0f);
   RF_CHECK_HIP(hipMemsetAsync(c.sk, 0, 4096, st));                       // stream-K flags
-  RF_CHECK_HIP(hipMemsetAsync(c.Xn, 0, (size_t)z.x, st));                // padded rows of the normed stream stay zero: finite K / V^T pads
-  RF_CHECK_HIP(hipMemsetAsync(c.AO, 0, (size_t)z.ao, st));
+  RF_CHECK_HIP(hipMemsetAsync(c.Xn, 0, (size_t)z.x, st));                // padded rows start finite (zero) and stay finite: they run through
+  RF_CHECK_HIP(hipMemsetAsync(c.AO, 0, (size_t)z.ao, st));                // the same norms as real rows; no real row ever reads them (masked keys)
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
@@ -292,9 +299,9 @@ static int text_attention(TextCtx& c, int heads, int inner, const float* bias, i
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes(TA_MAXS)));
     attr = true;
   }
-  ProfScope prof(RF_KC_ATTN, 4.0 * (double)c.S_pad * c.S_pad * 64.0 * heads, c.st);
-  hipLaunchKernelGGL(attn64_kernel, dim3(cdiv(c.S_pad, 64), heads), dim3(256), lds, c.st, c.QK, (int64_t)2 * inner, c.QK + inner, (int64_t)2 * inner, c.VT,
-                     (int64_t)c.S_pad, bias, bias_hs, c.AO, (int64_t)inner, c.S, c.S_pad, scale);
+  ProfScope prof(RF_KC_ATTN, 4.0 * (double)c.S_pad * c.S_pad * 64.0 * heads * c.B, c.st);
+  hipLaunchKernelGGL(attn64_kernel, dim3(cdiv(c.S_pad, 64), heads, c.B), dim3(256), lds, c.st, c.QK, (int64_t)2 * inner, c.QK + inner, (int64_t)2 * inner,
+                     c.VT, (int64_t)c.B * c.S_pad, bias, bias_hs, c.AO, (int64_t)inner, c.S, c.S_pad, scale);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
@@ -313,62 +320,59 @@ static int t5_check(const rf_t5_weights* w, int32_t S, const char* who) {
   return RF_OK;
 }
 
-extern "C" int64_t rf_t5_workspace_bytes(const rf_t5_weights* w, int32_t S) {
-  if (t5_check(w, S, "rf_t5_workspace_bytes") != RF_OK) return RF_ERR_SHAPE;
+extern "C" int64_t rf_t5_workspace_bytes(const rf_t5_weights* w, int32_t B, int32_t S) {
+  if (t5_check(w, S, "rf_t5_workspace_bytes") != RF_OK || B <= 0 || B > 64) return RF_ERR_SHAPE;
   const int S_pad = (int)round_up(S, 32);
-  return text_sizes(S_pad, w->d_model, w->heads * 64, w->d_ff, 2 * w->d_ff).total;
+  return text_sizes(B * S_pad, w->d_model, w->heads * 64, w->d_ff, 2 * w->d_ff).total;
 }
 
-// T5EncoderModel(ids)[0] for ONE sequence: ids [S] int32 on the device -> out [S][ld_out] bf16 (the final RMS norm applied).
-// pos_bias: [heads][S_pad][S_pad] fp32 for S_pad = round_up(S, 32) -- layer 0's bucketed relative-position bias, -inf in the columns
-// of padded keys (built once per S by the binding: integer bucketing + one gather).
-extern "C" int rf_t5_encode(const rf_t5_weights* w, const int32_t* ids, int32_t S, void* out, int64_t ld_out, const rf_workspace* ws, void* stream) {
+// T5EncoderModel(ids)[0] for B sequences of S tokens: ids [B][S] int32 on the device -> out [B][S][ld_out] bf16 (final RMS norm
+// applied).  pos_bias: [heads][S_pad][S_pad] fp32 for S_pad = round_up(S, 32) -- layer 0's bucketed relative-position bias, -inf in
+// the columns of padded keys (built once per S by the binding: integer bucketing + one gather).  Internally every sequence owns
+// S_pad rows; the projections and the FFN run over all B * S_pad rows at once.
+extern "C" int rf_t5_encode(const rf_t5_weights* w, const int32_t* ids, int32_t B, int32_t S, void* out, int64_t ld_out, const rf_workspace* ws,
+                            void* stream) {
   RF_TRY(t5_check(w, S, "rf_t5_encode"));
+  RF_REQUIRE(B > 0 && B <= 64, RF_ERR_SHAPE, "rf_t5_encode: B=%d (1 .. 64)", B);
   RF_REQUIRE(ids && out && aligned16(out) && ld_out % 8 == 0 && ld_out >= w->d_model, RF_ERR_NULL, "rf_t5_encode: NULL / unaligned tensor");
-  const int S_pad = (int)round_up(S, 32), D = w->d_model, inner = w->heads * 64, F = w->d_ff;
+  const int S_pad = (int)round_up(S, 32), D = w->d_model, inner = w->heads * 64, F = w->d_ff, R = B * S_pad;
   RF_REQUIRE(w->pos_bias && w->bias_S == S_pad, RF_ERR_SHAPE, "rf_t5_encode: pos_bias is built for S_pad = %d, this call needs %d", w->bias_S, S_pad);
   hipStream_t st = (hipStream_t)stream;
   TextCtx c;
-  RF_TRY(text_ctx(c, text_sizes(S_pad, D, inner, F, 2 * F), S, S_pad, ws, st, "rf_t5_encode"));
+  RF_TRY(text_ctx(c, text_sizes(R, D, inner, F, 2 * F), B, S, S_pad, ws, st, "rf_t5_encode"));
   {
-    ProfScope prof(RF_KC_ROWOP, (double)S_pad * D * 4, st);
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_for((int64_t)S_pad * D / 8)), dim3(256), 0, st, (const bf16_t*)w->embed, (const bf16_t*)nullptr, ids, c.X, S,
-                       S_pad, D, w->vocab);
+    ProfScope prof(RF_KC_ROWOP, (double)R * D * 4, st);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_for((int64_t)R * D / 8)), dim3(256), 0, st, (const bf16_t*)w->embed, (const bf16_t*)nullptr, ids, c.X, S,
+                       S_pad, R, D, w->vocab);
     RF_LAUNCH_CHECK();
   }
   auto rms = [&](const void* g, const bf16_t* x, bf16_t* y) {
-    ProfScope prof(RF_KC_ROWOP, (double)S * D * 4, st);
-    hipLaunchKernelGGL(rms_norm_rows_kernel, dim3(cdiv(S, 4)), dim3(256), 0, st, x, (const bf16_t*)g, y, S, D, w->eps);
+    ProfScope prof(RF_KC_ROWOP, (double)R * D * 4, st);
+    hipLaunchKernelGGL(rms_norm_rows_kernel, dim3(cdiv(R, 4)), dim3(256), 0, st, x, (const bf16_t*)g, y, R, D, w->eps);
     return hipGetLastError() == hipSuccess ? RF_OK : RF_ERR_HIP;
   };
   for (int i = 0; i < w->layers; ++i) {
     const rf_t5_layer& L = w->layer[i];
     RF_REQUIRE(L.ln0 && L.w_qk && L.w_v && L.w_o && L.ln1 && L.w_wi && L.w_wo, RF_ERR_NULL, "rf_t5_encode: layer %d has NULL weights", i);
     RF_TRY(rms(L.ln0, c.X, c.Xn));
-    RF_TRY(text_gemm(c, c.Xn, D, L.w_qk, nullptr, S_pad, 2 * inner, D, c.QK, 2 * inner, RF_EPI_STORE, nullptr));
-    RF_TRY(text_gemm(c, (const bf16_t*)L.w_v, D, c.Xn, nullptr, inner, S_pad, D, c.VT, S_pad, RF_EPI_STORE, nullptr));   // V^T = W_v x^T
-    RF_TRY(text_attention(c, w->heads, inner, w->pos_bias, (int64_t)S_pad * S_pad, 1.0f));                                 // T5: no 1/sqrt(d)
-    RF_TRY(text_gemm(c, c.AO, inner, L.w_o, nullptr, S, D, inner, c.X, D, RF_EPI_STORE, c.X));
+    RF_TRY(text_gemm(c, c.Xn, D, L.w_qk, nullptr, R, 2 * inner, D, c.QK, 2 * inner, RF_EPI_STORE, nullptr));
+    RF_TRY(text_gemm(c, (const bf16_t*)L.w_v, D, c.Xn, nullptr, inner, R, D, c.VT, R, RF_EPI_STORE, nullptr));   // V^T = W_v x^T
+    RF_TRY(text_attention(c, w->heads, inner, w->pos_bias, (int64_t)S_pad * S_pad, 1.0f));                       // T5: no 1/sqrt(d)
+    RF_TRY(text_gemm(c, c.AO, inner, L.w_o, nullptr, R, D, inner, c.X, D, RF_EPI_STORE, c.X));
     RF_TRY(rms(L.ln1, c.X, c.Xn));
-    RF_TRY(text_gemm(c, c.Xn, D, L.w_wi, nullptr, S, 2 * F, D, c.HID, 2 * F, RF_EPI_STORE, nullptr));
+    RF_TRY(text_gemm(c, c.Xn, D, L.w_wi, nullptr, R, 2 * F, D, c.HID, 2 * F, RF_EPI_STORE, nullptr));
     {
-      ProfScope prof(RF_KC_ROWOP, (double)S * F * 6, st);
-      hipLaunchKernelGGL(geglu_rows_kernel, dim3(grid_for((int64_t)S * F / 8)), dim3(256), 0, st, c.HID, c.G, S, F);
+      ProfScope prof(RF_KC_ROWOP, (double)R * F * 6, st);
+      hipLaunchKernelGGL(geglu_rows_kernel, dim3(grid_for((int64_t)R * F / 8)), dim3(256), 0, st, c.HID, c.G, R, F);
       RF_LAUNCH_CHECK();
     }
-    RF_TRY(text_gemm(c, c.G, F, L.w_wo, nullptr, S, D, F, c.X, D, RF_EPI_STORE, c.X));
+    RF_TRY(text_gemm(c, c.G, F, L.w_wo, nullptr, R, D, F, c.X, D, RF_EPI_STORE, c.X));
   }
-  {
-    ProfScope prof(RF_KC_ROWOP, (double)S * D * 4, st);
-    // (final norm straight into the caller's rows; ld_out may exceed d_model)
-    if (ld_out == D) {
-      hipLaunchKernelGGL(rms_norm_rows_kernel, dim3(cdiv(S, 4)), dim3(256), 0, st, c.X, (const bf16_t*)w->final_ln, (bf16_t*)out, S, D, w->eps);
-    } else {
-      hipLaunchKernelGGL(rms_norm_rows_kernel, dim3(cdiv(S, 4)), dim3(256), 0, st, c.X, (const bf16_t*)w->final_ln, c.Xn, S, D, w->eps);
-      RF_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 2, c.Xn, (size_t)D * 2, (size_t)D * 2, (size_t)S, hipMemcpyDeviceToDevice, st));
-    }
-    RF_LAUNCH_CHECK();
-  }
+  RF_TRY(rms(w->final_ln, c.X, c.Xn));
+  // the real rows of every sequence -> the caller's [B][S][ld_out]
+  for (int b = 0; b < B; ++b)
+    RF_CHECK_HIP(hipMemcpy2DAsync((char*)out + (int64_t)b * S * ld_out * 2, (size_t)ld_out * 2, c.Xn + (int64_t)b * S_pad * D, (size_t)D * 2, (size_t)D * 2,
+                                  (size_t)S, hipMemcpyDeviceToDevice, st));
   return RF_OK;
 }
 
@@ -381,53 +385,59 @@ static int clip_check(const rf_clip_weights* w, int32_t S, const char* who) {
   return RF_OK;
 }
 
-extern "C" int64_t rf_clip_text_workspace_bytes(const rf_clip_weights* w, int32_t S) {
-  if (clip_check(w, S, "rf_clip_text_workspace_bytes") != RF_OK) return RF_ERR_SHAPE;
+extern "C" int64_t rf_clip_text_workspace_bytes(const rf_clip_weights* w, int32_t B, int32_t S) {
+  if (clip_check(w, S, "rf_clip_text_workspace_bytes") != RF_OK || B <= 0 || B > 64) return RF_ERR_SHAPE;
   const int S_pad = (int)round_up(S, 32);
-  return text_sizes(S_pad, w->hidden, w->hidden, w->inter, w->inter).total;
+  return text_sizes(B * S_pad, w->hidden, w->hidden, w->inter, w->inter).total;
 }
 
-// CLIPTextModel(ids) for ONE sequence: last_hidden_state [S][hidden] (final LayerNorm applied; may be NULL) and pooler_output
-// [hidden] = the final-normed row eos_pos (the binding finds it: argmax(ids) for the legacy eos_token_id == 2 config, else the
-// first eos_token_id).  mask: [S_pad][S_pad] fp32, 0 on and below the diagonal, -inf above it and in the columns of padded keys.
-// The binding folds 1/sqrt(64) into w_q / b_q, writes LayerNorm weights as (weight - 1, bias) pairs for rf_layernorm_modulate and
-// folds v_proj.bias into the out-projection bias (softmax rows sum to 1).
-extern "C" int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t S, int32_t eos_pos, void* last_hidden, void* pooled,
-                                   const rf_workspace* ws, void* stream) {
+// CLIPTextModel(ids) for B sequences of S tokens: last_hidden_state [B][S][hidden] (final LayerNorm applied; may be NULL) and
+// pooler_output [B][hidden] = the final-normed row eos_pos[b] of sequence b (HOST array; the binding finds the positions: argmax(ids)
+// for the legacy eos_token_id == 2 config, else the first eos_token_id).  mask: [S_pad][S_pad] fp32, 0 on and below the diagonal,
+// -inf above it and in the columns of padded keys.  The binding folds 1/sqrt(64) into w_q / b_q, writes LayerNorm weights as
+// (weight - 1, bias) pairs for rf_layernorm_modulate and folds v_proj.bias into the out-projection bias (softmax rows sum to 1).
+extern "C" int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t B, int32_t S, const int32_t* eos_pos, void* last_hidden,
+                                   void* pooled, const rf_workspace* ws, void* stream) {
   RF_TRY(clip_check(w, S, "rf_clip_text_encode"));
-  RF_REQUIRE(ids && (last_hidden || pooled), RF_ERR_NULL, "rf_clip_text_encode: NULL tensor");
-  RF_REQUIRE(eos_pos >= 0 && eos_pos < S, RF_ERR_SHAPE, "rf_clip_text_encode: eos_pos=%d outside 0 .. %d", eos_pos, S - 1);
-  const int S_pad = (int)round_up(S, 32), D = w->hidden, F = w->inter;
+  RF_REQUIRE(B > 0 && B <= 64, RF_ERR_SHAPE, "rf_clip_text_encode: B=%d (1 .. 64)", B);
+  RF_REQUIRE(ids && (last_hidden || pooled) && (eos_pos || !pooled), RF_ERR_NULL, "rf_clip_text_encode: NULL tensor");
+  if (pooled)
+    for (int b = 0; b < B; ++b)
+      RF_REQUIRE(eos_pos[b] >= 0 && eos_pos[b] < S, RF_ERR_SHAPE, "rf_clip_text_encode: eos_pos[%d]=%d outside 0 .. %d", b, eos_pos[b], S - 1);
+  const int S_pad = (int)round_up(S, 32), D = w->hidden, F = w->inter, R = B * S_pad;
   RF_REQUIRE(w->mask && w->mask_S == S_pad, RF_ERR_SHAPE, "rf_clip_text_encode: mask is built for S_pad = %d, this call needs %d", w->mask_S, S_pad);
   hipStream_t st = (hipStream_t)stream;
   TextCtx c;
-  RF_TRY(text_ctx(c, text_sizes(S_pad, D, D, F, F), S, S_pad, ws, st, "rf_clip_text_encode"));
+  RF_TRY(text_ctx(c, text_sizes(R, D, D, F, F), B, S, S_pad, ws, st, "rf_clip_text_encode"));
   {
-    ProfScope prof(RF_KC_ROWOP, (double)S_pad * D * 6, st);
-    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_for((int64_t)S_pad * D / 8)), dim3(256), 0, st, (const bf16_t*)w->tok_embed, (const bf16_t*)w->pos_embed,
-                       ids, c.X, S, S_pad, D, w->vocab);
+    ProfScope prof(RF_KC_ROWOP, (double)R * D * 6, st);
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_for((int64_t)R * D / 8)), dim3(256), 0, st, (const bf16_t*)w->tok_embed, (const bf16_t*)w->pos_embed,
+                       ids, c.X, S, S_pad, R, D, w->vocab);
     RF_LAUNCH_CHECK();
   }
   for (int i = 0; i < w->layers; ++i) {
     const rf_clip_layer& L = w->layer[i];
     RF_REQUIRE(L.ln1_scale && L.ln1_shift && L.w_qk && L.b_qk && L.w_v && L.w_o && L.b_o && L.ln2_scale && L.ln2_shift && L.w_fc1 && L.b_fc1 && L.w_fc2 &&
                    L.b_fc2, RF_ERR_NULL, "rf_clip_text_encode: layer %d has NULL weights", i);
-    RF_TRY(rf_layernorm_modulate(c.X, D, c.Xn, D, S, D, L.ln1_scale, L.ln1_shift, w->eps, st));
-    RF_TRY(text_gemm(c, c.Xn, D, L.w_qk, L.b_qk, S_pad, 2 * D, D, c.QK, 2 * D, RF_EPI_STORE, nullptr));
-    RF_TRY(text_gemm(c, (const bf16_t*)L.w_v, D, c.Xn, nullptr, D, S_pad, D, c.VT, S_pad, RF_EPI_STORE, nullptr));
+    RF_TRY(rf_layernorm_modulate(c.X, D, c.Xn, D, R, D, L.ln1_scale, L.ln1_shift, w->eps, st));
+    RF_TRY(text_gemm(c, c.Xn, D, L.w_qk, L.b_qk, R, 2 * D, D, c.QK, 2 * D, RF_EPI_STORE, nullptr));
+    RF_TRY(text_gemm(c, (const bf16_t*)L.w_v, D, c.Xn, nullptr, D, R, D, c.VT, R, RF_EPI_STORE, nullptr));
     RF_TRY(text_attention(c, w->heads, D, w->mask, 0, 1.0f));
-    RF_TRY(text_gemm(c, c.AO, D, L.w_o, L.b_o, S, D, D, c.X, D, RF_EPI_STORE, c.X));
-    RF_TRY(rf_layernorm_modulate(c.X, D, c.Xn, D, S, D, L.ln2_scale, L.ln2_shift, w->eps, st));
-    RF_TRY(text_gemm(c, c.Xn, D, L.w_fc1, L.b_fc1, S, F, D, c.HID, F, RF_EPI_STORE, nullptr));
+    RF_TRY(text_gemm(c, c.AO, D, L.w_o, L.b_o, R, D, D, c.X, D, RF_EPI_STORE, c.X));
+    RF_TRY(rf_layernorm_modulate(c.X, D, c.Xn, D, R, D, L.ln2_scale, L.ln2_shift, w->eps, st));
+    RF_TRY(text_gemm(c, c.Xn, D, L.w_fc1, L.b_fc1, R, F, D, c.HID, F, RF_EPI_STORE, nullptr));
     {
-      ProfScope prof(RF_KC_ROWOP, (double)S * F * 4, st);
-      hipLaunchKernelGGL(quick_gelu_kernel, dim3(grid_for((int64_t)S * F / 8)), dim3(256), 0, st, c.HID, (int64_t)S * F / 8);
+      ProfScope prof(RF_KC_ROWOP, (double)R * F * 4, st);
+      hipLaunchKernelGGL(quick_gelu_kernel, dim3(grid_for((int64_t)R * F / 8)), dim3(256), 0, st, c.HID, (int64_t)R * F / 8);
       RF_LAUNCH_CHECK();
     }
-    RF_TRY(text_gemm(c, c.HID, F, L.w_fc2, L.b_fc2, S, D, F, c.X, D, RF_EPI_STORE, c.X));
+    RF_TRY(text_gemm(c, c.HID, F, L.w_fc2, L.b_fc2, R, D, F, c.X, D, RF_EPI_STORE, c.X));
   }
-  RF_TRY(rf_layernorm_modulate(c.X, D, c.Xn, D, S, D, w->final_ln_scale, w->final_ln_shift, w->eps, st));
-  if (last_hidden) RF_CHECK_HIP(hipMemcpyAsync(last_hidden, c.Xn, (size_t)S * D * 2, hipMemcpyDeviceToDevice, st));
-  if (pooled) RF_CHECK_HIP(hipMemcpyAsync(pooled, c.Xn + (int64_t)eos_pos * D, (size_t)D * 2, hipMemcpyDeviceToDevice, st));
+  RF_TRY(rf_layernorm_modulate(c.X, D, c.Xn, D, R, D, w->final_ln_scale, w->final_ln_shift, w->eps, st));
+  for (int b = 0; b < B; ++b) {
+    const bf16_t* src = c.Xn + (int64_t)b * S_pad * D;
+    if (last_hidden) RF_CHECK_HIP(hipMemcpyAsync((char*)last_hidden + (int64_t)b * S * D * 2, src, (size_t)S * D * 2, hipMemcpyDeviceToDevice, st));
+    if (pooled) RF_CHECK_HIP(hipMemcpyAsync((char*)pooled + (int64_t)b * D * 2, src + (int64_t)eos_pos[b] * D, (size_t)D * 2, hipMemcpyDeviceToDevice, st));
+  }
   return RF_OK;
 }

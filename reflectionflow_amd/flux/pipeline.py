@@ -268,18 +268,18 @@ class FluxPipeline:
         if prompt_embeds is None:
             prompts = [prompt] if isinstance(prompt, str) else list(prompt)
             prompts_2 = prompts if prompt_2 is None else ([prompt_2] if isinstance(prompt_2, str) else list(prompt_2))
-            pes, pools = [], []
-            split = hasattr(self.text_encoder, "encode_t5") and hasattr(self.text_encoder, "encode_clip")
-            for p1, p2 in zip(prompts, prompts_2):
-                if split:   # (HipTextEncoders: each tower runs once, on the prompt it sees)
-                    pe = self.text_encoder.encode_t5(p2, max_sequence_length, self.dtype, device)
-                    pooled = self.text_encoder.encode_clip(p1, self.dtype, device)
-                else:
+            if hasattr(self.text_encoder, "encode_t5") and hasattr(self.text_encoder, "encode_clip"):
+                # HipTextEncoders: each tower runs once, on the prompts it sees, and ALL prompts of the call share its launches
+                prompt_embeds = self.text_encoder.encode_t5(prompts_2, max_sequence_length, self.dtype, device)
+                pooled_prompt_embeds = self.text_encoder.encode_clip(prompts, self.dtype, device)
+            else:
+                pes, pools = [], []
+                for p1, p2 in zip(prompts, prompts_2):
                     pe, _ = self.text_encoder(p2, max_sequence_length, self.dtype, device)    # T5 sees prompt_2
                     _, pooled = self.text_encoder(p1, max_sequence_length, self.dtype, device)  # CLIP sees prompt
-                pes.append(pe)
-                pools.append(pooled)
-            prompt_embeds, pooled_prompt_embeds = torch.stack(pes), torch.stack(pools)
+                    pes.append(pe)
+                    pools.append(pooled)
+                prompt_embeds, pooled_prompt_embeds = torch.stack(pes), torch.stack(pools)
         if num_images_per_prompt != 1:
             prompt_embeds = prompt_embeds.repeat_interleave(num_images_per_prompt, 0)
             pooled_prompt_embeds = pooled_prompt_embeds.repeat_interleave(num_images_per_prompt, 0)

@@ -129,11 +129,12 @@ class HipT5Encoder:
         lib, w = L.load(), self._w
         bias = self._pos_bias(S)
         w.pos_bias, w.bias_S = bias.data_ptr(), _pad32(S)
-        ws = self._ws.get(lib.rf_t5_workspace_bytes(C.byref(w), S))
         ids32 = ids.to(torch.int32).contiguous()
         out = torch.empty(B, S, self.d_model, dtype=BF, device=self.device)
-        for b in range(B):
-            L.check(lib.rf_t5_encode(C.byref(w), ids32[b].data_ptr(), S, out[b].data_ptr(), self.d_model, C.byref(ws), stream_ptr()), "rf_t5_encode")
+        for b0 in range(0, B, 64):                      # (the library takes up to 64 sequences per call: one GEMM launch over all their rows)
+            nb = min(64, B - b0)
+            ws = self._ws.get(lib.rf_t5_workspace_bytes(C.byref(w), nb, S))
+            L.check(lib.rf_t5_encode(C.byref(w), ids32[b0].data_ptr(), nb, S, out[b0].data_ptr(), self.d_model, C.byref(ws), stream_ptr()), "rf_t5_encode")
         return out
 
 
@@ -201,13 +202,15 @@ class HipClipTextEncoder:
         lib, w = L.load(), self._w
         m = self._causal(S)
         w.mask, w.mask_S = m.data_ptr(), _pad32(S)
-        ws = self._ws.get(lib.rf_clip_text_workspace_bytes(C.byref(w), S))
         ids32 = ids.to(torch.int32).contiguous()
         eos = self.eos_positions(ids)
         last = torch.empty(B, S, self.hidden, dtype=BF, device=self.device)
         pooled = torch.empty(B, self.hidden, dtype=BF, device=self.device)
-        for b in range(B):
-            L.check(lib.rf_clip_text_encode(C.byref(w), ids32[b].data_ptr(), S, int(eos[b]), last[b].data_ptr(), pooled[b].data_ptr(), C.byref(ws),
+        for b0 in range(0, B, 64):
+            nb = min(64, B - b0)
+            ws = self._ws.get(lib.rf_clip_text_workspace_bytes(C.byref(w), nb, S))
+            pos = (C.c_int32 * nb)(*[int(e) for e in eos[b0:b0 + nb]])
+            L.check(lib.rf_clip_text_encode(C.byref(w), ids32[b0].data_ptr(), nb, S, pos, last[b0].data_ptr(), pooled[b0].data_ptr(), C.byref(ws),
                                             stream_ptr()), "rf_clip_text_encode")
         return last, pooled
 

@@ -130,13 +130,19 @@ def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: F
 
 
 def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
-                          start_index: int = 0, verifier=None, score_batch=None) -> List[dict]:
+                          start_index: int = 0, verifier=None, score_batch=None, refine_prompt=None) -> List[dict]:
     """Reflection rounds.  Deliberate deviation from tts_reflectionflow.py:314-322: the reference's `generate`
     call passes neither `latents`, `num_inference_steps` nor `guidance_scale` (so its defaults -- 28 steps,
     guidance 3.5, noise from the global RNG -- apply and the `get_noises` seeds only name files, SURVEY 8a quirks);
     here the config's steps/guidance and the per-candidate seeded noise ARE passed, so that a candidate is a pure
     function of (prompt, round, index) and results do not depend on the world size.  Each prompt's
-    `search_log.jsonl` holds that prompt's rounds only; the return value is the concatenation over prompts."""
+    `search_log.jsonl` holds that prompt's rounds only; the return value is the concatenation over prompts.
+
+    `refine_prompt(prompt, round, candidate_index, seed) -> str` is the hook of the reference's reflection / prompt-refinement LLMs
+    (tts_reflectionflow.py:286-294: `refined + " [Reflexion]: " + reflection`, a different prompt per candidate and round; the LLMs
+    themselves are out of scope).  The prompts of a rank's candidates are encoded ONCE per round, de-duplicated, in one
+    batched `encode_prompt` call (T5-XXL + CLIP-L share their GEMM launches across the prompts), and handed to `generate` as
+    embeddings -- the reference encodes inside every generate() call."""
     pa, sa, model_cfg = config["pipeline_args"], config["search_args"], config.get("model", {})
     dev, dtype = pipe.device, pipe.dtype
     N, topk = sa["search_branch"], max(1, sa.get("topk", 1))
@@ -149,6 +155,13 @@ def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pip
             seeds = candidate_seeds(index + start_index, rnd, N)
 
             cond_of_kept: Dict[int, Condition] = {}   # one decode -> resize per kept latent and round, shared by its candidates
+            # this rank's prompts of the round: one batched text-encoder call over the distinct ones
+            mine = list(shard.mine(len(seeds)))
+            prompt_of = {i: (refine_prompt(prompt, rnd, i, seeds[i]) if refine_prompt is not None else prompt) for i in mine}
+            uniq = list(dict.fromkeys(prompt_of.values()))
+            if uniq:
+                pe_all, pooled_all, _ = pipe.encode_prompt(prompt=uniq, max_sequence_length=pa.get("max_sequence_length", 512))
+            slot = {p: k for k, p in enumerate(uniq)}
 
             def gen(i, seed):
                 noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seed])[seed]
@@ -161,7 +174,9 @@ def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pip
                     # RNG): a per-candidate generator makes the sample a function of the candidate's seed alone --
                     # world-size independent, and the search loop leaves the global CPU / GPU RNG state untouched
                     conds = [cond_of_kept[j].with_generator(torch.Generator(device="cpu").manual_seed(seed))]
-                lat = generate(pipe, prompt=[prompt], conditions=conds, height=pa["height"], width=pa["width"],
+                k = slot[prompt_of[i]]
+                lat = generate(pipe, prompt_embeds=pe_all[k:k + 1], pooled_prompt_embeds=pooled_all[k:k + 1], conditions=conds,
+                               height=pa["height"], width=pa["width"], max_sequence_length=pe_all.shape[1],
                                num_inference_steps=pa["num_inference_steps"], guidance_scale=pa["guidance_scale"],
                                latents=noise, model_config=model_cfg, default_lora=True, output_type="latent").images
                 _save(os.path.join(pdir, "samples", f"{rnd}_round@{seed}"), lat, pipe, pa["height"], pa["width"])

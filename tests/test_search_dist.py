@@ -72,6 +72,13 @@ def _fake_generate(pipe, prompt=None, conditions=None, latents=None, **kw):
 
 class _FakePipe:
     device, dtype, vae, image_processor = torch.device("cpu"), torch.float32, None, None
+    encode_calls = 0
+
+    def encode_prompt(self, prompt, max_sequence_length=512):
+        """the round's distinct prompts in ONE call (runner.run_reflection_search); embeddings = a function of the prompt text"""
+        type(self).encode_calls += 1
+        v = torch.tensor([[float(sum(p.encode()) % 97)] for p in prompt])
+        return v[:, None, :].expand(len(prompt), 8, 1).contiguous(), v, torch.zeros(8, 3)
 
 
 def _search_cfg():

@@ -118,6 +118,31 @@ def test_clip_text_encoder_vs_oracle(dev, vocab, hidden, heads, inter, layers, m
 
 
 @torch.no_grad()
+def test_a_batch_shares_the_launches_and_matches_single_sequences(dev):
+    """Five ragged sequences (S = 77 -> 96 rows each inside the library) in ONE call: every row matches the oracle, and the batched
+    result equals the one-by-one result to bf16 rounding (the GEMM schedule differs with the row count, so not bitwise)."""
+    from reflectionflow_amd.flux.text_hip import HipClipTextEncoder, HipT5Encoder
+    sd = bf16_round(TO.synthetic_t5_state(200, 256, 64, 4, 512, 2, seed=41))
+    ids = torch.randint(0, 200, (5, 77), generator=torch.Generator().manual_seed(42))
+    enc = HipT5Encoder(sd, 4, dev)
+    out = enc.encode(ids.to(dev))
+    one = torch.cat([enc.encode(ids[b:b + 1].to(dev)) for b in range(5)])
+    ref = TO.t5_encode(sd, ids, 4)
+    assert rel_l2(out, ref) < 2e-2 and rel_l2(out, one) < 5e-3
+    for b in range(5):
+        assert rel_l2(out[b], ref[b]) < 2.5e-2, b
+    csd = bf16_round(TO.synthetic_clip_state(128, 128, 2, 256, 2, 77, seed=43))
+    cids = torch.randint(3, 126, (5, 50), generator=torch.Generator().manual_seed(44))
+    for b in range(5):
+        cids[b, 10 + 7 * b:] = 127
+    cenc = HipClipTextEncoder(csd, 2, dev)
+    last, pooled = cenc.encode(cids.to(dev))
+    lref, pref = TO.clip_text_encode(csd, cids, 2)
+    assert rel_l2(last, lref) < 2e-2 and rel_l2(pooled, pref) < 2.5e-2
+    assert all(torch.equal(pooled[b], last[b, 10 + 7 * b]) for b in range(5))
+
+
+@torch.no_grad()
 def test_against_the_transformers_fixture_directly(dev):
     """HIP output vs the stored outputs of transformers' own fp32 modules (tests/golden/text_encoders.npz): t5_a, t5_b, clip_a."""
     from reflectionflow_amd.flux.text_hip import HipClipTextEncoder, HipT5Encoder
@@ -203,3 +228,34 @@ def test_pipeline_text_encoder_contract(dev):
     img = generate(pipe, prompt="a photo of a cat", model_config={}, height=64, width=64, num_inference_steps=2, max_sequence_length=64,
                    output_type="latent", generator=torch.Generator().manual_seed(1)).images
     assert torch.isfinite(img.float()).all()
+
+
+@torch.no_grad()
+def test_reflection_runner_encodes_a_rounds_prompts_in_one_batch(dev, tmp_path):
+    """run_reflection_search with a per-candidate `refine_prompt` hook (the reference's reflection LLM rewrites the prompt per candidate
+    and round, tts_reflectionflow.py:286-294): the rank's distinct prompts of a round go through the HIP text encoders in ONE batched
+    call per tower, not one call per candidate."""
+    from reflectionflow_amd.flux.pipeline import FluxPipeline
+    from reflectionflow_amd.tts import runner, search
+    calls = []
+
+    def tokenize(prompts, L):
+        calls.append((len(prompts), L))
+        t5_ids = torch.zeros(len(prompts), L, dtype=torch.long)
+        clip_ids = torch.full((len(prompts), 77), 127, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            b = [3 + (c % 100) for c in p.encode()][: min(L, 77) - 1]
+            t5_ids[i, : len(b)] = torch.tensor(b)
+            clip_ids[i, : len(b)] = torch.tensor(b)
+        return t5_ids, clip_ids
+    cfgt = dict(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64)
+    pipe = FluxPipeline.synthetic(cfgt, seed=0, torch_dtype=BF, device=dev)
+    pipe.enable_hip_text_encoders(TO.synthetic_t5_state(128, 256, 64, 4, 512, 2, seed=3), TO.synthetic_clip_state(128, 64, 1, 128, 2, 77, seed=4),
+                                  tokenize, t5_heads=4, clip_heads=1)
+    cfg = {"pipeline_args": dict(height=64, width=64, condition_size=32, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64),
+           "search_args": dict(search_branch=4, search_rounds=0, topk=1), "model": {}}
+    log = runner.run_reflection_search(cfg, ["a red cube"], str(tmp_path), pipe, search.Shard(0, 1),
+                                       refine_prompt=lambda p, rnd, i, seed: f"{p} [Reflexion]: variant {i % 2}")
+    assert len(log) == 1 and len(log[0]["scores"]) == 4
+    # one round, 4 candidates, 2 distinct prompts: exactly one T5 call and one CLIP call, each over the 2 distinct prompts
+    assert calls == [(2, 64), (2, 77)], calls

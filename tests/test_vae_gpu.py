@@ -173,7 +173,8 @@ def test_pipeline_call_sites_run_on_the_hip_vae(dev):
     batch = runner.decode_candidates(pipe, packed, 64, 64)      # (height / width name the FLUX geometry: 64 / 8 = 8 x 8 latents; this
                                                                 #  3-level test VAE scales by 4 -> 32 x 32 images)
     assert batch.shape == (2, 3, 32, 32) and batch.is_cuda and float(batch.min()) >= 0.0 and float(batch.max()) <= 1.0
-    assert rel_l2(batch[0], (img[0].float() / 2 + 0.5).clamp(0, 1)) < 1e-6
+    want = pipe.vae.decode((lat / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor).to(BF), return_dict=False)[0]   # generate.py:302-305
+    assert rel_l2(batch[0], (want[0].float() / 2 + 0.5).clamp(0, 1)) < 1e-6
     pil = pipe.image_processor.postprocess(img, output_type="pil")[0]
     cond = Condition("cot", condition=pil.resize((32, 32)), position_delta=[0, -2])
     tokens, ids, type_id = cond.with_generator(torch.Generator().manual_seed(1)).encode(pipe)

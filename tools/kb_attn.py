@@ -7,6 +7,7 @@ from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A
 from reflectionflow_amd import _lib, ops
 from tools.kbench import timeit
 dev = torch.device("cuda:0"); lib = _lib.load()
+lib.rf_debug_attn_mix(0)   # the plain one-size grids (the mixed-size launch is tools/kb_attn_mix.py's subject)
 for S in (4608, 5632, 17920):
     H = 24
     q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)

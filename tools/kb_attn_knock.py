@@ -6,7 +6,7 @@ from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A
 from reflectionflow_amd import _lib, ops
 from tools.kbench import timeit
 dev = torch.device("cuda:0"); lib = _lib.load()
-lib.rf_debug_attn_v2(1); lib.rf_debug_attn_sk(0); lib.rf_debug_attn_v5(1)
+lib.rf_debug_attn_v2(1); lib.rf_debug_attn_sk(0); lib.rf_debug_attn_v5(1); lib.rf_debug_attn_mix(0)
 for S in (4608, 17920):
     H = 24
     q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
@@ -21,4 +21,4 @@ for S in (4608, 17920):
             mhz, us = C.c_double(0), C.c_double(0)
             lib.rf_debug_clock_probe(1, C.byref(mhz), C.byref(us))
             print(f"S={S} {name:28s} {t*1e6:8.1f} us {4.0*S*S*H*128/t/1e12:7.1f} TF @{mhz.value:5.0f} MHz  block 0 loop {us.value:7.1f} us = {us.value*mhz.value/(S//64):6.0f} clocks per key tile", flush=True)
-lib.rf_debug_attn_knock(0); lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v5(-1)
+lib.rf_debug_attn_knock(0); lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v5(-1); lib.rf_debug_attn_mix(-1)
