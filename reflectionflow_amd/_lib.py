@@ -201,7 +201,7 @@ _EXP_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2
              "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
              "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_attn_knock": (C.c_int, [C.c_int]),
              "rf_debug_attn_v6": (C.c_int, [C.c_int]), "rf_debug_attn_lag": (C.c_int, [C.c_int]),
-             "rf_debug_attn_stamps": (C.c_int, [C.c_void_p]), "rf_debug_attn_mix": (C.c_int, [C.c_int]),
+             "rf_debug_attn_stamps": (C.c_int, [C.c_void_p]), "rf_debug_attn_mix": (C.c_int, [C.c_int]), "rf_debug_attn_v7": (C.c_int, [C.c_int]), "rf_debug_attn_stamps7": (C.c_int, [C.c_void_p]),
              "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
              "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]), "rf_debug_gemm_mi16": (C.c_int, [C.c_int]),
              "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]),

@@ -512,6 +512,7 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 __device__ unsigned long long g_attn_clk_probe[4];   // see ClkProbe (common.hpp)
 #ifdef RF_EXPERIMENTS
 __device__ unsigned long long g_attn_stamps[8][8];   // VAR & 16: s_memtime of block 0's waves around the halves of key tile 40
+__device__ unsigned long long g_attn_stamps7[8][16];  // v7: at the phase boundaries of key tile 40
 #endif
 
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
@@ -1278,6 +1279,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p,
   else attn5_body<false, LAG, 0, 1, true>(p, smem, tid, lane, w, head, q0 + 128 + (w - 4) * 16, 0, p.S / ATT_KV, nullptr, clk);
 }
 
+#ifdef RF_EXPERIMENTS
+#include "experiments/attention_v7_exp.inc"
+#endif
+
 // Sizes of the mixed launch for `units` = S / 16 q-tiles per head: units = 16 a + 12 b.  Greedy in-order dispatch of the a * heads
 // big workgroups, then the b * heads small ones, onto P CUs, with a small workgroup costing `small_cost` of a big one (measured
 // 0.75-0.8); returns the makespan in big-workgroup units and the best (a, b), or a = units / 16, b = 0 if nothing beats the
@@ -1420,6 +1425,7 @@ int read_clk_probe_attn(unsigned long long* h) {
 }
 
 // Kernel-selection knobs: compile-time constants in librf_flux.so; mutable (rf_debug_*) in the experiments build only.
+#define RF_ATT_V7_DEFAULT 0
 struct AttnTuning {
   int v2;      // -1 = cost model between v1 and v2, 0 / 1 = forced
   int v4;      // 1 = the shift-free kernels may run, 0 = never
@@ -1434,11 +1440,12 @@ struct AttnTuning {
   int sk;      // split launch: -1 = heuristic, 0 = never, 1 = whenever possible
   int lag;     // -1 = lagged-max kernel only without a usable bound, 0 = never, 1 = always
   int mix;     // mixed-size launch: -1 = when the dispatch simulation predicts >= 4 %, 0 = never
+  int v7;      // 1 = the ping-pong schedule (attn7_body) for the whole-key-axis launches of the 16x16x32 kernels, 0 = v5's
 };
 #ifdef RF_EXPERIMENTS
-static AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1};
+static AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
 #else
-static constexpr AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1};
+static constexpr AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
 #endif
 static int g_last_attn_path = 0;
 
@@ -1457,6 +1464,10 @@ extern "C" int rf_debug_attn_knock(int k) { rf::g_at.knock = k; return RF_OK; }
 extern "C" int rf_debug_attn_sk(int mode) { rf::g_at.sk = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
 extern "C" int rf_debug_attn_lag(int mode) { rf::g_at.lag = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
 extern "C" int rf_debug_attn_mix(int mode) { rf::g_at.mix = mode < 0 ? -1 : 0; return RF_OK; }
+extern "C" int rf_debug_attn_v7(int on) { rf::g_at.v7 = on ? 1 : 0; return RF_OK; }
+extern "C" int rf_debug_attn_stamps7(unsigned long long* out128) {   // [8 waves][16]
+  return hipMemcpyFromSymbol(out128, HIP_SYMBOL(rf::g_attn_stamps7), 128 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
+}
 extern "C" int rf_debug_attn_stamps(unsigned long long* out64) {   // [8 waves][8]
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(rf::g_attn_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
 }
@@ -1520,7 +1531,16 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
 #ifdef RF_EXPERIMENTS
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7mix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+#endif
+#ifdef RF_EXPERIMENTS
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v6, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7k<48>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7k<80>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
@@ -1638,6 +1658,10 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       g_last_attn_path = 9;
       break;
     case RF_ATTN_LAGGED16:
+#ifdef RF_EXPERIMENTS
+      if (g_at.v7) hipLaunchKernelGGL(attn_fwd_kernel_v7<true>, grid2, blk, ATT4_LDS, st, p);
+      else
+#endif
       hipLaunchKernelGGL(attn_fwd_kernel_v5<true>, grid2, blk, ATT4_LDS, st, p);
       g_last_attn_path = 8;
       break;
@@ -1651,6 +1675,12 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       mx.n_big = a * heads;
       mx.big_per_head = a;
       const dim3 gridm((a + b) * heads);
+#ifdef RF_EXPERIMENTS
+      if (g_at.v7) {
+        if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v7mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
+        else hipLaunchKernelGGL(attn_fwd_kernel_v7mix<false>, gridm, blk, ATT4_LDS, st, p, mx);
+      } else
+#endif
       if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v5mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
       else hipLaunchKernelGGL(attn_fwd_kernel_v5mix<false>, gridm, blk, ATT4_LDS, st, p, mx);
       g_last_attn_path = kern == RF_ATTN_LAGGED16_MIX ? 11 : 10;
@@ -1661,6 +1691,13 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       if (g_at.v6 && !g_at.knock) {
         hipLaunchKernelGGL(attn_fwd_kernel_v6, grid2, dim3(256), ATT4_LDS, st, p);
         g_last_attn_path = 7;
+        break;
+      }
+      if (g_at.v7 && (g_at.knock == 16 || g_at.knock == 48 || g_at.knock == 80)) {
+        if (g_at.knock == 16) hipLaunchKernelGGL(attn_fwd_kernel_v7k<16>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 48) hipLaunchKernelGGL(attn_fwd_kernel_v7k<48>, grid2, blk, ATT4_LDS, st, p);
+        else hipLaunchKernelGGL(attn_fwd_kernel_v7k<80>, grid2, blk, ATT4_LDS, st, p);
+        g_last_attn_path = 5;
         break;
       }
       if (g_at.knock) {
@@ -1685,6 +1722,10 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
         g_last_attn_path = 5;
         break;
       }
+#endif
+#ifdef RF_EXPERIMENTS
+      if (g_at.v7) hipLaunchKernelGGL(attn_fwd_kernel_v7<false>, grid2, blk, ATT4_LDS, st, p);
+      else
 #endif
       hipLaunchKernelGGL(attn_fwd_kernel_v5<false>, grid2, blk, ATT4_LDS, st, p);
       g_last_attn_path = 5;

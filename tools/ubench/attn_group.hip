@@ -30,10 +30,12 @@ __global__ __launch_bounds__(512) void group_kernel(int iters, float* sink, unsi
         a[0] = *(const bf16x8*)(rd + G * 4096);
         a[1] = *(const bf16x8*)(rd + G * 4096 + 2048);
       }
+      if constexpr ((VAR & 16) == 0) {   // (16: no MFMAs -- what the VALU work costs alone)
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
+        for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) acc[G][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[bb], b[bb * 2 + q], acc[G][q], 0, 0, 0);
+          for (int q = 0; q < 2; ++q) acc[G][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[bb], b[bb * 2 + q], acc[G][q], 0, 0, 0);
+      }
       if constexpr ((VAR & 1) != 0) {   // 4 exp2
         float e[4];
 #pragma unroll
@@ -69,7 +71,7 @@ extern "C" int attn_group_run(int var, int threads, int blocks, int iters, float
   hipStream_t st = (hipStream_t)stream;
 #define RUN(V) case V: hipLaunchKernelGGL(group_kernel<V>, dim3(blocks), dim3(threads), 0, st, iters, sink, clk); break;
   switch (var) {
-    RUN(0) RUN(1) RUN(3) RUN(4) RUN(8) RUN(9) RUN(11) RUN(12) RUN(2)
+    RUN(0) RUN(1) RUN(3) RUN(4) RUN(8) RUN(9) RUN(11) RUN(12) RUN(2) RUN(17) RUN(19) RUN(20)
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -11,10 +11,11 @@ dev = torch.device("cuda:0")
 sink = torch.zeros(256 * 512, device=dev); clk = torch.zeros(2, dtype=torch.int64, device=dev)
 ITERS = 2000
 names = {0: "4 MFMA", 1: "+ 4 exp2", 3: "+ 4 exp2 + 4 adds (= F without reads)", 4: "+ 2 cvt_pk (= G without reads)", 8: "+ 2 ds_read_b128",
-         9: "+ 2 reads + 4 exp2", 11: "+ 2 reads + 4 exp2 + 4 adds (= F)", 12: "+ 2 reads + 2 cvt_pk (= G)"}
-for blocks in (1, 256):
+         9: "+ 2 reads + 4 exp2", 11: "+ 2 reads + 4 exp2 + 4 adds (= F)", 12: "+ 2 reads + 2 cvt_pk (= G)",
+         17: "NO MFMA: 4 exp2 alone", 19: "NO MFMA: 4 exp2 + 4 adds", 20: "NO MFMA: 2 cvt_pk"}
+for blocks in (1,):
     for threads in (256, 512):
-        for var in (0, 1, 3, 4, 8, 9, 11, 12):
+        for var in (0, 1, 3, 4, 8, 9, 11, 12, 17, 19, 20):
             for _ in range(2):
                 assert lib.attn_group_run(var, threads, blocks, ITERS, sink.data_ptr(), clk.data_ptr(), None) == 0
             torch.cuda.synchronize()
