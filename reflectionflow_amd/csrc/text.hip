@@ -122,6 +122,7 @@ static inline int ta_lds_bytes(int S_pad) { return S_pad * 128 + 64 * (S_pad * 2
 // column = key), bias [.][S_pad][S_pad] fp32 with head stride bias_hs (0: shared by the heads) or NULL, out [S][ldo].
 // scores = scale * q.k + bias; S_pad % 32 == 0; rows / keys >= S must be masked by the bias (-inf) and are not written.
 // blockIdx.z = sequence: its rows of q / k / out start at z * S_pad, its columns of vt at z * S_pad (out: z * S_pad as well).
+template <int QI>   // query tiles per wave: a workgroup stages K / V^T once for 64 * QI queries
 __global__ __launch_bounds__(256) void attn64_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
                                                      const bf16_t* __restrict__ vt, int64_t ldvt, const float* __restrict__ bias, int64_t bias_hs,
                                                      bf16_t* __restrict__ out, int64_t ldo, int S, int S_pad, float scale) {
@@ -157,15 +158,18 @@ __global__ __launch_bounds__(256) void attn64_kernel(const bf16_t* __restrict__ 
     *(u32x2*)(dst + (8 * (g0 + 1) + 4 * tile) * 2) = hi;
   }
   __syncthreads();
+  const int nt = S_pad >> 4;
+  const float LOG2E = 1.4426950408889634f;
+  const float sl2 = scale * LOG2E;
+#pragma unroll 1
+  for (int it = 0; it < QI; ++it) {
   // ---- scores: S^T tile t = K[16t .. 16t+15] Q^T: this lane holds keys 16t + 4g + r of query l15 ---------------------------------
-  const int q_row = qb * 64 + w * 16 + l15;
+  const int q_row = (qb * QI + it) * 64 + w * 16 + l15;
+  if ((qb * QI + it) * 64 >= S_pad) break;
   const int q_ld = q_row < S_pad ? q_row : S_pad - 1;
   bf16x8 qf[2];
 #pragma unroll
   for (int ds = 0; ds < 2; ++ds) qf[ds] = *(const bf16x8*)(q + (int64_t)q_ld * ldq + head * 64 + ds * 32 + g * 8);
-  const int nt = S_pad >> 4;
-  const float LOG2E = 1.4426950408889634f;
-  const float sl2 = scale * LOG2E;
   const float* brow = bias ? bias + head * bias_hs + (int64_t)q_ld * S_pad + 4 * g : nullptr;
   f32x4 s[TA_NT];
   float mx = -__builtin_huge_valf();
@@ -229,6 +233,7 @@ __global__ __launch_bounds__(256) void attn64_kernel(const bf16_t* __restrict__ 
       *(u32x2*)(orow + dt * 16) = v;
     }
   }
+  }   // it
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
@@ -296,12 +301,20 @@ static int text_attention(TextCtx& c, int heads, int inner, const float* bias, i
   const int lds = ta_lds_bytes(c.S_pad);
   static bool attr = false;
   if (!attr) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes(TA_MAXS)));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes(TA_MAXS)));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ta_lds_bytes(TA_MAXS)));
     attr = true;
   }
+  // a workgroup stages the head's K and V^T (2 x 64 KiB at 512 keys) for its queries: with enough (head, sequence) pairs to fill the
+  // CUs it takes 256 queries instead of 64 and stages a quarter as often
+  const bool wide = (int64_t)heads * c.B * cdiv(c.S_pad, 256) >= 256;
   ProfScope prof(RF_KC_ATTN, 4.0 * (double)c.S_pad * c.S_pad * 64.0 * heads * c.B, c.st);
-  hipLaunchKernelGGL(attn64_kernel, dim3(cdiv(c.S_pad, 64), heads, c.B), dim3(256), lds, c.st, c.QK, (int64_t)2 * inner, c.QK + inner, (int64_t)2 * inner,
-                     c.VT, (int64_t)c.B * c.S_pad, bias, bias_hs, c.AO, (int64_t)inner, c.S, c.S_pad, scale);
+  if (wide)
+    hipLaunchKernelGGL(attn64_kernel<4>, dim3(cdiv(c.S_pad, 256), heads, c.B), dim3(256), lds, c.st, c.QK, (int64_t)2 * inner, c.QK + inner, (int64_t)2 * inner,
+                       c.VT, (int64_t)c.B * c.S_pad, bias, bias_hs, c.AO, (int64_t)inner, c.S, c.S_pad, scale);
+  else
+    hipLaunchKernelGGL(attn64_kernel<1>, dim3(cdiv(c.S_pad, 64), heads, c.B), dim3(256), lds, c.st, c.QK, (int64_t)2 * inner, c.QK + inner, (int64_t)2 * inner,
+                       c.VT, (int64_t)c.B * c.S_pad, bias, bias_hs, c.AO, (int64_t)inner, c.S, c.S_pad, scale);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }

@@ -131,6 +131,12 @@ def test_a_batch_shares_the_launches_and_matches_single_sequences(dev):
     assert rel_l2(out, ref) < 2e-2 and rel_l2(out, one) < 5e-3
     for b in range(5):
         assert rel_l2(out[b], ref[b]) < 2.5e-2, b
+    # 16 x 512 tokens x 8 heads: enough (head, sequence) pairs for the attention kernel's 256-query workgroups (K / V^T staged once per 256 queries)
+    sd2 = bf16_round(TO.synthetic_t5_state(100, 512, 64, 8, 1024, 1, seed=45))
+    ids2 = torch.randint(0, 100, (16, 512), generator=torch.Generator().manual_seed(46))
+    enc2 = HipT5Encoder(sd2, 8, dev)
+    out2 = enc2.encode(ids2.to(dev))
+    assert rel_l2(out2, TO.t5_encode(sd2, ids2, 8)) < 1.5e-2 and rel_l2(out2[3:4], enc2.encode(ids2[3:4].to(dev))) < 5e-3
     csd = bf16_round(TO.synthetic_clip_state(128, 128, 2, 256, 2, 77, seed=43))
     cids = torch.randint(3, 126, (5, 50), generator=torch.Generator().manual_seed(44))
     for b in range(5):
