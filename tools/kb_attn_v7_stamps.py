@@ -25,5 +25,8 @@ for label, kn in (("v7", 16), ("v7, no DMA after tile 3 (knock-out)", 48), ("v7,
     for w in range(8):
         st = [buf[w * 16 + i] for i in range(9)]
         d = [int(st[i + 1]) - int(st[i]) for i in range(8)]
-        print(f"  wave {w}: " + "  ".join(f"{x:7d}" for x in d) + f"   | {int(st[8]) - int(st[0]):5d} | {int(st[0]) - int(base):+d}", flush=True)
+        x = [int(buf[w * 16 + i]) for i in range(14)]
+        print(f"  wave {w}: " + "  ".join(f"{v:7d}" for v in d) + f"   | {int(st[8]) - int(st[0]):5d} | {int(st[0]) - int(base):+d}"
+              f"   || M2 issue {x[9] - x[4]:4d} + barrier {x[5] - x[9]:4d} | O2: reads {x[10] - x[5]:4d}, exp2+sums {x[11] - x[10]:4d}, tail {x[12] - x[11]:4d}, barrier {x[6] - x[12]:4d}"
+              f" | M3 issue {x[13] - x[6]:4d} + barrier {x[7] - x[13]:4d}", flush=True)
 lib.rf_debug_attn_knock(0); lib.rf_debug_attn_v7(0); lib.rf_debug_attn_v2(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v5(-1)
