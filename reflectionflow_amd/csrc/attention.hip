@@ -809,7 +809,7 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
 // VAR (experiments; 1 and 2 give wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing, 4 = fragment
 // reads ONE group ahead of their MFMAs instead of two (32 = three), 8 = 8-byte epilogue stores, 16 = s_memtime stamps around the
 // halves of key tile 40 (rf_debug_attn_stamps)
-template <bool PROBE, bool LAG, int KNOCK = 0, int NQT = 2, bool ROT = false>
+template <bool PROBE, bool LAG, int KNOCK = 0, int NQT = 2, bool ROT = false, int DMA = 1>
 __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
                                            const int head, const int q0w, const int t0, const int nt, float* partial, ClkProbe& clk) {
   const int l15 = lane & 15, g = lane >> 4;
@@ -831,25 +831,44 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *(const bf16x8*)(qp + ds * 32);
   }
-  // DMA pieces: 2 of the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each) per wave
-  uint32_t k_src[2], v_src[2];
+  // DMA pieces: the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each).  DMA = 1: every wave issues 2 + 2 of
+  // them; DMA = 2: this wave issues 4 + 4 (waves 0-3 of a workgroup whose waves 4-7 run with DMA = 0 and issue none).  The SIMD's
+  // arbiter lets the older wave of a pair run ahead; it then WAITS ~1000 clocks per tile at the barrier for its partner (tile stamps,
+  // DESIGN K3M), so the ~60-clock issue of a piece is free there and on the critical path in the partner.
+  constexpr int NPC = DMA == 2 ? 4 : (DMA == 1 ? 2 : 0), PSTR = DMA == 2 ? 4 : 8;   // pieces per tile of this wave; piece = i * PSTR + (w % PSTR)
+  uint32_t k_src[NPC > 0 ? NPC : 1], v_src[NPC > 0 ? NPC : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + w) * 4 + (lane >> 4);
+  for (int i = 0; i < NPC; ++i) {
+    const int pc = i * PSTR + (w % PSTR);
+    const int row = pc * 4 + (lane >> 4);
     const int ksw = (row & 7) | ((row >> 1) & 8);
     k_src[i] = (uint32_t)(row * 256 + (((lane & 15) ^ ksw) * 16));
-    const int vrow = (i * 8 + w) * 8 + (lane >> 3);
+    const int vrow = pc * 8 + (lane >> 3);
     v_src[i] = (uint32_t)((vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
   }
   auto issue_k = [&](int t, int slot) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 8 + w) * 1024), k_src[i], (t0 + t) * (ATT_KV * 256));
+    for (int i = 0; i < NPC; ++i)
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * PSTR + (w % PSTR)) * 1024), k_src[i], (t0 + t) * (ATT_KV * 256));
   };
   auto issue_v = [&](int t, int slot) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 8 + w) * 1024), v_src[i], (t0 + t) * (128 * 64 * 2));
+    for (int i = 0; i < NPC; ++i)
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * PSTR + (w % PSTR)) * 1024), v_src[i], (t0 + t) * (128 * 64 * 2));
+  };
+  // counted waits: `n` issue calls (K or V^T tiles) may stay in flight = n * NPC instructions of THIS wave
+  auto wait_barrier = [&](const int n) {
+    if constexpr (NPC == 0) {
+      __builtin_amdgcn_s_barrier();
+    } else if constexpr (NPC == 2) {
+      RF_ATT4_WAIT_BARRIER(2 * n);
+    } else {
+      if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   };
   // fragment read addresses: 4 (K, per d step) + 2 (V^T, per 32-key block) per-lane registers; ring slot, key block,
   // T tile (+8 rows) and d tile are immediates.  K row of MFMA row l15 in tile T0: (l15 & 7) | ((l15 & 8) << 1).
@@ -891,7 +910,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   if (nt > 2) issue_k(2, 2);
   issue_v(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill above
-  RF_ATT4_WAIT_BARRIER(2 * ((nt > 1) + (nt > 2) + 1));   // K0 landed
+  wait_barrier((nt > 1) + (nt > 2) + 1);   // K0 landed
 #pragma unroll
   for (int bt = 0; bt < 4; ++bt) {   // (b, T) = (bt >> 1, bt & 1)
 #pragma unroll
@@ -963,7 +982,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     };
     stamp(0);
     // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t)
-    RF_ATT4_WAIT_BARRIER(2 * ((t + 2 < nt) + 1));
+    wait_barrier((t + 2 < nt) + 1);
     stamp(1);
     if (t + 3 < nt) issue_k(t + 3, (TS + 3) % 4);
     if (t + 1 < nt) issue_v(t + 1, (TS + 1) % 4);
@@ -1190,7 +1209,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 
   if (PROBE) clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
-  RF_ATT4_WAIT_BARRIER(0);
+  wait_barrier(0);
   if constexpr (ROT) {   // the rotated order has not packed P(nt-1) yet
 #pragma unroll
     for (int ti = 0; ti < 4 * NQT; ++ti) {
@@ -1228,6 +1247,10 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   attn5_finish<NQT, (KNOCK & 8) != 0>(p, oacc, l_run, lane, head, q0w);
 }
 
+// The variant the product kernels run (the VAR bits of attn5_body): wave priority scheme 2 -- s_setprio 2 in G (scores + packing), 0 in F
+// (PV + exp2) -- worth 1.8 % on top of the DMA distribution (208.3 -> 204.6 us at S = 4608, profiles/r03_kb_attn_stamps_v7.log).
+constexpr int ATT5_VAR = 256;
+
 template <bool LAG>
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1239,8 +1262,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   // waves w and w + 4 share a SIMD: the second one runs the halves of an interval in the rotated order, so that one of the pair is in
   // its exp2-heavy half while the other is in its MFMA-only half (see attn5_body)
   const int head = blockIdx.x % p.heads, q0w = (int)(blockIdx.x / p.heads) * 256 + w * 32;
-  if (w < 4) attn5_body<true, LAG, 0, 2, false>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
-  else attn5_body<false, LAG, 0, 2, true>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
+  if (w < 4) attn5_body<true, LAG, ATT5_VAR, 2, false, 2>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
+  else attn5_body<false, LAG, ATT5_VAR, 2, true, 0>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
 }
 
 #ifdef RF_EXPERIMENTS
@@ -1274,9 +1297,9 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p,
   const int b2 = big ? b : b - mx.n_big;
   const int head = b2 % p.heads;
   const int q0 = big ? (b2 / p.heads) * 256 : mx.big_per_head * 256 + (b2 / p.heads) * 192;
-  if (w < 4) attn5_body<true, LAG, 0, 2, false>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
-  else if (big) attn5_body<false, LAG, 0, 2, true>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
-  else attn5_body<false, LAG, 0, 1, true>(p, smem, tid, lane, w, head, q0 + 128 + (w - 4) * 16, 0, p.S / ATT_KV, nullptr, clk);
+  if (w < 4) attn5_body<true, LAG, ATT5_VAR, 2, false, 2>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+  else if (big) attn5_body<false, LAG, ATT5_VAR, 2, true, 0>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+  else attn5_body<false, LAG, ATT5_VAR, 1, true, 0>(p, smem, tid, lane, w, head, q0 + 128 + (w - 4) * 16, 0, p.S / ATT_KV, nullptr, clk);
 }
 
 #ifdef RF_EXPERIMENTS
@@ -1368,8 +1391,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5sk(const AttnParams p, 
     // across the loop and spill)
     int tid_i = tid;
     asm volatile("" : "+v"(tid_i));
-    if (w < 4) attn5_body<false, LAG, 0, 2, false>(p, smem, tid_i, tid_i & 63, w, head, qb * 256 + w * 32, 4 * q0, 4 * len, partial, clk);
-    else attn5_body<false, LAG, 0, 2, true>(p, smem, tid_i, tid_i & 63, w, head, qb * 256 + w * 32, 4 * q0, 4 * len, partial, clk);
+    if (w < 4) attn5_body<false, LAG, ATT5_VAR, 2, false, 2>(p, smem, tid_i, tid_i & 63, w, head, qb * 256 + w * 32, 4 * q0, 4 * len, partial, clk);
+    else attn5_body<false, LAG, ATT5_VAR, 2, true, 0>(p, smem, tid_i, tid_i & 63, w, head, qb * 256 + w * 32, 4 * q0, 4 * len, partial, clk);
     cur += len;
   }
 }
@@ -1552,13 +1575,17 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<256>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<384>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<512>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<640>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<768>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<144>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<272>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<400>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1040>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<512>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<528>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
 #endif
     attr_set = true;
   }
@@ -1712,12 +1739,15 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
         else if (g_at.knock == 128) hipLaunchKernelGGL(attn_fwd_kernel_v5k<128>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 256) hipLaunchKernelGGL(attn_fwd_kernel_v5k<256>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 384) hipLaunchKernelGGL(attn_fwd_kernel_v5k<384>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 512) hipLaunchKernelGGL(attn_fwd_kernel_v5k<512>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 1024) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1024>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 640) hipLaunchKernelGGL(attn_fwd_kernel_v5k<640>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 768) hipLaunchKernelGGL(attn_fwd_kernel_v5k<768>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 144) hipLaunchKernelGGL(attn_fwd_kernel_v5k<144>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 272) hipLaunchKernelGGL(attn_fwd_kernel_v5k<272>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 400) hipLaunchKernelGGL(attn_fwd_kernel_v5k<400>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 1024) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1024>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 1040) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1040>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 528) hipLaunchKernelGGL(attn_fwd_kernel_v5k<528>, grid2, blk, ATT4_LDS, st, p);
         else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;
         break;
