@@ -196,7 +196,7 @@ typedef enum rf_attn_kernel {
   RF_ATTN_AUTO = 0,
   RF_ATTN_ONLINE128 = 1,        /* online softmax, 4 waves x 32 queries (masks, bias, ragged S)            */
   RF_ATTN_ONLINE256 = 2,        /* online softmax, 8 waves x 32 queries, K / VT rings                      */
-  RF_ATTN_BOUNDED32 = 4,        /* bounded score, 32x32x16 MFMAs (AUTO picks it at >= 8192 keys)           */
+  RF_ATTN_BOUNDED32 = 4,        /* bounded score, 32x32x16 MFMAs (explicit requests only since round 3)    */
   RF_ATTN_BOUNDED16 = 5,        /* bounded score, 16x16x32 MFMAs                                           */
   RF_ATTN_BOUNDED16_SPLIT = 6,  /* ... as one persistent workgroup per CU + combine launch (needs ws)      */
   RF_ATTN_LAGGED16 = 8,         /* lagged-max, 16x16x32 MFMAs: no bound needed                             */

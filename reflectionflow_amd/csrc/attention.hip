@@ -541,24 +541,38 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
-  // DMA pieces: 2 of the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each) per wave
-  uint32_t k_src[2], v_src[2];
+  // DMA pieces: the 16 x 1 KiB pieces of a K tile (4 rows each) and of a V^T tile (8 rows each).  Waves 0-3 issue ALL of them (4 + 4
+  // each), waves 4-7 none: the SIMD's arbiter lets the older wave of a pair run ahead and it then waits ~1000 clocks per tile at the
+  // barrier (tile stamps of v5, DESIGN K3M) -- the ~60-clock issue of a piece is free there and on the critical path in its partner.
+  const bool dma_owner = w < 4;
+  uint32_t k_src[4], v_src[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (i * 8 + w) * 4 + (lane >> 4);
+  for (int i = 0; i < 4; ++i) {
+    const int pc = i * 4 + (w & 3);
+    const int row = pc * 4 + (lane >> 4);
     k_src[i] = (uint32_t)(row * 256 + (((lane & 15) ^ (row & 15)) * 16));
-    const int vrow = (i * 8 + w) * 8 + (lane >> 3);
+    const int vrow = pc * 8 + (lane >> 3);
     v_src[i] = (uint32_t)((vrow * 64 + (((lane & 7) ^ ((vrow >> 1) & 7)) * 8)) * 2);
   }
   auto issue_k = [&](int t, int slot) {
+    if (!dma_owner) return;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 8 + w) * 1024), k_src[i], t * (ATT_KV * 256));
+    for (int i = 0; i < 4; ++i)
+      RF_BUF_LOAD_LDS(rsK, (lds_void*)(kring + slot * 16384 + (i * 4 + (w & 3)) * 1024), k_src[i], t * (ATT_KV * 256));
   };
   auto issue_v = [&](int t, int slot) {
+    if (!dma_owner) return;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 8 + w) * 1024), v_src[i], t * (128 * 64 * 2));
+    for (int i = 0; i < 4; ++i)
+      RF_BUF_LOAD_LDS(rsV, (lds_void*)(vring + slot * 16384 + (i * 4 + (w & 3)) * 1024), v_src[i], t * (128 * 64 * 2));
+  };
+  // counted wait + barrier: n issue calls (4 instructions each in an owner wave, none elsewhere) may stay in flight
+  auto wait_barrier = [&](const int n) {
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   };
   // fragment read addresses: 8 (K, per k-step) + 4 (V^T, per key step) per-lane registers; ring slot, key block and
   // d block are immediates
@@ -593,7 +607,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
   if (nt > 2) issue_k(2, 2);
   issue_v(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero fill above
-  RF_ATT4_WAIT_BARRIER(2 * ((nt > 1) + (nt > 2) + 1));   // K0 landed
+  wait_barrier((nt > 1) + (nt > 2) + 1);   // K0 landed
 #pragma unroll
   for (int kvb = 0; kvb < 2; ++kvb) {
 #pragma unroll
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
     constexpr int TS = decltype(ts_tag)::value;
     constexpr int KSLOT = (TS + 1) % 4, VSLOT = (TS + 3) % 4;
     // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t)
-    RF_ATT4_WAIT_BARRIER(2 * ((t + 2 < nt) + 1));
+    wait_barrier((t + 2 < nt) + 1);
     if (t + 3 < nt) issue_k(t + 3, (TS + 3) % 4);
     if (t + 1 < nt) issue_v(t + 1, KSLOT);
     __builtin_amdgcn_sched_barrier(0);
@@ -690,7 +704,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
 
   clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
-  RF_ATT4_WAIT_BARRIER(0);
+  wait_barrier(0);
   {
     const int vslot = (nt - 1) % ATT4_RING;
 #pragma unroll
@@ -1452,12 +1466,11 @@ int read_clk_probe_attn(unsigned long long* h) {
 struct AttnTuning {
   int v2;      // -1 = cost model between v1 and v2, 0 / 1 = forced
   int v4;      // 1 = the shift-free kernels may run, 0 = never
-  int v5;      // MFMA shape of the bounded kernel: 1 = 16x16x32 (v5), 0 = 32x32x16 (v4), -1 = by size: v5 below 8192 keys.
-               // In isolation v5 is faster at every length (+0.5 % at 4608 ... +4.6 % at 17920), but it also runs the chip
-               // at 2.0 instead of 1.75 GHz, and inside a forward that costs the neighbouring GEMMs their clock:
-               // interleaved in-sequence A/B (tools/bench_cfg5.py --ab-attn): S = 4608: attention 13.46 vs 13.40 ms and
-               // GEMMs 47.6 vs 48.0 ms per forward with v5 vs v4 (v5 +0.6 % overall); S = 17920: attention 189.5 vs 187.6
-               // and GEMMs 186.6 vs 183.5 ms (v5 -1.3 % overall).
+  int v5;      // MFMA shape of the bounded kernel: 1 = 16x16x32 (v5; shipped at every length), 0 = 32x32x16 (v4), -1 = by size: v5 below
+               // 8192 keys.  Round 2 shipped -1: v5 ran the chip at 2.0 instead of 1.75 GHz and at S = 17920 that cost the neighbouring
+               // GEMMs more than it won (189.5 + 186.6 vs 187.6 + 183.5 ms per forward).  With the DMA pieces issued by the waves
+               // that wait (round 3) both kernels got faster, v5 more: in sequence at S = 17920 attention 169.3 vs 175.9 ms and
+               // GEMMs 181.5 vs 179.3 ms per forward (profiles/r03_ab_attn_cfg5.log): v5 is 1.2 % ahead overall, 53.2 % of peak.
   int v6;      // experiments: one wave per SIMD form
   int knock;   // experiments: timing knock-outs
   int sk;      // split launch: -1 = heuristic, 0 = never, 1 = whenever possible
@@ -1466,9 +1479,9 @@ struct AttnTuning {
   int v7;      // 1 = the ping-pong schedule (attn7_body) for the whole-key-axis launches of the 16x16x32 kernels, 0 = v5's
 };
 #ifdef RF_EXPERIMENTS
-static AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
+static AttnTuning g_at = {-1, 1, 1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
 #else
-static constexpr AttnTuning g_at = {-1, 1, -1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
+static constexpr AttnTuning g_at = {-1, 1, 1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
 #endif
 static int g_last_attn_path = 0;
 

@@ -193,7 +193,7 @@ def test_attention_bounded_score_kernel(dev, S, H):
     lib = _lib.load()
     o4 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
     # (5 = plain grid, 10 = the mixed-size grid of the same kernel, taken when its dispatch simulation predicts >= 4 %)
-    assert lib.rf_debug_last_attn_path() in ((5, 10) if S < 8192 else (4,)), "AUTO with a proven bound must take the bounded kernel"
+    assert lib.rf_debug_last_attn_path() in (5, 10), "AUTO with a proven bound must take the bounded kernel"
     o4b = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, scratch=False)
     o2 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound, kernel=_lib.RF_ATTN_ONLINE256)
     assert lib.rf_debug_last_attn_path() == 2
