@@ -1297,7 +1297,7 @@ struct AttnMixParams {
   int big_per_head;
 };
 
-template <bool LAG>
+template <bool LAG, int MIX_SMALL_DMA_A = 0>   // 192-query workgroups: 0 = waves 4-7 issue the DMA pieces (shipped), 2 = waves 0-3 (experiments)
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p, const AttnMixParams mx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
@@ -1311,9 +1311,15 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p,
   const int b2 = big ? b : b - mx.n_big;
   const int head = b2 % p.heads;
   const int q0 = big ? (b2 / p.heads) * 256 : mx.big_per_head * 256 + (b2 / p.heads) * 192;
-  if (w < 4) attn5_body<true, LAG, ATT5_VAR, 2, false, 2>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
-  else if (big) attn5_body<false, LAG, ATT5_VAR, 2, true, 0>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
-  else attn5_body<false, LAG, ATT5_VAR, 1, true, 0>(p, smem, tid, lane, w, head, q0 + 128 + (w - 4) * 16, 0, p.S / ATT_KV, nullptr, clk);
+  // DMA pieces: in a 256-query workgroup waves 0-3 (which wait for their partners) issue them all; in a 192-query one the waves with ONE
+  // q-tile (4-7) are the early ones and take them
+  if (big) {
+    if (w < 4) attn5_body<true, LAG, ATT5_VAR, 2, false, 2>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+    else attn5_body<false, LAG, ATT5_VAR, 2, true, 0>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+  } else {
+    if (w < 4) attn5_body<true, LAG, ATT5_VAR, 2, false, MIX_SMALL_DMA_A>(p, smem, tid, lane, w, head, q0 + w * 32, 0, p.S / ATT_KV, nullptr, clk);
+    else attn5_body<false, LAG, ATT5_VAR, 1, true, 2 - MIX_SMALL_DMA_A>(p, smem, tid, lane, w, head, q0 + 128 + (w - 4) * 16, 0, p.S / ATT_KV, nullptr, clk);
+  }
 }
 
 #ifdef RF_EXPERIMENTS
@@ -1567,6 +1573,7 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
 #ifdef RF_EXPERIMENTS
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
@@ -1720,6 +1727,10 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
         if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v7mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
         else hipLaunchKernelGGL(attn_fwd_kernel_v7mix<false>, gridm, blk, ATT4_LDS, st, p, mx);
       } else
+#endif
+#ifdef RF_EXPERIMENTS
+      if (g_at.knock == 2048 && kern == RF_ATTN_BOUNDED16_MIX) hipLaunchKernelGGL((attn_fwd_kernel_v5mix<false, 2>), gridm, blk, ATT4_LDS, st, p, mx);
+      else
 #endif
       if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v5mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
       else hipLaunchKernelGGL(attn_fwd_kernel_v5mix<false>, gridm, blk, ATT4_LDS, st, p, mx);

@@ -66,16 +66,17 @@ if args.ab_mix:
     import os
     os.environ["RF_DENOISE_GRAPH"] = "0"
     for rep in range(4):
-        for mix in (0, -1):
-            lib.rf_debug_attn_mix(mix)
+        for mix in (0, -1, -2):                      # -2: mixed-size launch whose 192-query workgroups let waves 0-3 issue the DMA (experiment)
+            lib.rf_debug_attn_mix(-1 if mix else 0)
+            lib.rf_debug_attn_knock(2048 if mix == -2 else 0)
             one(2, 2); torch.cuda.synchronize()
             t0 = time.perf_counter(); one(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
             with ops.profile(4096) as pr:
                 one(1, 2); torch.cuda.synchronize()
             a, gm = pr.classes["attention"], pr.classes.get("gemm_main", pr.classes.get("gemm_w8"))
-            print(f"rep {rep} mixed-size launch {'auto' if mix else 'off '}: {dt / T * 1e3:8.2f} ms/step wall   attention {a['us']/2e3:7.2f} ms/forward = "
+            print(f"rep {rep} mixed-size launch {'off ' if mix == 0 else ('auto' if mix == -1 else 'A-dma')}: {dt / T * 1e3:8.2f} ms/step wall   attention {a['us']/2e3:7.2f} ms/forward = "
                   f"{a['work']/(a['us']*1e-6)/1e12:7.1f} TF   GEMM class {gm['us']/2e3:7.2f} ms/forward   (last attention path {lib.rf_debug_last_attn_path()})", flush=True)
-    lib.rf_debug_attn_mix(-1)
+    lib.rf_debug_attn_mix(-1); lib.rf_debug_attn_knock(0)
     sys.exit(0)
 t0 = time.perf_counter(); o = one(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 assert torch.isfinite(o.float()).all()
