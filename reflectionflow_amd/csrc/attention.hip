@@ -829,6 +829,11 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   const int l15 = lane & 15, g = lane >> 4;
   const int S = p.S;
   constexpr int PRIO = (KNOCK >> 7) & 7;
+  // SUMM: the row sums l = sum_k P ride on the matrix pipe -- O^T gets a ninth "d tile" whose V^T rows are all ones (a constant register
+  // fragment, no LDS read): 2 NQT MFMAs per key tile instead of 16 NQT dependent v_add_f32 in the exp2 half (a wave's adds cost ~6 clocks
+  // each on its critical path, DESIGN K3M; the matrix pipe is ~60 % busy).  l then sums the bf16-ROUNDED P, the values the numerator uses.
+  // Not with LAG, whose overflow test needs the sums before P is packed.
+  constexpr bool SUMM = !LAG && (KNOCK & 2048) != 0;
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
   const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
   const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
@@ -906,6 +911,14 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   float l_run[NQT];
 #pragma unroll
   for (int qt = 0; qt < NQT; ++qt) l_run[qt] = 0.f;
+  [[maybe_unused]] f32x4 lsum[NQT];    // SUMM: every row of this "O^T tile" is the row sum of query l15
+  [[maybe_unused]] bf16x8 ones;
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lsum[qt][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
   // score tiles, index ti = (b*2 + T)*NQT + qt: this lane holds keys b*32 + T*8 + {0-3 | 4-7 | 16-19 | 20-23}[g] of query l15
   f32x4 s_cur[4 * NQT], s_nxt[4 * NQT];
   bf16x8 pf[2 * NQT];   // P(t-1): B-operand fragments [b*NQT + qt] of the pending PV product: words T*2, T*2+1 from tile (b, T, qt)
@@ -1058,6 +1071,10 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt)
           oacc[G][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[P % NFR][b], pf[b * NQT + qt], oacc[G][qt], 0, 0, 0);
+      if constexpr (SUMM && (G == 0 || G == 4)) {   // the ones "d tile": key block b = G / 4 of P(t-1)
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) lsum[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[(G / 4) * NQT + qt], lsum[qt], 0, 0, 0);
+      }
       if constexpr (!(KNOCK & 2)) {
         if constexpr (NQT == 2) {   // score tile G = (b*2 + T)*2 + qt
           float e4[4];
@@ -1067,15 +1084,17 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             s_cur[G][j] = e4[j];
-            psum[G & 1] += e4[j];
+            if constexpr (!SUMM) psum[G & 1] += e4[j];
           }
         } else {                    // four score tiles over eight groups: half a tile each
           float e0 = __builtin_amdgcn_exp2f(s_cur[G >> 1][(G & 1) * 2]), e1 = __builtin_amdgcn_exp2f(s_cur[G >> 1][(G & 1) * 2 + 1]);
           asm volatile("" : "+v"(e0), "+v"(e1));
           s_cur[G >> 1][(G & 1) * 2] = e0;
           s_cur[G >> 1][(G & 1) * 2 + 1] = e1;
-          psum[0] += e0;   // (the summation order of the two-q-tile form: bit-identical row sums)
-          psum[0] += e1;
+          if constexpr (!SUMM) {
+            psum[0] += e0;   // (the summation order of the two-q-tile form: bit-identical row sums)
+            psum[0] += e1;
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1244,6 +1263,15 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b * NQT + qt], oacc[dt][qt], 0, 0, 0);
       }
+    if constexpr (SUMM) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt) lsum[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[b * NQT + qt], lsum[qt], 0, 0, 0);
+      // every lane of a query holds the WHOLE row sum; attn5_finish / the combine kernel add a query's four lanes: hand them a quarter each
+#pragma unroll
+      for (int qt = 0; qt < NQT; ++qt) l_run[qt] = lsum[qt][0] * 0.25f;
+    }
   }
   if constexpr (NQT == 2)   // (the mixed-size launch never splits the key axis)
   if (partial != nullptr) {
@@ -1261,9 +1289,10 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   attn5_finish<NQT, (KNOCK & 8) != 0>(p, oacc, l_run, lane, head, q0w);
 }
 
-// The variant the product kernels run (the VAR bits of attn5_body): wave priority scheme 2 -- s_setprio 2 in G (scores + packing), 0 in F
-// (PV + exp2) -- worth 1.8 % on top of the DMA distribution (208.3 -> 204.6 us at S = 4608, profiles/r03_kb_attn_stamps_v7.log).
-constexpr int ATT5_VAR = 256;
+// The variant the product kernels run (the VAR bits of attn5_body): 256 = wave priority scheme 2 -- s_setprio 2 in G (scores + packing),
+// 0 in F (PV + exp2) -- worth 1.8 % on top of the DMA distribution (208.3 -> 204.6 us at S = 4608, profiles/r03_kb_attn_stamps_v7.log);
+// 2048 = the row sums on the matrix pipe (bounded form only; 1.3-2 % in seven interleaved pairs, profiles/r03_kb_attn_stamps_v10.log).
+constexpr int ATT5_VAR = 256 | 2048;
 
 template <bool LAG>
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
@@ -1602,6 +1631,10 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<272>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<400>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2320>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2304>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<832>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<320>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1040>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<512>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
@@ -1772,6 +1805,10 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
         else if (g_at.knock == 1024) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1024>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 1040) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1040>, grid2, blk, ATT4_LDS, st, p);
         else if (g_at.knock == 528) hipLaunchKernelGGL(attn_fwd_kernel_v5k<528>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 320) hipLaunchKernelGGL(attn_fwd_kernel_v5k<320>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 832) hipLaunchKernelGGL(attn_fwd_kernel_v5k<832>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 2304) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2304>, grid2, blk, ATT4_LDS, st, p);
+        else if (g_at.knock == 2320) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2320>, grid2, blk, ATT4_LDS, st, p);
         else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
         g_last_attn_path = 5;
         break;

@@ -15,15 +15,15 @@ bound = float(q.float().norm(dim=-1).max() * k.float().norm(dim=-1).max()) * 1.0
 out = torch.empty(S, H * 128, device=dev, dtype=torch.bfloat16)
 f = lambda: ops.attention(q, k, vt, S, out=out, q_prescaled=True, score_bound=bound, kernel=L.RF_ATTN_BOUNDED16)
 ref = None
-for rep in range(3):
-    for name, kn in (("shipped (waves 0-3 issue all DMA)", 0), ("every wave issues 2+2 pieces (round 2)", 1024), ("prio 1: F 2, G 0", 128), ("prio 2: F 0, G 2", 256), ("prio 3: A F0 G2, B G2 F1", 384), ("prio 4: B 1, A 0", 512), ("prio 5: alternating groups", 640), ("prio 6: A F1 G2, B G2 F0", 768), ("no rotation", 64)):
+for rep in range(7):
+    for name, kn in (("shipped (prio 2, rotated)", 256), ("row sums on the matrix pipe", 2304)):
         lib.rf_debug_attn_knock(kn)
         t = timeit(f, 10)
         torch.cuda.synchronize()
         if ref is None:
             ref = ops.attention(q, k, vt, S, q_prescaled=True, kernel=L.RF_ATTN_ONLINE256).float()
         print(f"{name:44s} {t*1e6:7.1f} us   max|d| vs online-softmax kernel {float((out.float() - ref).abs().max()):.1e}", flush=True)
-for name, kn in (("shipped + stamps", 16), ("prio 4 + stamps", 528)):
+for name, kn in (("shipped + stamps", 272), ("row sums on the matrix pipe + stamps", 2320)):
     lib.rf_debug_attn_knock(kn)
     for _ in range(5):
         f()
