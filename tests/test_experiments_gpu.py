@@ -145,12 +145,14 @@ def test_attention_one_wave_per_simd_is_bit_identical(dev, exp, S, H):
     lib = exp
     try:
         lib.rf_debug_attn_v5(1); lib.rf_debug_attn_sk(0); lib.rf_debug_attn_mix(0)     # the plain one-size grid of both kernels
+        lib.rf_debug_attn_knock(256)     # v5 with its row sums formed by v_add_f32 as in v6 (the shipped v5 forms them on the matrix pipe)
         o5 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
         assert lib.rf_debug_last_attn_path() == 5
+        lib.rf_debug_attn_knock(0)
         lib.rf_debug_attn_v6(1)
         o6 = ops.attention(q, k, vt, S, q_prescaled=True, score_bound=bound)
         assert lib.rf_debug_last_attn_path() == 7
     finally:
-        lib.rf_debug_attn_v5(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0); lib.rf_debug_attn_mix(-1)
+        lib.rf_debug_attn_v5(-1); lib.rf_debug_attn_sk(-1); lib.rf_debug_attn_v6(0); lib.rf_debug_attn_mix(-1); lib.rf_debug_attn_knock(0)
     assert torch.equal(o5, o6)
     assert_close(o6, ref, f"attention v6 S={S}", atol=2e-3)

@@ -2,7 +2,7 @@
 # Round-3 measurement session on the GPU box (one gpurun call): the bench line, rocprofv3 kernel trace + stats of the bench command,
 # PMC passes of the dominant kernels and of the VAE path, the VAE call-site trace (no MIOpen kernel), the cfg4 side bench.
 export TMPDIR=/tmp
-OUT=gpurun_out/final3
+OUT=gpurun_out/final4
 mkdir -p $OUT
 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-isolated-shapes --no-graph > $GRAFT_REPO_ROOT/$OUT/bench_prof.json 2> $GRAFT_REPO_ROOT/$OUT/bench_prof.err )
