@@ -195,7 +195,8 @@ RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quan
 # switch: tests pin a kernel per launch through rf_gemm_desc.schedule / rf_attn_desc.kernel.
 _EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_clock_probe": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-               "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)])}
+               "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)]),
+               "rf_debug_attn_mix_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)])}
 # librf_flux_exp.so only (make -C reflectionflow_amd/csrc EXPERIMENTS=1; tools/kb_*.py): the A/B switches of the studies in profiles/
 _EXP_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
              "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),

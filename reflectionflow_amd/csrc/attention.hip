@@ -1522,6 +1522,17 @@ static int g_last_attn_path = 0;
 
 }  // namespace rf
 
+// read-only: the sizes the mixed-size launch would use for S keys x heads on num_cus CUs (pure host arithmetic: CPU tests check its
+// invariants without a GPU).  out = {256-query workgroups per head, 192-query workgroups per head, 1000 x simulated makespan in units of
+// a 256-query workgroup, plain-grid rounds}
+extern "C" int rf_debug_attn_mix_plan(int32_t S, int32_t heads, int32_t num_cus, int32_t* out) {
+  RF_REQUIRE(out != nullptr && S > 0 && S % 256 == 0 && heads > 0 && num_cus >= 8, RF_ERR_SHAPE, "rf_debug_attn_mix_plan: bad arguments");
+  int a = 0, b = 0;
+  const float span = rf::attn_mix_plan(S / 16, heads, num_cus / 8 * 8, rf::ATT5_SMALL_COST, &a, &b);
+  out[0] = a; out[1] = b; out[2] = (int32_t)(span * 1000.f + 0.5f); out[3] = rf::cdiv(heads * (S / 256), num_cus / 8 * 8);
+  return RF_OK;
+}
+
 // read-only introspection: 1 / 2 / 4 / 5 = kernel version, 6 = v5 split launch, 8 = v5 lagged-max, 9 = its split launch, 10 / 11 = the
 // mixed-size launch of the bounded / lagged-max kernel (7 = v6, experiments)
 extern "C" int rf_debug_last_attn_path(void) { return rf::g_last_attn_path; }

@@ -148,11 +148,14 @@ class FluxPipeline:
                                  clip_heads: int = 12, clip_eos_token_id: int = 2):
         """Run FluxPipeline.encode_prompt's two encoder calls (generate.py:148-161) on the HIP path (rf_t5_encode / rf_clip_text_encode,
         SURVEY 8f row 2).  Weights: transformers-layout state dicts, or `root` = a diffusers FLUX directory whose `text_encoder_2/` and
-        `text_encoder/` sub-directories hold the safetensors (+ config.json for the head counts).  `tokenize(prompt, max_sequence_length)
-        -> (t5_ids [B, L], clip_ids [B, 77])` is the caller's: the SentencePiece / BPE vocabularies are not part of this repo."""
+        `text_encoder/` sub-directories hold the safetensors (+ config.json for the head counts) and whose `tokenizer/`, `tokenizer_2/` hold the
+        vocabularies (flux/tokenizers.py).  `tokenize(prompts, max_sequence_length) -> (t5_ids [B, L], clip_ids [B, 77])` overrides them."""
         from .text_hip import HipClipTextEncoder, HipT5Encoder, HipTextEncoders
         if tokenize is None:
-            raise ValueError("enable_hip_text_encoders(): a tokenize(prompt, max_sequence_length) callable is required")
+            if root is None:
+                raise ValueError("enable_hip_text_encoders(): a tokenize(prompts, max_sequence_length) callable or a checkpoint root is required")
+            from .tokenizers import load_flux_tokenizers
+            tokenize = load_flux_tokenizers(root)          # <root>/tokenizer + <root>/tokenizer_2, transformers' tokenizer classes
         if root is not None:
             import json
             from safetensors.torch import load_file

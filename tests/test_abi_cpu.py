@@ -67,7 +67,7 @@ def test_no_kernel_selecting_switch_is_exported(lib):
     from reflectionflow_amd import _lib
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     dbg = sorted(set(re.findall(r"\b(rf_debug_[a-z0-9_]+)", out)))
-    assert dbg == ["rf_debug_clock_probe", "rf_debug_last_attn_path", "rf_debug_last_gemm_path", "rf_debug_sk_plan"], dbg
+    assert dbg == ["rf_debug_attn_mix_plan", "rf_debug_clock_probe", "rf_debug_last_attn_path", "rf_debug_last_gemm_path", "rf_debug_sk_plan"], dbg
     d = _lib.rf_gemm_desc()
     d.N, d.num_groups, d.schedule = 64, 1, 17
     assert lib.rf_gemm_bf16(C.byref(d), None) == -1 and b"schedule=17" in lib.rf_last_error()
