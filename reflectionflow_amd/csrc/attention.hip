@@ -819,10 +819,13 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
 //
 // NQT = q-tiles (16 queries) of THIS wave: 2 everywhere except in waves 4-7 of the 192-query workgroups of the mixed-size launch
 // (attn_fwd_kernel_v5mix), which carry one.  q0w = the wave's first query row.  Every wave of a workgroup executes the same
-// barriers and issues the same DMA pieces whatever its NQT.
-// VAR (experiments; 1 and 2 give wrong results): 1 = no fragment reads in the loop, 2 = no exp2 / sums / packing, 4 = fragment
-// reads ONE group ahead of their MFMAs instead of two (32 = three), 8 = 8-byte epilogue stores, 16 = s_memtime stamps around the
-// halves of key tile 40 (rf_debug_attn_stamps)
+// barriers whatever its NQT.  ROT: this wave runs the halves of an interval in the order G, F (waves 4-7); DMA: see below.
+// KNOCK = variant bits.  The product runs ATT5_VAR = 256 | 2048; everything else is reachable only from the experiments library:
+//   1, 2   timing knock-outs (wrong results): no fragment reads in the loop / no exp2, sums, packing
+//   4, 32  fragment reads ONE / THREE groups ahead of their MFMAs instead of two (4 | 32: four)
+//   8      8-byte epilogue stores        16  s_memtime stamps around the halves of key tile 40 (rf_debug_attn_stamps)
+//   128, 256, 384, ... (bits 7-9)  wave-priority scheme 1..7 (256 = scheme 2: s_setprio 2 in G, 0 in F -- shipped)
+//   2048   row sums on the matrix pipe (SUMM; bounded form only -- shipped)
 template <bool PROBE, bool LAG, int KNOCK = 0, int NQT = 2, bool ROT = false, int DMA = 1>
 __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
                                            const int head, const int q0w, const int t0, const int nt, float* partial, ClkProbe& clk) {
