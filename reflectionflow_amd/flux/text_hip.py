@@ -194,8 +194,9 @@ class HipClipTextEncoder:
         return (ids == self.eos_token_id).int().argmax(-1).tolist()
 
     @torch.no_grad()
-    def encode(self, ids: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """ids [B, S] -> (last_hidden_state [B, S, hidden], pooler_output [B, hidden]), bf16."""
+    def encode(self, ids: torch.Tensor, pool_in_library: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """ids [B, S] -> (last_hidden_state [B, S, hidden], pooler_output [B, hidden]), bf16.  pool_in_library: let rf_clip_text_encode
+        copy the pooled rows itself from host-side EOS positions (costs a host sync to find them; tests)."""
         if not ids.is_cuda:
             raise RFError("HipClipTextEncoder.encode: ids are on the CPU; the HIP path has no CPU fallback")
         B, S = ids.shape
@@ -203,15 +204,22 @@ class HipClipTextEncoder:
         m = self._causal(S)
         w.mask, w.mask_S = m.data_ptr(), _pad32(S)
         ids32 = ids.to(torch.int32).contiguous()
-        eos = self.eos_positions(ids)
         last = torch.empty(B, S, self.hidden, dtype=BF, device=self.device)
-        pooled = torch.empty(B, self.hidden, dtype=BF, device=self.device)
+        if pool_in_library:
+            eos = self.eos_positions(ids)
+            pooled = torch.empty(B, self.hidden, dtype=BF, device=self.device)
         for b0 in range(0, B, 64):
             nb = min(64, B - b0)
             ws = self._ws.get(lib.rf_clip_text_workspace_bytes(C.byref(w), nb, S))
-            pos = (C.c_int32 * nb)(*[int(e) for e in eos[b0:b0 + nb]])
-            L.check(lib.rf_clip_text_encode(C.byref(w), ids32[b0].data_ptr(), nb, S, pos, last[b0].data_ptr(), pooled[b0].data_ptr(), C.byref(ws),
-                                            stream_ptr()), "rf_clip_text_encode")
+            pos_h = (C.c_int32 * nb)(*[int(e) for e in eos[b0:b0 + nb]]) if pool_in_library else None
+            L.check(lib.rf_clip_text_encode(C.byref(w), ids32[b0].data_ptr(), nb, S, pos_h, last[b0].data_ptr(),
+                                            pooled[b0].data_ptr() if pool_in_library else None, C.byref(ws), stream_ptr()), "rf_clip_text_encode")
+        if pool_in_library:
+            return last, pooled
+        # pooler_output = the final-normed row at the EOS position: a device-side gather (no host sync; the C entry point takes host
+        # positions for bindings that have them)
+        pos = ids.argmax(-1) if self.eos_token_id == 2 else (ids == self.eos_token_id).int().argmax(-1)
+        pooled = last[torch.arange(B, device=self.device), pos]
         return last, pooled
 
 

@@ -99,6 +99,8 @@ def test_clip_text_encoder_vs_oracle(dev, vocab, hidden, heads, inter, layers, m
     assert last.shape == (2, S, hidden) and pooled.shape == (2, hidden) and torch.isfinite(last.float()).all()
     assert torch.equal(last, last2) and torch.equal(pooled, pooled2)
     assert enc.eos_positions(ids) == [S // 3, S - 1]
+    last3, pooled3 = enc.encode(ids.to(dev), pool_in_library=True)        # the C entry point's own pooled copy (host EOS positions)
+    assert torch.equal(last3, last) and torch.equal(pooled3, pooled)
     yard = None
     try:
         import transformers as tr
