@@ -205,7 +205,7 @@ _EXP_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2
              "rf_debug_attn_stamps": (C.c_int, [C.c_void_p]), "rf_debug_attn_mix": (C.c_int, [C.c_int]), "rf_debug_attn_v7": (C.c_int, [C.c_int]), "rf_debug_attn_stamps7": (C.c_int, [C.c_void_p]),
              "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
              "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]), "rf_debug_gemm_mi16": (C.c_int, [C.c_int]),
-             "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]),
+             "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_pp4": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]),
              "rf_debug_gemm_nt_store": (C.c_int, [C.c_int]),
              "rf_debug_gemm_timeline": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_void_p, C.c_void_p])}
 EXP_LIB_PATH = os.path.join(_HERE, "librf_flux_exp.so")

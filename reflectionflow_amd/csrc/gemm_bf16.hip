@@ -76,6 +76,7 @@ __device__ unsigned long long g_clk_probe_epi[2];   // {s_memtime, s_memrealtime
 
 // Kernel-selection knobs.  In librf_flux.so they are compile-time constants (the shipped choice); the experiments build
 // (-DRF_EXPERIMENTS) makes them mutable through rf_debug_* setters for the A/B tools.
+#define RF_GEMM_PP4_DEFAULT 0
 struct Tuning {
   int nt_store;            // LDS-staged epilogue writes output rows with non-temporal stores
   int mi16;                // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs
@@ -85,11 +86,12 @@ struct Tuning {
   int persistent_rounds;   // > 0: bf16 launches with >= this many rounds run as ONE persistent launch (measured neutral: off)
   int skinny;              // LoRA down-projections on the single-launch skinny-N kernel (measured slower: off)
   int w4_knock;            // variant selector of the experimental kernels
+  int pp4;                 // bf16 tile-per-block launches on gemm_mainloop_pp4_m16 (two 32-MFMA phases per K-tile)
 };
 #ifdef RF_EXPERIMENTS
-static Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0};
+static Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0, RF_GEMM_PP4_DEFAULT};
 #else
-static constexpr Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0};
+static constexpr Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0, RF_GEMM_PP4_DEFAULT};
 #endif
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
@@ -1166,6 +1168,7 @@ __global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) {
 
 #ifdef RF_EXPERIMENTS
 #include "experiments/gemm_kernels_exp.inc"
+#include "experiments/gemm_pp4_exp.inc"
 #endif
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
@@ -1396,6 +1399,9 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
 #ifdef RF_EXPERIMENTS
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+#endif
+#ifdef RF_EXPERIMENTS
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -1414,6 +1420,9 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   }
 #endif
   if (p.w8) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+#ifdef RF_EXPERIMENTS
+  else if (g_tune.pp4) hipLaunchKernelGGL(gemm_bf16_pp16f_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+#endif
   else hipLaunchKernelGGL(gemm_bf16_pp16e_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
@@ -1848,6 +1857,7 @@ extern "C" int rf_debug_gemm_timeline(const rf_gemm_desc* d, unsigned long long*
 }
 extern "C" int rf_debug_gemm_nt_store(int on) { rf::g_tune.nt_store = on ? 1 : 0; return RF_OK; }
 extern "C" int rf_debug_gemm_skinny(int on) { rf::g_tune.skinny = on ? 1 : 0; return RF_OK; }   // skinny-N kernel vs split-K
+extern "C" int rf_debug_gemm_pp4(int on) { rf::g_tune.pp4 = on ? 1 : 0; return RF_OK; }
 extern "C" int rf_debug_gemm_even(int on) { rf::g_tune.even = on ? 1 : 0; return RF_OK; }       // 6/6/6/6 vs 8/4/8/4 phases
 extern "C" int rf_debug_gemm_mi16(int on) { rf::g_tune.mi16 = on ? 1 : 0; return RF_OK; }       // MFMA shape of the bf16 256x256 kernel
 extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_tune.w4_knock = k; return RF_OK; }
