@@ -267,3 +267,38 @@ def test_reflection_runner_encodes_a_rounds_prompts_in_one_batch(dev, tmp_path):
     assert len(log) == 1 and len(log[0]["scores"]) == 4
     # one round, 4 candidates, 2 distinct prompts: exactly one T5 call and one CLIP call, each over the 2 distinct prompts
     assert calls == [(2, 64), (2, 77)], calls
+
+
+@torch.no_grad()
+def test_enable_hip_text_encoders_from_a_checkpoint_directory(dev, tmp_path):
+    """`pipe.enable_hip_text_encoders(root=...)`: weights from `<root>/text_encoder_2` + `<root>/text_encoder` (safetensors + config.json for
+    the head counts / EOS convention), vocabularies from `<root>/tokenizer_2` + `<root>/tokenizer` -- the diffusers FLUX layout; then
+    `encode_prompt("...")` runs tokenizer -> HIP encoders end to end and equals the encoders fed the same ids by hand."""
+    pytest.importorskip("transformers")
+    pytest.importorskip("sentencepiece")
+    import json
+    from safetensors.torch import save_file
+    from reflectionflow_amd.flux.pipeline import FluxPipeline
+    from reflectionflow_amd.flux.text_hip import HipClipTextEncoder, HipT5Encoder
+    from reflectionflow_amd.flux.tokenizers import load_flux_tokenizers
+    from tests.test_tokenizers_cpu import _make_root
+    root, vocab = _make_root(tmp_path)
+    t5_sd = TO.synthetic_t5_state(64, 256, 64, 4, 512, 2, seed=51)            # the tiny SentencePiece model has <= 64 pieces
+    clip_sd = TO.synthetic_clip_state(len(vocab), 64, 1, 128, 2, 77, seed=52)
+    for sub, sd, cfg in (("text_encoder_2", t5_sd, {"num_heads": 4, "d_kv": 64}),
+                         ("text_encoder", {"text_model." + k: v for k, v in clip_sd.items()}, {"num_attention_heads": 1, "eos_token_id": 2})):
+        os.makedirs(os.path.join(root, sub))
+        save_file({k: v.to(BF).contiguous() for k, v in sd.items() if k != "encoder.embed_tokens.weight"}, os.path.join(root, sub, "model.safetensors"))
+        json.dump(cfg, open(os.path.join(root, sub, "config.json"), "w"))
+    cfgt = dict(num_layers=1, num_single_layers=1, num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64)
+    pipe = FluxPipeline.synthetic(cfgt, seed=0, torch_dtype=BF, device=dev)
+    pipe.enable_hip_text_encoders(root=root)
+    prompts = ["a photo of a cat", "two dogs playing in the park"]
+    pe, pooled, text_ids = pipe.encode_prompt(prompt=prompts, max_sequence_length=48)
+    assert pe.shape == (2, 48, 256) and pooled.shape == (2, 64) and text_ids.shape == (48, 3)
+    t5_ids, clip_ids = load_flux_tokenizers(root)(prompts, 48)
+    want_pe = HipT5Encoder(bf16_round(t5_sd), 4, dev).encode(t5_ids.to(dev))
+    want_pooled = HipClipTextEncoder(bf16_round(clip_sd), 1, dev).encode(clip_ids.to(dev))[1]
+    assert torch.equal(pe, want_pe) and torch.equal(pooled, want_pooled)
+    # ... and against the oracle on the tokenizer's ids
+    assert rel_l2(pe, TO.t5_encode(bf16_round(t5_sd), t5_ids, 4)) < 2.5e-2
