@@ -44,10 +44,15 @@ def main(mode: str, argv=None):
     shard = search.init_distributed()
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    pipe = runner.build_pipeline(config, dev, synthetic=args.synthetic, small=args.small)
+    os.makedirs(args.output_dir, exist_ok=True)
+    if mode == "reflection" and args.imgpath:
+        # tts_reflectionflow.py:535-565: prompts and the round-1 pool come from the --imgpath tree (one folder per prompt with
+        # metadata.jsonl + samples/), i.e. from a tts_t2i_noise_scaling output directory
+        return runner.run_reflection_search(config, None, args.output_dir, pipe, shard, start_index=args.start_index,
+                                            imgpath=args.imgpath)
     with open(args.meta_path) as fp:
         metadatas = [json.loads(line) for line in fp]
     metadatas = metadatas[args.start_index:] if args.end_index == -1 else metadatas[args.start_index:args.end_index]
-    pipe = runner.build_pipeline(config, dev, synthetic=args.synthetic, small=args.small)
     prompts = [m["prompt"] for m in metadatas]
-    os.makedirs(args.output_dir, exist_ok=True)
-    return MODES[mode](config, prompts, args.output_dir, pipe, shard, start_index=args.start_index)
+    return MODES[mode](config, prompts, args.output_dir, pipe, shard, start_index=args.start_index, metadatas=metadatas)

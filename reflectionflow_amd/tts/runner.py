@@ -1,18 +1,21 @@
 """Candidate-parallel search runner shared by the two driver scripts.
 
-Mirrors the control flow of the reference drivers for the denoise path only:
+Mirrors the control flow of the reference drivers:
   * noise scaling  (tts/tts_t2i_noise_scaling.py:126-159, sample :16-77): per prompt x round draw
-    `search_branch` seeded noises and generate one candidate per noise -- no dependency between rounds;
-  * reflection loop (tts/tts_reflectionflow.py:591-629, sample :94-463): score the previous round,
-    keep the top-k, build a "cot" Condition from each kept candidate, generate the next round with
-    the FLUX-Corrector LoRA active on the condition tokens, re-score.
+    `search_branch` seeded noises and generate one candidate per noise -- no dependency between rounds; the
+    output tree is what the reflection driver's `--imgpath` reads;
+  * reflection loop (tts/tts_reflectionflow.py:591-629, sample :94-463): order the previous round's images by the
+    verifier's key, keep topk = search_branch, generate candidate i from the i-th best parent as a "cot" Condition
+    with the FLUX-Corrector LoRA active on the condition tokens, re-score, file the candidates into chains, write
+    the best-of-chain / best-overall artefacts.  Pinned by tests/golden/search_tree.json, recorded from the
+    reference's own main().
 What is NOT here (outside the hot path): the GPT-4o / NVILA verifiers and
-the reflection / prompt-refinement LLM calls.  `search.stub_verifier` stands in for their output
-contract; prompts are therefore not rewritten between rounds.
+the reflection / prompt-refinement LLMs.  They plug in through `score_batch` / `score_images` and the
+`reflect` / `refine` hooks; `search.stub_score_batch` stands in for the verifier's output contract.
 
-Sharding: candidate i of a round runs on rank i % world_size; the only collective is the all-gather
-of {score, label} at the round boundary (search.allgather_scores).  Seeds are a pure function of
-(prompt index, round, candidate), so results do not depend on the world size.
+Sharding: candidate i of a round runs on rank i % world_size; the collectives are the all-gather of {score, label}
+records and one owners-only all-gather of the parents' latents per round (tts/search.py).  Seeds are a pure
+function of (prompt index, round, candidate), so results do not depend on the world size.
 """
 from __future__ import annotations
 
@@ -97,24 +100,33 @@ def latent_to_condition(latents: torch.Tensor, height: int, width: int, conditio
     return Condition("cot", tokens=tokens, ids=ids, position_delta=[0, -condition_size // 16])
 
 
-def _save(path: str, latents: torch.Tensor, pipe: FluxPipeline, height: int, width: int):
+def _save(path: str, latents: torch.Tensor, pipe: FluxPipeline, height: int, width: int) -> str:
+    """Write one candidate: PNG like the reference when the pipeline has a VAE, else the packed latents as .pt.  Returns the file."""
     os.makedirs(os.path.dirname(path), exist_ok=True)
     if pipe.vae is not None and pipe.image_processor is not None:              # full pipeline available: PNG like the reference
         z = pipe._unpack_latents(latents, height, width, pipe.vae_scale_factor)
         z = z / pipe.vae.config.scaling_factor + pipe.vae.config.shift_factor
         img = pipe.image_processor.postprocess(pipe.vae.decode(z, return_dict=False)[0], output_type="pil")[0]
         img.save(path + ".png")
-    else:
-        torch.save(latents.cpu(), path + ".pt")
+        return path + ".png"
+    torch.save(latents.cpu(), path + ".pt")
+    return path + ".pt"
 
 
 def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
-                      start_index: int = 0) -> List[dict]:
+                      start_index: int = 0, metadatas: Optional[List[dict]] = None) -> List[dict]:
+    """tts_t2i_noise_scaling.py:126-159.  The output directory has the layout the reflection driver's `--imgpath` reads
+    (`<index>/metadata.jsonl` + `<index>/samples/<round>_round@<seed>.png`), as in the reference."""
     pa, sa = config["pipeline_args"], config["search_args"]
     dev, dtype = pipe.device, pipe.dtype
     out = []
     for index, prompt in enumerate(prompts):
-        sample_dir = os.path.join(output_dir, f"{index + start_index:0>5}", "samples")
+        outpath = os.path.join(output_dir, f"{index + start_index:0>5}")
+        sample_dir = os.path.join(outpath, "samples")
+        if shard.rank == 0:
+            os.makedirs(sample_dir, exist_ok=True)
+            with open(os.path.join(outpath, "metadata.jsonl"), "w") as fp:       # tts_t2i_noise_scaling.py:136-137
+                json.dump(metadatas[index] if metadatas is not None else {"prompt": prompt}, fp)
         for rnd in range(1, sa["search_rounds"] + 1):
             seeds = candidate_seeds(index + start_index, rnd, sa["search_branch"])
             for i in shard.mine(len(seeds)):
@@ -129,69 +141,265 @@ def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: F
     return out
 
 
-def run_reflection_search(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
-                          start_index: int = 0, verifier=None, score_batch=None, refine_prompt=None) -> List[dict]:
-    """Reflection rounds.  Deliberate deviation from tts_reflectionflow.py:314-322: the reference's `generate`
-    call passes neither `latents`, `num_inference_steps` nor `guidance_scale` (so its defaults -- 28 steps,
-    guidance 3.5, noise from the global RNG -- apply and the `get_noises` seeds only name files, SURVEY 8a quirks);
-    here the config's steps/guidance and the per-candidate seeded noise ARE passed, so that a candidate is a pure
-    function of (prompt, round, index) and results do not depend on the world size.  Each prompt's
-    `search_log.jsonl` holds that prompt's rounds only; the return value is the concatenation over prompts.
+# ------------------------------------------------------------------------------------------------ reflection search
+def read_imgpath(imgpath: str) -> List[dict]:
+    """The `--imgpath` pool reader of tts_reflectionflow.py:535-556: one sub-folder per prompt with `metadata.jsonl`
+    (first line = {"prompt", "tag", ...}) and `samples/` (every file, sorted, is a pool image)."""
+    out = []
+    for folder in sorted(os.listdir(imgpath)):
+        fp = os.path.join(imgpath, folder)
+        if not os.path.isdir(fp):
+            continue
+        with open(os.path.join(fp, "metadata.jsonl")) as f:
+            meta = [json.loads(line) for line in f if line.strip()]
+        sp = os.path.join(fp, "samples")
+        images = [os.path.join(sp, x) for x in sorted(os.listdir(sp))] if os.path.exists(sp) else []
+        out.append({"metadata": meta, "images": images})
+    return out
 
-    `refine_prompt(prompt, round, candidate_index, seed) -> str` is the hook of the reference's reflection / prompt-refinement LLMs
-    (tts_reflectionflow.py:286-294: `refined + " [Reflexion]: " + reflection`, a different prompt per candidate and round; the LLMs
-    themselves are out of scope).  The prompts of a rank's candidates are encoded ONCE per round, de-duplicated, in one
-    batched `encode_prompt` call (T5-XXL + CLIP-L share their GEMM launches across the prompts), and handed to `generate` as
-    embeddings -- the reference encodes inside every generate() call."""
+
+def stub_score_images(paths: List[str], prompt: str):
+    """Stand-in verifier for pool images that come from disk (`--imgpath`): a score from the file's bytes."""
+    import hashlib
+    sc = [int(hashlib.sha256(open(p, "rb").read()).hexdigest()[:8], 16) / 0xFFFFFFFF for p in paths]
+    return torch.tensor(sc, dtype=torch.float32), torch.tensor([int(v >= 0.5) for v in sc], dtype=torch.int32)
+
+
+def _bcast(shard: search.Shard, obj):
+    """rank 0's Python object on every rank (the LLM hooks run once, on rank 0)."""
+    if shard.world_size == 1:
+        return obj
+    box = [obj if shard.rank == 0 else None]
+    torch.distributed.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def _copy(src: str, dst_stem: str):
+    import shutil
+    os.makedirs(os.path.dirname(dst_stem), exist_ok=True)
+    shutil.copyfile(src, dst_stem + os.path.splitext(src)[1])
+
+
+def run_reflection_search(config: dict, prompts: Optional[List[str]], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
+                          start_index: int = 0, verifier=None, score_batch=None, reflect=None, refine=None,
+                          imgpath: Optional[str] = None, score_images=None, metadatas: Optional[List[dict]] = None) -> List[dict]:
+    """The reflection search of tts_reflectionflow.py:591-629 (`main`'s round loop) + :94-463 (`sample`), sharded over ranks.
+
+    Per prompt: a POOL of images -- the `--imgpath` folder's `samples/` when `imgpath` is given (as the reference), else
+    `search_branch` plain t2i candidates generated here as "round 0" (= one round of tts_t2i_noise_scaling) -- then rounds
+    1..search_rounds, each exactly the reference's: order the pool by the verifier's key, keep `topk = search_branch`
+    (:609; `search_args.topk` overrides), pad by repetition (:179-182), write `best_img_detailedscore.jsonl`; run the
+    reflection / prompt-refinement hooks (:196-259) and write `best_img_meta.jsonl`; generate candidate i from PARENT
+    selected[i] -- its image resized to `condition_size` as a "cot" Condition with position_delta [0, -size // 16]
+    (:273-279) -- under prompt i (`refined[i] + " [Reflexion]: " + reflection[i]`, :286-294); score the candidates; file
+    them into chains (:358-395); write `midimg/<round>_round@<seed>`, `samples_lastround/`, `samples_path_bestround/` (best
+    of each chain) and, after the last round, `samples_best/` (:397-444).  The new candidates are the next pool.
+    `tests/golden/search_tree.json` (recorded from the reference's own main()) pins all of that.
+
+    Hooks (the LLMs are out of scope; both run on rank 0 and their strings are broadcast):
+      reflect(ctx) -> List[str]         ctx = dict(selected=[{"image_name", "score", "label", "path" | "latents"}...] in
+                                        selection order, original_prompt, current_prompt (list), reflections (list, "" at
+                                        round 1), evaluations (JSON strings), search_round)
+      refine(ctx, reflections) -> List[str]
+    `score_batch(latents [n, S, 64], seeds) -> (f32 [n], i32 [n])` scores generated candidates on the device (one call per
+    round and rank); `score_images(paths, prompt) -> (f32, i32)` scores an `--imgpath` pool.
+
+    Deliberate deviations: the reference's `generate` call passes neither `latents`,
+    `num_inference_steps` nor `guidance_scale` (so 28 steps / 3.5 / global-RNG noise apply and the `get_noises` seeds only
+    name files); here the config's steps / guidance and the per-candidate seeded noise ARE passed, so a candidate is a pure
+    function of (prompt, round, index) and results do not depend on the world size.  A candidate is scored ONCE (the
+    reference scores it after generation and again as next round's pool, :337-356 / :157-170 -- the same numbers).  The
+    parent hand-off is one all-gather of latents instead of PNG paths.  `search_log.jsonl` is an addition."""
     pa, sa, model_cfg = config["pipeline_args"], config["search_args"], config.get("model", {})
     dev, dtype = pipe.device, pipe.dtype
-    N, topk = sa["search_branch"], max(1, sa.get("topk", 1))
+    N, R = sa["search_branch"], sa["search_rounds"]
+    topk = int(sa.get("topk") or N)                                              # tts_reflectionflow.py:609
+    kind = config.get("verifier_args", {}).get("name", "nvila")
+    kind = kind if kind in search.SORT_KEYS else "nvila"
+    H, W, csize = pa["height"], pa["width"], pa["condition_size"]
+    use_reflection = reflect is not None
+    use_refine = refine is not None
+    if use_reflection and not use_refine:
+        refine = lambda ctx, refl: list(ctx["current_prompt"])                  # noqa: E731  (the reference needs both, :288-290)
+    pools = read_imgpath(imgpath) if imgpath else None
+    if pools is not None:
+        end = config.get("end_index", -1)
+        pools = pools[start_index:] if end in (-1, None) else pools[start_index:end]
+        prompts = [p["metadata"][0]["prompt"] for p in pools]
+        metadatas = [p["metadata"][0] for p in pools]
     all_logs: List[dict] = []
+    like = torch.empty(1, (H // 16) * (W // 16), 64, device=dev, dtype=dtype)
     for index, prompt in enumerate(prompts):
-        pdir = os.path.join(output_dir, f"{index + start_index:0>5}")
-        log: List[dict] = []                                                    # this prompt's rounds only
-        kept: List[torch.Tensor] = []                                           # selected latents, identical on every rank
-        for rnd in range(0, sa["search_rounds"] + 1):
-            seeds = candidate_seeds(index + start_index, rnd, N)
+        outpath = os.path.join(output_dir, f"{index + start_index:0>5}")
+        dirs = {k: os.path.join(outpath, k) for k in ("samples_lastround", "samples_best", "samples_path_bestround", "midimg")}
+        if shard.rank == 0:
+            for d in dirs.values():
+                os.makedirs(d, exist_ok=True)
+            with open(os.path.join(outpath, "metadata.jsonl"), "w") as fp:       # :576-577
+                json.dump(metadatas[index] if metadatas is not None else {"prompt": prompt}, fp)
+            for f in ("best_img_detailedscore.jsonl", "best_img_meta.jsonl"):    # appended to per round
+                if os.path.exists(os.path.join(outpath, f)):
+                    os.remove(os.path.join(outpath, f))
+        if shard.world_size > 1:
+            torch.distributed.barrier()
+        log: List[dict] = []
+        tree = search.ReflectionTree(kind)
+        updated_prompt = [prompt] * N                                           # :579
+        reflections = [""] * N if use_reflection else None                      # :582-585
 
-            cond_of_kept: Dict[int, Condition] = {}   # one decode -> resize per kept latent and round, shared by its candidates
-            # this rank's prompts of the round: one batched text-encoder call over the distinct ones
-            mine = list(shard.mine(len(seeds)))
-            prompt_of = {i: (refine_prompt(prompt, rnd, i, seeds[i]) if refine_prompt is not None else prompt) for i in mine}
-            uniq = list(dict.fromkeys(prompt_of.values()))
-            if uniq:
+        def generate_round(rnd, parents, parent_payload, round_prompts, subdir):
+            """This rank's candidates of one round -> (seeds, names, files, scores [(f, i)] of ALL candidates, local latents)."""
+            seeds = candidate_seeds(index + start_index, rnd, N)
+            mine = list(shard.mine(N))
+            uniq = list(dict.fromkeys(round_prompts[i] for i in mine))
+            if uniq:                                                            # one batched text-encoder call per round and rank
                 pe_all, pooled_all, _ = pipe.encode_prompt(prompt=uniq, max_sequence_length=pa.get("max_sequence_length", 512))
             slot = {p: k for k, p in enumerate(uniq)}
-
-            def gen(i, seed):
-                noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seed])[seed]
+            cond_cache: Dict[int, Condition] = {}                               # one decode -> resize per parent and rank
+            local: Dict[int, torch.Tensor] = {}
+            for i in mine:
+                seed = seeds[i]
+                noise = get_noises(MAX_SEED, 1, H, W, device=dev, dtype=dtype, seeds=[seed])[seed]
                 conds = None
-                if rnd > 0:                                                     # round 0 = plain t2i (noise scaling)
-                    j = i % len(kept)
-                    if j not in cond_of_kept:
-                        cond_of_kept[j] = candidate_condition(pipe, kept[j], pa["height"], pa["width"], pa["condition_size"])
-                    # Condition.encode samples the VAE posterior (pipeline_tools.py:10; the reference draws from the global
-                    # RNG): a per-candidate generator makes the sample a function of the candidate's seed alone --
-                    # world-size independent, and the search loop leaves the global CPU / GPU RNG state untouched
-                    conds = [cond_of_kept[j].with_generator(torch.Generator(device="cpu").manual_seed(seed))]
-                k = slot[prompt_of[i]]
+                if parents is not None:
+                    conds = []                                                  # beyond the padded selection: no condition (:307)
+                    if i < len(parents):
+                        j = parents[i]
+                        if j not in cond_cache:
+                            cond_cache[j] = _payload_condition(pipe, parent_payload[j], H, W, csize)
+                        # Condition.encode samples the VAE posterior (pipeline_tools.py:10; the reference draws from the global
+                        # RNG): a per-candidate generator makes the sample a function of the candidate's seed alone
+                        conds = [cond_cache[j].with_generator(torch.Generator(device="cpu").manual_seed(seed))]
+                k = slot[round_prompts[i]]
                 lat = generate(pipe, prompt_embeds=pe_all[k:k + 1], pooled_prompt_embeds=pooled_all[k:k + 1], conditions=conds,
-                               height=pa["height"], width=pa["width"], max_sequence_length=pe_all.shape[1],
+                               height=H, width=W, max_sequence_length=pe_all.shape[1],
                                num_inference_steps=pa["num_inference_steps"], guidance_scale=pa["guidance_scale"],
                                latents=noise, model_config=model_cfg, default_lora=True, output_type="latent").images
-                _save(os.path.join(pdir, "samples", f"{rnd}_round@{seed}"), lat, pipe, pa["height"], pa["width"])
-                return lat
+                _save(os.path.join(outpath, subdir, f"{rnd}_round@{seed}"), lat, pipe, H, W)
+                local[i] = lat
+            scores = _score_local(shard, N, mine, local, seeds, verifier, score_batch)
+            ext = ".png" if (pipe.vae is not None and pipe.image_processor is not None) else ".pt"
+            names = [f"{subdir}/{rnd}_round@{s}{ext}" for s in seeds]
+            return seeds, names, scores, local
 
-            sel, scores, local = search.run_round(shard, seeds, gen, verifier, topk=topk, score_batch=score_batch)
-            # hand the selected latents to every rank: ONE all-gather (topk x 512 KiB per rank at 1024^2; the reference hands
-            # PNG paths over)
-            like = torch.empty(1, (pa["height"] // 16) * (pa["width"] // 16), 64, device=dev, dtype=dtype)
-            kept = search.allgather_selected_latents(shard, sel, local, like)
-            log.append({"prompt": prompt, "round": rnd, "seeds": seeds, "scores": scores, "selected": sel})
+        # ---- the pool
+        if pools is not None:
+            pool_names = list(pools[index]["images"])
+            mine = shard.mine(len(pool_names))
+            fn = score_images or stub_score_images
+            sc, lab = fn([pool_names[i] for i in mine], prompt) if mine else (torch.empty(0), torch.empty(0, dtype=torch.int32))
+            s_all, l_all = search.allgather_score_tensors(shard, len(pool_names), sc, lab)
+            pool_scores = [(float(a), int(b)) for a, b in zip(s_all.tolist(), l_all.tolist())]
+            pool_local: Dict[int, object] = {i: p for i, p in enumerate(pool_names)}      # files: every rank can read them
+            pool_on_disk = True
+            log.append({"prompt": prompt, "round": 0, "pool": pool_names, "scores": pool_scores})
+        else:
+            seeds0, pool_names, pool_scores, pool_local = generate_round(0, None, None, [prompt] * N, "samples")
+            pool_on_disk = False
+            log.append({"prompt": prompt, "round": 0, "seeds": seeds0, "generated": pool_names, "scores": pool_scores})
+
+        for rnd in range(1, R + 1):
+            # ---- selection (:157-182) + its artefact (:185-190)
+            sel = tree.select(pool_scores, topk)
+            selected_names = [pool_names[j] for j in sel]
+            evaluation = [_evaluation(pool_names[j], pool_scores[j], tree.scalar) for j in sel]
+            if shard.rank == 0:
+                with open(os.path.join(outpath, "best_img_detailedscore.jsonl"), "a") as f:
+                    f.write(json.dumps({"evaluation": evaluation, "filenames_batch": selected_names}) + "\n")
+            # ---- the parents' payloads on every rank: ONE owners-only all-gather (pool images on disk need none)
+            if pool_on_disk:
+                payload = {j: pool_local[j] for j in set(sel)}
+            else:
+                kept = search.allgather_selected_latents(shard, sel, pool_local, like)
+                payload = {j: kept[k] for k, j in enumerate(sel)}
+            # ---- reflection / refinement hooks (:196-259) on rank 0, strings broadcast; best_img_meta.jsonl (:262-271)
+            round_prompts = [prompt] * N                                        # :295
+            new_reflections = refined = None
+            if use_reflection or use_refine:
+                if shard.rank == 0:
+                    ctx = dict(selected=[dict(e, **({"path": os.path.join(outpath, n) if not os.path.isabs(n) else n}),
+                                              latents=None if pool_on_disk else payload[j])
+                                         for e, n, j in zip(evaluation, selected_names, sel)],
+                               original_prompt=prompt, current_prompt=list(updated_prompt), reflections=reflections,
+                               evaluations=[json.dumps(e) for e in evaluation], search_round=rnd)
+                    new_reflections = list(reflect(ctx)) if use_reflection else None
+                    refined = list(refine(ctx, new_reflections))
+                    with open(os.path.join(outpath, "best_img_meta.jsonl"), "a") as f:
+                        if use_reflection:
+                            f.write(f"reflections{rnd}: " + json.dumps(new_reflections) + "\n")
+                        if use_refine:
+                            f.write(f"refined_prompt{rnd}: " + json.dumps(refined) + "\n")
+                        f.write(f"filenames_batch{rnd}: " + json.dumps(selected_names) + "\n")
+                new_reflections, refined = _bcast(shard, (new_reflections, refined))
+                if use_reflection:                                              # :286-294
+                    round_prompts = ([refined[i] + " [Reflexion]: " + new_reflections[i] for i in range(len(new_reflections))]
+                                     if new_reflections else list(refined))
+                    round_prompts += [prompt] * (N - len(round_prompts))
+            # ---- generation + scoring (:297-356)
+            seeds, names, scores, local = generate_round(rnd, sel, payload, round_prompts, "midimg")
+            parents = [selected_names[i] if i < len(sel) else None for i in range(N)]
+            tree.record(rnd, names, scores, parents)                            # :358-395
+            best_chain = tree.best_of_chains()
+            # ---- artefacts (:397-444), rank 0, after every rank's files exist (the score all-gather ordered them)
+            if shard.rank == 0:
+                if rnd == R:
+                    for i, n in enumerate(names):
+                        _copy(os.path.join(outpath, n), os.path.join(dirs["samples_lastround"], f"{i:05}"))
+                for i, n in enumerate(names if rnd == 1 else best_chain):
+                    _copy(os.path.join(outpath, n), os.path.join(dirs["samples_path_bestround"], f"{i:05}"))
+                if rnd == R:                                                    # the reference names this file by a leftover loop index
+                    last_i = (len(names) if rnd == 1 else len(best_chain)) - 1
+                    _copy(os.path.join(outpath, tree.best_overall()), os.path.join(dirs["samples_best"], f"{last_i:05}"))
+            rec = {"prompt": prompt, "round": rnd, "seeds": seeds, "scores": scores, "selected": sel,
+                   "selected_names": selected_names, "parents": parents, "generated": names, "prompts": round_prompts,
+                   "chains": tree.snapshot(), "best_of_chains": best_chain, "flag_terminated": rnd == R}
+            if use_reflection:
+                rec["reflections"] = new_reflections
+                reflections = new_reflections                                   # :619-620
+            if use_refine:
+                rec["refined_prompt"] = refined
+                updated_prompt = refined                                        # :621-622
+            log.append(rec)
+            pool_names, pool_scores, pool_local, pool_on_disk = names, scores, local, False     # :623
         if shard.rank == 0:
-            os.makedirs(pdir, exist_ok=True)
-            with open(os.path.join(pdir, "search_log.jsonl"), "w") as f:
+            with open(os.path.join(outpath, "search_log.jsonl"), "w") as f:
                 for r in log:
                     f.write(json.dumps(r) + "\n")
         all_logs += log
+    if shard.world_size > 1:
+        torch.distributed.barrier()
     return all_logs
+
+
+def _evaluation(name: str, score, scalar: bool) -> dict:
+    """One verifier record in the reference's shape (:162-164 nvila; the scalar form keeps the metric name of refine_args)."""
+    if scalar:
+        return {"image_name": name, "overall_score": {"score": score[0]}}
+    return {"image_name": name, "label": "yes" if score[1] == 1 else "no", "score": score[0]}
+
+
+def _payload_condition(pipe: FluxPipeline, payload, height: int, width: int, condition_size: int) -> Condition:
+    """A parent -> its "cot" Condition (tts_reflectionflow.py:273-279): an image file is opened and resized as the reference
+    does; a candidate's packed latents go through `candidate_condition` (decode -> 8-bit image -> resize, or the latent stand-in)."""
+    if isinstance(payload, str):
+        if payload.endswith(".pt"):
+            return candidate_condition(pipe, torch.load(payload).to(pipe.device, pipe.dtype), height, width, condition_size)
+        from PIL import Image
+        img = Image.open(payload).resize((condition_size, condition_size))
+        return Condition(condition=img, condition_type="cot", position_delta=[0, -condition_size // 16])
+    return candidate_condition(pipe, payload, height, width, condition_size)
+
+
+def _score_local(shard, n, mine, local, seeds, verifier, score_batch):
+    """This rank's candidates -> ONE batched verifier call -> ONE all-gather of {f32, i32} records -> all n (score, label)."""
+    if verifier is not None and score_batch is None:
+        res = [verifier(local[i], int(seeds[i])) for i in mine]
+        sc = torch.tensor([r[0] for r in res], dtype=torch.float32)
+        lab = torch.tensor([r[1] for r in res], dtype=torch.int32)
+    elif mine:
+        fn = score_batch or search.stub_score_batch
+        sc, lab = fn(torch.stack([local[i].reshape(-1, local[i].shape[-1]) for i in mine]), [int(seeds[i]) for i in mine])[:2]
+    else:
+        sc, lab = torch.empty(0, dtype=torch.float32), torch.empty(0, dtype=torch.int32)
+    s_all, l_all = search.allgather_score_tensors(shard, n, sc, lab)
+    return [(float(a), int(b)) for a, b in zip(s_all.tolist(), l_all.tolist())]

@@ -11,7 +11,12 @@ deterministic top-k.  The reflection loop adds ONE all-gather of the selected pa
 
 Selection rule = the reference's NVILA key (tts_reflectionflow.py:165-170): label "yes" first by
 descending score, then "no" by ascending score; ties broken by candidate index; the selection is
-padded by repetition when topk exceeds the pool (:179-182).
+padded by repetition when topk exceeds the pool (:179-182).  A scalar ("openai") verifier sorts by
+descending score (:152-156).
+
+`ReflectionTree` is the reference's per-prompt search state (tts_reflectionflow.py:157-182 selection,
+:273-279 / :297-313 candidate i <- i-th best parent, :337-395 chains, :402-444 best-of-chain / best
+overall), pinned by `tests/golden/search_tree.json`, which was recorded from the reference's own `main()`.
 """
 from __future__ import annotations
 
@@ -96,36 +101,131 @@ def allgather_score_tensors(shard: Shard, n: int, scores: torch.Tensor, labels: 
     return sel[:, 0].contiguous().view(torch.float32), sel[:, 1].contiguous()
 
 
+def _owner_slots(shard: Shard, sel: Sequence[int]):
+    """Where each distinct selected candidate travels: candidate i -> (owner rank, slot in the owner's buffer); every rank
+    derives the same table from `sel`.  Returns (slots, per) with per = the largest number of selected candidates one rank owns."""
+    slots: Dict[int, Tuple[int, int]] = {}
+    count = [0] * shard.world_size
+    for i in sorted(set(int(x) for x in sel)):
+        r = shard.owner(i)
+        slots[i] = (r, count[r])
+        count[r] += 1
+    return slots, max(count) if count else 0
+
+
 def allgather_selected_latents(shard: Shard, sel: Sequence[int], local: Dict[int, torch.Tensor], like: torch.Tensor, device=None):
     """Hand the selected candidates' packed latents to every rank with ONE all-gather (the reference hands PNG paths over,
-    tts_reflectionflow.py:145,160,328-332): every rank contributes a [len(sel), ...] buffer holding the selected latents it
-    owns (zeros elsewhere); slot j of the result is read from its owner's block.  len(sel) x 512 KiB per rank at 1024^2.
+    tts_reflectionflow.py:145,160,328-332).  OWNERS ONLY: a rank contributes the selected latents it generated, each exactly once
+    (repeats in `sel` and candidates of other ranks cost nothing), in a buffer of `per` slots = the largest per-rank count.  With
+    the reference's topk = N every candidate is selected once: N x 512 KiB in total at 1024^2 (16 MiB for N = 32), not world x that.
     `like`: a tensor with a latent's shape/dtype (for ranks that own none).  Returns the list of latents in `sel` order."""
     if shard.world_size == 1:
         return [local[i] for i in sel]
     dev = _collective_device(device)
-    k = len(sel)
-    mine = torch.zeros((k,) + tuple(like.shape), dtype=like.dtype, device=dev)
-    for j, i in enumerate(sel):
-        if i in local:
+    slots, per = _owner_slots(shard, sel)
+    mine = torch.zeros((per,) + tuple(like.shape), dtype=like.dtype, device=dev)
+    for i, (r, j) in slots.items():
+        if r == shard.rank:
             mine[j] = local[i].to(dev)
-    out = torch.empty((shard.world_size * k,) + tuple(like.shape), dtype=like.dtype, device=dev)
+    out = torch.empty((shard.world_size * per,) + tuple(like.shape), dtype=like.dtype, device=dev)
     dist.all_gather_into_tensor(out, mine)
-    out = out.view((shard.world_size, k) + tuple(like.shape))
-    return [out[shard.owner(i), j].to(like.device) for j, i in enumerate(sel)]
+    out = out.view((shard.world_size, per) + tuple(like.shape))
+    return [out[slots[int(i)][0], slots[int(i)][1]].to(like.device) for i in sel]
+
+
+def selected_latents_bytes(shard: Shard, sel: Sequence[int], like: torch.Tensor) -> int:
+    """Bytes one rank RECEIVES in allgather_selected_latents (world x per slots)."""
+    _, per = _owner_slots(shard, sel)
+    return shard.world_size * per * like.numel() * like.element_size()
 
 
 def nvila_sort_key(score: float, label: int, index: int):
-    """tts_reflectionflow.py:165-170 (+ index tie-break so every rank picks the same candidates)."""
+    """tts_reflectionflow.py:165-170 (+ index tie-break = Python's stable sort, so every rank picks the same candidates)."""
     return (0, -score, index) if label == 1 else (1, score, index)
 
 
-def select_topk(scores: Sequence[Tuple[float, int]], topk: int) -> List[int]:
-    order = sorted(range(len(scores)), key=lambda i: nvila_sort_key(scores[i][0], scores[i][1], i))
+def scalar_sort_key(score: float, label: int, index: int):
+    """tts_reflectionflow.py:152-156: a scalar-metric ("openai") verifier -- descending score, stable."""
+    return (-score, index)
+
+
+SORT_KEYS = {"nvila": nvila_sort_key, "stub": nvila_sort_key, "openai": scalar_sort_key}
+
+
+def select_topk(scores: Sequence[Tuple[float, int]], topk: int, kind: str = "nvila") -> List[int]:
+    key = SORT_KEYS[kind]
+    order = sorted(range(len(scores)), key=lambda i: key(scores[i][0], scores[i][1], i))
     sel = order[:topk]
-    if topk > len(sel) and sel:                       # tts_reflectionflow.py:179-182
+    if topk > len(sel) and sel:                       # tts_reflectionflow.py:179-182 (one repetition of the head, no more)
         sel = sel + sel[: topk - len(sel)]
     return sel
+
+
+class ReflectionTree:
+    """Per-prompt state of the reflection search, the way the reference keeps it.
+
+    Vocabulary: a POOL is the previous round's images (round 1: the `--imgpath` images, tts_reflectionflow.py:556-565);
+    `select` orders it (:157-182); candidate i of the round is generated from parent `selected[i]` (:273-279, 297-313;
+    candidates beyond the padded selection get no condition); `record` files the round's candidates into CHAINS
+    (:358-395): round 1 opens one chain per candidate, later a candidate joins the first chain that holds its parent.
+    `best_of_chains` / `best_overall` are :402-444.  Images are identified by caller-chosen names (the reference uses file
+    paths).  Labels are 1 = "yes", 0 = "no" (None for a scalar verifier)."""
+
+    def __init__(self, kind: str = "nvila"):
+        if kind not in SORT_KEYS:
+            raise ValueError(f"verifier kind must be one of {sorted(SORT_KEYS)}")
+        self.kind = kind
+        self.scalar = SORT_KEYS[kind] is scalar_sort_key
+        self.chains: Dict[str, Dict[str, list]] = {}          # insertion-ordered, keyed by the round-1 image
+
+    def select(self, scores: Sequence[Tuple[float, int]], topk: int) -> List[int]:
+        return select_topk(scores, topk, self.kind)
+
+    def record(self, search_round: int, names: Sequence[str], scores: Sequence[Tuple[float, int]],
+               parents: Sequence[Optional[str]]) -> None:
+        for i, name in enumerate(names):
+            sc, lab = float(scores[i][0]), scores[i][1]
+            if search_round == 1:
+                ch = self.chains.setdefault(name, {"images": [], "scores": [], "labels": []})
+                self._append(ch, name, sc, lab)
+                continue
+            for ch in self.chains.values():               # the first chain holding the parent (:388-392); an image is in one chain
+                if parents[i] in ch["images"]:
+                    self._append(ch, name, sc, lab)
+                    break
+
+    @staticmethod
+    def _append(ch, name, sc, lab):
+        ch["images"].append(name)
+        ch["scores"].append(sc)
+        ch["labels"].append(lab)
+
+    def _best_index(self, ch) -> int:
+        key = SORT_KEYS[self.kind]
+        return min(range(len(ch["scores"])), key=lambda j: key(ch["scores"][j], ch["labels"][j], j))
+
+    def best_of_chains(self) -> List[str]:
+        """One image per chain, in chain order (:410-425)."""
+        return [ch["images"][self._best_index(ch)] for ch in self.chains.values()]
+
+    def best_overall(self) -> Optional[str]:
+        """The best image over all chains (:428-444)."""
+        key = SORT_KEYS[self.kind]
+        flat = [(ch["scores"][j], ch["labels"][j], ch["images"][j]) for ch in self.chains.values() for j in range(len(ch["images"]))]
+        if not flat:
+            return None
+        k = min(range(len(flat)), key=lambda j: key(flat[j][0], flat[j][1], j))
+        return flat[k][2]
+
+    def snapshot(self) -> Dict[str, Dict[str, list]]:
+        """JSON form with the reference's field names ("labels" as yes / no; absent for a scalar verifier)."""
+        out = {}
+        for k, ch in self.chains.items():
+            d = {"images": list(ch["images"]), "scores": list(ch["scores"])}
+            if not self.scalar:
+                d["labels"] = ["yes" if l == 1 else "no" for l in ch["labels"]]
+            out[k] = d
+        return out
 
 
 def stub_verifier(latents: torch.Tensor, seed: int) -> Tuple[float, int]:
@@ -144,14 +244,16 @@ def stub_score_batch(latents: torch.Tensor, seeds: Sequence[int]):
     lat = latents.reshape(latents.shape[0], -1) if latents.dim() > 2 else latents
     base = torch.tensor([(((int(sd) * 2654435761) & 0xFFFFFFFF) % 10007) / 10007.0 for sd in seeds], dtype=torch.float32,
                         device=lat.device)
-    stat = lat.float().abs().mean(dim=1)
+    # one reduction PER ROW: the fp32 summation order of a row must not depend on how many rows (= which world size) share the
+    # call, or a near-tie could flip between world sizes (score_batch implementations must be row-wise batch-invariant)
+    stat = torch.stack([row.float().abs().mean() for row in lat]) if lat.shape[0] else lat.new_zeros(0, dtype=torch.float32)
     scores = 0.5 * base + 0.5 * torch.remainder(stat, 1.0)
     return scores, (scores >= 0.5).to(torch.int32)
 
 
 def run_round(shard: Shard, seeds: Sequence[int], generate_fn: Callable[[int, int], torch.Tensor],
               verifier: Optional[Callable[[torch.Tensor, int], Tuple[float, int]]] = None, topk: int = 1,
-              score_batch: Optional[Callable] = None):
+              score_batch: Optional[Callable] = None, kind: str = "nvila"):
     """One search round: this rank generates its candidates, scores them (ONE batched verifier call: `score_batch`, default
     the stub; a per-candidate `verifier(latents, seed) -> (score, label)` is wrapped), all ranks exchange the {f32, i32}
     records with one all-gather and agree on the top-k.  Returns (selected candidate indices, all scores, local latents)."""
@@ -171,4 +273,4 @@ def run_round(shard: Shard, seeds: Sequence[int], generate_fn: Callable[[int, in
         sc, lab = torch.empty(0, dtype=torch.float32), torch.empty(0, dtype=torch.int32)
     s_all, l_all = allgather_score_tensors(shard, n, sc, lab)
     scores = [(float(a), int(b)) for a, b in zip(s_all.tolist(), l_all.tolist())]
-    return select_topk(scores, topk), scores, local_lat
+    return select_topk(scores, topk, kind), scores, local_lat

@@ -271,8 +271,8 @@ def test_cfg1_small_model_denoise_matches_oracle(dev):
 
 @torch.no_grad()
 def test_reflection_search_runner_small(dev, tmp_path):
-    """tts_reflectionflow-style search (round 0 plain, then rounds conditioned on the selected candidate with the
-    corrector LoRA on the condition tokens) on a 2+2-block model: runs, is deterministic, writes the artefacts."""
+    """tts_reflectionflow-style search (a plain "round 0" pool, then rounds conditioned on the i-th best parent with the corrector
+    LoRA on the condition tokens) on a 2+2-block model: runs, is deterministic, writes the reference's artefact tree."""
     import json
     import os
     from reflectionflow_amd.flux.pipeline import synthetic_lora_state_dict
@@ -286,12 +286,64 @@ def test_reflection_search_runner_small(dev, tmp_path):
         pipe.load_lora_weights(synthetic_lora_state_dict(pipe.transformer, r=8, seed=3), adapter_name="reflection")
         out = str(tmp_path / f"run{rep}")
         logs.append(runner.run_reflection_search(cfg, ["a red cube left of a blue ball"], out, pipe, search.Shard(0, 1)))
-        files = sorted(os.listdir(os.path.join(out, "00000", "samples")))
-        assert len(files) == 3 * 3 and all(f.endswith(".pt") and "_round@" in f for f in files)
-        lat = torch.load(os.path.join(out, "00000", "samples", files[-1]))
+        pdir = os.path.join(out, "00000")
+        pool, mid = sorted(os.listdir(os.path.join(pdir, "samples"))), sorted(os.listdir(os.path.join(pdir, "midimg")))
+        assert len(pool) == 3 and len(mid) == 2 * 3 and all(f.endswith(".pt") and "_round@" in f for f in pool + mid)
+        lat = torch.load(os.path.join(pdir, "midimg", mid[-1]))
         assert lat.shape == (1, 256, 64) and torch.isfinite(lat.float()).all()
+        for d, n in (("samples_lastround", 3), ("samples_path_bestround", 3), ("samples_best", 1)):
+            assert len(os.listdir(os.path.join(pdir, d))) == n, d
+        assert len(open(os.path.join(pdir, "best_img_detailedscore.jsonl")).read().splitlines()) == 2
     assert logs[0] == logs[1], "search must be deterministic for fixed seeds"
-    assert [r["round"] for r in logs[0]] == [0, 1, 2] and all(len(r["selected"]) == 1 for r in logs[0])
+    assert [r["round"] for r in logs[0]] == [0, 1, 2]
+    # the reference's tree: topk = search_branch, candidate i <- the i-th best of the previous round, one chain per round-1 candidate
+    for r in logs[0][1:]:
+        assert sorted(r["selected"]) == [0, 1, 2] and len(r["parents"]) == 3 and len(r["chains"]) == 3
+    assert all(len(ch["images"]) == 2 for ch in logs[0][2]["chains"].values())
+
+
+@torch.no_grad()
+def test_reflection_search_on_gpu_follows_the_reference_fixture(dev, tmp_path):
+    """The same replay as tests/test_search_tree.py, but with the real GPU work in the loop: 2+2-block model, corrector LoRA, HIP VAE
+    (decode -> 8-bit image -> resize -> encode hand-off, PNG artefacts).  The verifier table of the fixture scenario `nvila_n4_r3`
+    (recorded from the reference's main()) is replayed by candidate; parents, chains and best-of-chain must equal the fixture's."""
+    import json
+    import os
+    from reflectionflow_amd.flux.pipeline import FluxPipeline, synthetic_lora_state_dict
+    from reflectionflow_amd.tts import runner, search
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "search_tree.json")))["nvila_n4_r3"]
+    N, R, table = 4, 3, gold["table"]
+    small = dict(num_layers=2, num_single_layers=2, num_attention_heads=2, joint_attention_dim=256, pooled_projection_dim=64)
+    pipe = FluxPipeline.synthetic(small, seed=0, device=dev, with_vae=True,
+                                  vae_config=dict(block_out_channels=(64, 128, 256, 512), norm_num_groups=32))   # 8x, 512-channel mid attention
+    pipe.set_progress_bar_config(disable=True)
+    pipe.enable_hip_vae()
+    pipe.load_lora_weights(synthetic_lora_state_dict(pipe.transformer, r=8, seed=3), adapter_name="reflection")
+    cfg = {"pipeline_args": dict(height=256, width=256, condition_size=128, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64),
+           "search_args": dict(search_branch=N, search_rounds=R), "verifier_args": {"name": "nvila"}, "model": {"union_cond_attn": True}}
+    seed2name, logical = {}, {}
+    for r in range(0, R + 1):
+        for i, s in enumerate(runner.candidate_seeds(0, r, N)):
+            seed2name[s] = f"init{i}" if r == 0 else f"r{r}c{i}"
+            logical[("samples" if r == 0 else "midimg") + f"/{r}_round@{s}.png"] = seed2name[s]
+
+    def score_batch(latents, seeds):
+        assert latents.is_cuda and latents.shape == (len(seeds), 256, 64)
+        names = [seed2name[s] for s in seeds]
+        return (torch.tensor([table[n][1] for n in names], dtype=torch.float32, device=latents.device),
+                torch.tensor([1 if table[n][0] == "yes" else 0 for n in names], dtype=torch.int32, device=latents.device))
+    out = str(tmp_path / "out")
+    log = runner.run_reflection_search(cfg, [gold["prompt"]], out, pipe, search.Shard(0, 1), score_batch=score_batch)
+    for rec, gr in zip(log[1:], gold["rounds"]):
+        assert [logical[p] for p in rec["parents"]] == gr["parents"]
+        assert {logical[k]: [logical[n] for n in ch["images"]] for k, ch in rec["chains"].items()} == \
+               {k: ch["images"] for k, ch in gr["chains"].items()}
+        assert {logical[k]: ch["scores"] for k, ch in rec["chains"].items()} == {k: ch["scores"] for k, ch in gr["chains"].items()}
+    from PIL import Image
+    pdir = os.path.join(out, "00000")
+    best = Image.open(os.path.join(pdir, "samples_best", os.listdir(os.path.join(pdir, "samples_best"))[0]))
+    want = [n for n, l in logical.items() if l == list(gold["samples_best"].values())[0]][0]
+    assert best.size == (256, 256) and best.tobytes() == Image.open(os.path.join(pdir, want)).tobytes()
 
 
 @torch.no_grad()

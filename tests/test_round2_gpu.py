@@ -319,7 +319,8 @@ def test_pil_output_and_reference_round_handoff_with_vae(dev, tmp_path):
     for rep in range(2):
         out = str(tmp_path / f"run{rep}")
         logs.append(runner.run_reflection_search(cfg, ["a red cube left of a blue ball"], out, pipe, search.Shard(0, 1)))
-        files = sorted(os.listdir(os.path.join(out, "00000", "samples")))
-        assert len(files) == 4 and all(f.endswith(".png") for f in files)
-        assert Image.open(os.path.join(out, "00000", "samples", files[0])).size == (256, 256)
+        files = sorted(os.listdir(os.path.join(out, "00000", "samples")))               # the plain "round 0" pool
+        mid = sorted(os.listdir(os.path.join(out, "00000", "midimg")))                  # round 1, as the reference names it
+        assert len(files) == 2 and len(mid) == 2 and all(f.endswith(".png") for f in files + mid)
+        assert Image.open(os.path.join(out, "00000", "midimg", mid[0])).size == (256, 256)
     assert logs[0] == logs[1]

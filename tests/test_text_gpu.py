@@ -240,8 +240,8 @@ def test_pipeline_text_encoder_contract(dev):
 
 @torch.no_grad()
 def test_reflection_runner_encodes_a_rounds_prompts_in_one_batch(dev, tmp_path):
-    """run_reflection_search with a per-candidate `refine_prompt` hook (the reference's reflection LLM rewrites the prompt per candidate
-    and round, tts_reflectionflow.py:286-294): the rank's distinct prompts of a round go through the HIP text encoders in ONE batched
+    """run_reflection_search with `reflect` / `refine` hooks (the reference's reflection LLM rewrites the prompt per candidate and
+    round, tts_reflectionflow.py:286-294): the rank's distinct prompts of a round go through the HIP text encoders in ONE batched
     call per tower, not one call per candidate."""
     from reflectionflow_amd.flux.pipeline import FluxPipeline
     from reflectionflow_amd.tts import runner, search
@@ -261,12 +261,15 @@ def test_reflection_runner_encodes_a_rounds_prompts_in_one_batch(dev, tmp_path):
     pipe.enable_hip_text_encoders(TO.synthetic_t5_state(128, 256, 64, 4, 512, 2, seed=3), TO.synthetic_clip_state(128, 64, 1, 128, 2, 77, seed=4),
                                   tokenize, t5_heads=4, clip_heads=1)
     cfg = {"pipeline_args": dict(height=64, width=64, condition_size=32, num_inference_steps=2, guidance_scale=3.5, max_sequence_length=64),
-           "search_args": dict(search_branch=4, search_rounds=0, topk=1), "model": {}}
+           "search_args": dict(search_branch=4, search_rounds=1), "model": {}}
     log = runner.run_reflection_search(cfg, ["a red cube"], str(tmp_path), pipe, search.Shard(0, 1),
-                                       refine_prompt=lambda p, rnd, i, seed: f"{p} [Reflexion]: variant {i % 2}")
-    assert len(log) == 1 and len(log[0]["scores"]) == 4
-    # one round, 4 candidates, 2 distinct prompts: exactly one T5 call and one CLIP call, each over the 2 distinct prompts
-    assert calls == [(2, 64), (2, 77)], calls
+                                       reflect=lambda ctx: [f"variant {i % 2}" for i in range(len(ctx["selected"]))],
+                                       refine=lambda ctx, refl: list(ctx["current_prompt"]))
+    assert len(log) == 2 and len(log[1]["scores"]) == 4
+    assert log[1]["prompts"] == [f"a red cube [Reflexion]: variant {i % 2}" for i in range(4)]
+    # the pool round: one prompt; round 1: 4 candidates, 2 distinct prompts -> exactly one T5 pass and one CLIP pass per round, each
+    # over the distinct prompts only
+    assert calls == [(1, 64), (1, 77), (2, 64), (2, 77)], calls
 
 
 @torch.no_grad()
