@@ -472,6 +472,69 @@ int64_t rf_clip_text_workspace_bytes(const rf_clip_weights* w, int32_t B, int32_
 int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t B, int32_t S, const int32_t* eos_pos, void* last_hidden, void* pooled,
                         const rf_workspace* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * TRAINING path: backward of the same blocks, for the LoRA reflection tuning of
+ * train_flux/train/model.py:164-238 (flow-matching MSE through tranformer_forward; per-block recompute = the
+ * gradient-checkpoint branch train_flux/flux/transformer.py:139-157).  Base weights are frozen, so a block's backward is
+ *   dX through every GEMM      = rf_gemm_bf16 on TRANSPOSED weight copies  (dX = dY W  ==  dY (W^T)^T)
+ *   LoRA factor gradients      = rf_gemm_bf16 over the TOKEN axis on rf_transpose_bf16'd operands
+ *   everything else            = the kernels below.
+ * Gradients travel between kernels as bf16 (as torch's bf16 autograd does), sums are fp32, column reductions are
+ * fixed-order two-stage sums: the whole backward is bit-reproducible (no atomics).
+ * ---------------------------------------------------------------------------------- */
+
+/* The attention operands of a training step from the RAW q|k|v rows (the QKV GEMM with RF_EPI_STORE, [S][ld_raw],
+ * columns [q | k | v] of heads*128 each): per-head RMSNorm + RoPE as rf_qk_rmsnorm_rope (rows < n_added use w_added_*),
+ * q scaled by q_scale (softmax_scale * log2 e), written as
+ *   q, k, v : [heads][s_pad][128] head-major rows (rows >= S zero),
+ *   vt      : rf_attention's V^T tiles,
+ *   qt, kt  : [heads][s_pad/32][128][32] TRANSPOSED TILES for rf_attention_bwd: element (d, slot(n)) of block n/32 holds
+ *             x[n][d], slot(n) = 8 ((n%16)/4) + 4 ((n%32)/16) + n%4 -- the order in which a 16x16x32 MFMA consumes the
+ *             rows of two 16x16 score tiles. */
+int rf_qkv_train_fwd(const void* raw, int64_t ld_raw, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,
+                     const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k,
+                     const float* cos_tab, const float* sin_tab, float eps, float q_scale,
+                     void* q, void* k, void* v, void* vt, void* qt, void* kt, void* stream);
+/* Its backward: (dq, dk, dv) head-major [heads][s_pad][128] (dq = gradient w.r.t. the SCALED q) -> d_raw [S][ld_draw]. */
+int rf_qkv_train_bwd(const void* raw, int64_t ld_raw, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,
+                     const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k,
+                     const float* cos_tab, const float* sin_tab, float eps, float q_scale,
+                     const void* dq, const void* dk, const void* dv, void* d_raw, int64_t ld_draw, void* stream);
+
+/* Flash-attention backward (F.scaled_dot_product_attention of block.py:123-125), plain joint attention (mode 0):
+ *   q (scaled), k, v, qt, kt from rf_qkv_train_fwd;  o = the forward's output, dout = its gradient, both [S][ld] token-major;
+ *   dq, dk, dv: [heads][s_pad][128] bf16;  dot ([heads][s_pad/32][128][32] bf16), lse, dsum (fp32 [heads][s_pad]): scratch.
+ * Three launches: D = rowsum(dO o O) + dO^T tiles; per 64 queries the row statistics then dq; per 128 keys dk, dv. */
+typedef struct rf_attn_bwd_desc {
+  const void *q, *k, *v, *qt, *kt;
+  const void *o, *dout; int64_t ldo, lddo;
+  void *dq, *dk, *dv;
+  void* dot; float* lse; float* dsum;
+  int32_t heads, S, s_pad, mode;
+} rf_attn_bwd_desc;
+int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream);
+
+/* y = LayerNorm(x) (1 + scale) + shift  (rf_layernorm_modulate):  dx[m] = (dres ? dres[m] : 0) + LN-backward(dy[m]);
+ * d_scale[c] = sum_m dy[m,c] xhat[m,c], d_shift[c] = sum_m dy[m,c]  (fp32 [D]).  partials: scratch of
+ * rf_train_partials_bytes(D) bytes.  D % 8 == 0, D <= 3072. */
+int64_t rf_train_partials_bytes(int32_t D);
+int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* dres, int64_t lddres,
+                              void* dx, int64_t lddx, int32_t rows, int32_t D, const void* scale, float eps,
+                              float* d_scale, float* d_shift, float* partials, int64_t partials_bytes, void* stream);
+/* y = residual + gate o f  (RF_EPI_GATE_RES):  df = gate o dy (bf16),  d_gate[c] = sum_m dy[m,c] f[m,c] (fp32 [D]). */
+int rf_gate_bwd(const void* dy, int64_t lddy, const void* f, int64_t ldf, const void* gate, void* df, int64_t lddf,
+                int32_t rows, int32_t D, float* d_gate, float* partials, int64_t partials_bytes, void* stream);
+/* out = res + gate o f, the gated residual as its own pass (the training forward keeps f for rf_gate_bwd) */
+int rf_gate_residual(const void* f, int64_t ldf, const void* gate, const void* res, int64_t ldr, void* out, int64_t ldo,
+                     int32_t rows, int32_t D, void* stream);
+/* h = gelu_tanh(z);  dz = dh * gelu_tanh'(z)   (block.py:252,296) */
+int rf_gelu(const void* z, int64_t ldz, void* h, int64_t ldh, int32_t rows, int32_t cols, void* stream);
+int rf_gelu_bwd(const void* z, int64_t ldz, const void* dh, int64_t lddh, void* dz, int64_t lddz, int32_t rows, int32_t cols,
+                void* stream);
+/* dst[c][r] = src[r][c], r < rows; zero for rows <= r < rows_pad (the K % 64 padding of a token-axis contraction) */
+int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, int32_t cols, void* dst, int64_t ld_dst,
+                      int32_t rows_pad, void* stream);
+
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
  * shape with hipEvents on `stream`; returns average microseconds in *us. */
 int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
@@ -493,7 +556,8 @@ typedef enum rf_kernel_class {
   RF_KC_ROWOP = 3,       /* LayerNorm+modulate, RMSNorm+RoPE, Euler, SiLU, add */
   RF_KC_GEMM_W8 = 4,     /* fp8-weight GEMM launches (rf_gemm_w8a8) */
   RF_KC_QUANT = 5,       /* activation quantisation row kernels of the fp8 path */
-  RF_KC_COUNT = 6
+  RF_KC_ATTN_BWD = 6,    /* rf_attention_bwd (work = 5 products x 2 S^2 128 per head = 2.5 x the forward's) */
+  RF_KC_COUNT = 7
 } rf_kernel_class;
 int rf_profile_begin(int32_t max_launches);
 int rf_profile_end(double* us_sum /*[RF_KC_COUNT]*/, int64_t* launches /*[RF_KC_COUNT]*/,

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -52,6 +52,12 @@ class rf_attn_desc(C.Structure):
                 ("ldo", C.c_int64), ("mode", C.c_int32), ("q_prescaled", C.c_int32),
                 ("cross_bias", C.c_float), ("scale", C.c_float), ("score_bound", C.c_float), ("lag_thresh", C.c_float),
                 ("kernel", C.c_int32), ("mix_small", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+
+
+class rf_attn_bwd_desc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "qt", "kt", "o", "dout")] + [("ldo", C.c_int64), ("lddo", C.c_int64)] + [
+        (n, C.c_void_p) for n in ("dq", "dk", "dv", "dot", "lse", "dsum")] + [
+        ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("mode", C.c_int32)]
 
 
 class rf_w8(C.Structure):
@@ -186,11 +192,25 @@ _SIGS = {
     "rf_t5_encode": (C.c_int, [C.POINTER(rf_t5_weights), _P, C.c_int32, C.c_int32, _P, C.c_int64, C.POINTER(rf_workspace), _P]),
     "rf_clip_text_workspace_bytes": (C.c_int64, [C.POINTER(rf_clip_weights), C.c_int32, C.c_int32]),
     "rf_clip_text_encode": (C.c_int, [C.POINTER(rf_clip_weights), _P, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _P, _P, C.POINTER(rf_workspace), _P]),
+    # training path
+    "rf_qkv_train_fwd": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                   _P, _P, _P, _P, _P, _P, _P]),
+    "rf_qkv_train_bwd": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float,
+                                   _P, _P, _P, _P, C.c_int64, _P]),
+    "rf_attention_bwd": (C.c_int, [C.POINTER(rf_attn_bwd_desc), _P]),
+    "rf_train_partials_bytes": (C.c_int64, [C.c_int32]),
+    "rf_layernorm_modulate_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_float,
+                                            _P, _P, _P, C.c_int64, _P]),
+    "rf_gate_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64, _P]),
+    "rf_gate_residual": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "rf_gelu": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "rf_gelu_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "rf_transpose_bf16": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int64, C.c_int32, _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),
     "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int32)]),
 }
-RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant")
+RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant", "attention_bwd")
 # read-only introspection (tests, bench); not part of the declared drop-in surface.  librf_flux.so exports NO kernel-selecting
 # switch: tests pin a kernel per launch through rf_gemm_desc.schedule / rf_attn_desc.kernel.
 _EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),

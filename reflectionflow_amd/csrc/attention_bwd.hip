@@ -1,0 +1,350 @@
+// Flash-attention BACKWARD for gfx950 (MI355X), head_dim 128, non-causal joint attention (the training
+// step of train_flux/train/model.py:164-238 differentiates F.scaled_dot_product_attention of block.py:123-125).
+//
+//   forward (recomputed by the caller):  s2 = q~ . k   (q~ carries softmax_scale * log2 e),  P = exp2(s2 - lse2),  O = P V
+//   backward:   D  = rowsum(dO o O)                 dV = P^T dO
+//               dP = dO V^T                         g  = ln2 * P o (dP - D)          ( = dL/ds2 )
+//               dq~ = g K                           dK = g^T q~
+//
+// Deterministic, no atomics: two kernels, each accumulating its outputs in registers over a loop --
+//   attn_bwd_dq_kernel   one workgroup per 64 queries (a wave owns 16): pass 1 streams the keys once for the row statistics
+//                        lse2 (online max / sum; the forward kernels do not emit them), pass 2 streams them again for dq~;
+//   attn_bwd_dkv_kernel  one workgroup per 64 * KT keys (a wave owns KT tiles of 16), streams the queries for dK, dV.
+// All five products run on v_mfma_f32_16x16x32_bf16.  A 16x16 score tile leaves a lane with 4 rows of ONE column, so two
+// tiles give the 8 contraction slots of the next MFMA's operand without any data movement, provided the other operand is
+// laid out in the same slot order:  slot(n) = 8 ((n % 16) / 4) + 4 (n / 16) + n % 4  for index n of a block of 32
+// (the trick of the forward kernels' V^T).  The producers write those operands once as TRANSPOSED TILES
+//   xT [heads][s_pad / 32][128 (d)][32 (slot)]     for x in {q~, k, dO}
+// (rf_qkv_train_fwd for q~ / k, attn_bwd_prep_kernel for dO), so every LDS stage here is a straight 16-byte copy and every
+// fragment read a conflict-free ds_read_b128: row-major [32][128] tiles are XOR-swizzled per 16-byte chunk (chunk ^ (row & 15)),
+// transposed tiles are read as 1 KiB contiguous per fragment.
+#include "common.hpp"
+
+namespace rf {
+
+constexpr int AB_ROWS = 32 * 256;     // bytes of a [32][128] bf16 tile (row-major, swizzled) or of a transposed tile
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int slot32(int n) { return 8 * ((n & 15) >> 2) + 4 * (n >> 4) + (n & 3); }
+
+// 256 threads copy a [32][128] bf16 row tile (global row pitch ld elements, rows >= rows_valid read as zero) into the swizzled image
+__device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, int64_t ld, int rows_valid, int tid) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int idx = tid + 256 * p, r = idx >> 4, c = idx & 15;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < rows_valid) v = *(const u32x4*)(src + (int64_t)r * ld + c * 8);
+    *(u32x4*)(dst + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+  }
+}
+// ... and a transposed tile (8 KiB contiguous)
+__device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int tid) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int idx = tid + 256 * p;
+    *(u32x4*)(dst + idx * 16) = *(const u32x4*)(src + idx * 8);
+  }
+}
+// A/B fragment of a swizzled row tile: lane (g, i) <- row 16 t + i, elements 32 ks + 8 g .. + 7
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int t, int ks, int l15, int g) {
+  const int r = 16 * t + l15;
+  return *(const bf16x8*)(tile + r * 256 + (((4 * ks + g) ^ (r & 15)) << 4));
+}
+// fragment of a transposed tile: lane (g, i) <- d = 16 dt + i, slots 8 g .. 8 g + 7
+__device__ __forceinline__ bf16x8 frag_tile(const char* tile, int dt, int l15, int g) {
+  return *(const bf16x8*)(tile + (16 * dt + l15) * 64 + g * 16);
+}
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+  return c;
+#endif
+}
+
+// ---- prep: D = rowsum(dO o O), dO^T tiles -----------------------------------------------------------------------------------
+// grid (s_pad / 32, heads), 256 threads: 32 tokens x the head's 128 channels.
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, int64_t ldo, const bf16_t* __restrict__ dout,
+                                                            int64_t lddo, bf16_t* __restrict__ dot, float* __restrict__ dsum, int S,
+                                                            int s_pad) {
+  __shared__ bf16_t tile[32][130];          // pitch 65 dwords: column reads of 2-byte elements spread over the banks
+  const int tid = threadIdx.x, head = blockIdx.y, t0 = blockIdx.x * 32;
+  const int i = tid >> 3, c = tid & 7, tok = t0 + i;
+  float part = 0.f;
+  float dv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) dv[e] = 0.f;
+  if (tok < S) {
+    float ov[16];
+    const bf16_t* dp = dout + (int64_t)tok * lddo + head * 128 + c * 16;
+    const bf16_t* op = o + (int64_t)tok * ldo + head * 128 + c * 16;
+    unpack8(*(const u32x4*)dp, *reinterpret_cast<float(*)[8]>(&dv[0]));
+    unpack8(*(const u32x4*)(dp + 8), *reinterpret_cast<float(*)[8]>(&dv[8]));
+    unpack8(*(const u32x4*)op, *reinterpret_cast<float(*)[8]>(&ov[0]));
+    unpack8(*(const u32x4*)(op + 8), *reinterpret_cast<float(*)[8]>(&ov[8]));
+#pragma unroll
+    for (int e = 0; e < 16; ++e) part += dv[e] * ov[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) tile[i][c * 16 + e] = f2bf(dv[e]);
+  part += __shfl_xor(part, 1);
+  part += __shfl_xor(part, 2);
+  part += __shfl_xor(part, 4);
+  if (c == 0) dsum[(int64_t)head * s_pad + tok] = part;
+  __syncthreads();
+  bf16_t* dst = dot + ((int64_t)head * (s_pad >> 5) + blockIdx.x) * (128 * 32);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int d = (tid >> 2) + 64 * p, g = tid & 3;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(tile[(e < 4 ? 4 * g + e : 16 + 4 * g + e - 4)][d]);
+    *(u32x4*)(dst + d * 32 + g * 8) = pack8(v);
+  }
+}
+
+// ---- dq~ (and the row statistics) -------------------------------------------------------------------------------------------
+// grid (s_pad / 64, heads), 256 threads.  LDS: K rows | V rows | K^T tile of the current 32 keys.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                          const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt,
+                                                          const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ dsum,
+                                                          float* __restrict__ lse, bf16_t* __restrict__ dq, int S, int s_pad) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * AB_ROWS];
+  char* const kl = smem;
+  char* const vl = smem + AB_ROWS;
+  char* const ktl = smem + 2 * AB_ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y;
+  const int qrow = blockIdx.x * 64 + w * 16 + l15;            // this lane's query (as a COLUMN of the S^T tiles)
+  const int64_t hb = (int64_t)head * s_pad;
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *(const bf16x8*)(q + (hb + qrow) * 128 + 32 * ks + 8 * g);
+    u32x4 z = {0u, 0u, 0u, 0u};
+    if (qrow < S) z = *(const u32x4*)(dout + (int64_t)qrow * lddo + head * 128 + 32 * ks + 8 * g);
+    dof[ks] = __builtin_bit_cast(bf16x8, z);
+  }
+  const int nsteps = (S + 31) >> 5;
+  const float NEG = -__builtin_huge_valf();
+
+  // pass 1: lse2 of this lane's query over all keys (each lane sees keys 4 g + r (+16) of every step; merged over g at the end)
+  float m = NEG, l = 0.f;
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();
+    stage_rows(kl, k + (hb + st * 32) * 128, 128, 32, tid);
+    __syncthreads();
+    f32x4 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[t] = mfma16(frag_rows(kl, t, ks, l15, g), qf[ks], s[t]);
+    }
+    float mx = m;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (st * 32 + 16 * t + 4 * g + r >= S) s[t][r] = NEG;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    if (mx > NEG) {
+      float add = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) add += __builtin_amdgcn_exp2f(s[t][r] - mx);
+      l = l * __builtin_amdgcn_exp2f(m - mx) + add;     // m = -inf, l = 0 on the first contribution: exp2(-inf) = 0
+      m = mx;
+    }
+  }
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(l, o);
+    const float mn = fmaxf(m, m2);
+    if (mn > NEG) l = l * __builtin_amdgcn_exp2f(m - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
+    m = mn;
+  }
+  // padded queries: lse = +huge makes every P of that row exactly 0 in the dK / dV kernel
+  const float my_lse = (qrow < S && l > 0.f) ? m + __builtin_amdgcn_logf(l) : 1e30f;
+  if (g == 0) lse[hb + qrow] = my_lse;
+  const float my_d = dsum[hb + qrow];
+
+  // pass 2: dq~^T[d][q] += K^T[d][key slots] g^T[key slots][q]
+  f32x4 acc[8];
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int st = 0; st < nsteps; ++st) {
+    __syncthreads();
+    stage_rows(kl, k + (hb + st * 32) * 128, 128, 32, tid);
+    stage_rows(vl, v + (hb + st * 32) * 128, 128, 32, tid);
+    stage_tile(ktl, kt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+    __syncthreads();
+    float gv[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma16(frag_rows(kl, t, ks, l15, g), qf[ks], s);
+        dp = mfma16(frag_rows(vl, t, ks, l15, g), dof[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = st * 32 + 16 * t + 4 * g + r < S;
+        const float p = ok ? __builtin_amdgcn_exp2f(s[r] - my_lse) : 0.f;
+        gv[4 * t + r] = LN2 * p * (dp[r] - my_d);
+      }
+    }
+    const bf16x8 gf = __builtin_bit_cast(bf16x8, pack8(gv));
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) acc[dt] = mfma16(frag_tile(ktl, dt, l15, g), gf, acc[dt]);
+  }
+  bf16_t* drow = dq + (hb + qrow) * 128 + 4 * g;      // padded rows are written too (zeros: their dO and D are zero)
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) {
+    u32x2 o;
+    o[0] = pack2(acc[dt][0], acc[dt][1]);
+    o[1] = pack2(acc[dt][2], acc[dt][3]);
+    *(u32x2*)(drow + 16 * dt) = o;
+  }
+}
+
+// ---- dK, dV -----------------------------------------------------------------------------------------------------------------
+// grid (s_pad / (64 KT), heads), 256 threads; a wave owns KT tiles of 16 keys (their k, v fragments stay in registers).
+// LDS per step of 32 queries: q~ rows | dO rows | q~^T tile | dO^T tile | lse[32] | D[32].
+template <int KT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qt,
+                                                           const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                           const bf16_t* __restrict__ dout, int64_t lddo, const bf16_t* __restrict__ dot,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                           bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int s_pad) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * AB_ROWS + 256];
+  char* const ql = smem;
+  char* const dol = smem + AB_ROWS;
+  char* const qtl = smem + 2 * AB_ROWS;
+  char* const dotl = smem + 3 * AB_ROWS;
+  float* const stat = (float*)(smem + 4 * AB_ROWS);     // lse[32] | D[32]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y;
+  const int64_t hb = (int64_t)head * s_pad;
+  const int kv0 = (blockIdx.x * 4 + w) * 16 * KT;             // first key of this wave
+  bf16x8 kf[KT][4], vf[KT][4];
+#pragma unroll
+  for (int kt_ = 0; kt_ < KT; ++kt_) {
+    int kr = kv0 + 16 * kt_ + l15;
+    kr = kr < s_pad ? kr : s_pad - 1;                         // (a partial last workgroup: results of those lanes are not written)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[kt_][ks] = *(const bf16x8*)(k + (hb + kr) * 128 + 32 * ks + 8 * g);
+      vf[kt_][ks] = *(const bf16x8*)(v + (hb + kr) * 128 + 32 * ks + 8 * g);
+    }
+  }
+  f32x4 akv[KT][8], avv[KT][8];
+#pragma unroll
+  for (int kt_ = 0; kt_ < KT; ++kt_)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) akv[kt_][dt] = f32x4{0.f, 0.f, 0.f, 0.f}, avv[kt_][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (S + 31) >> 5;
+  for (int st = 0; st < nsteps; ++st) {
+    const int q0 = st * 32;
+    __syncthreads();
+    stage_rows(ql, q + (hb + q0) * 128, 128, 32, tid);
+    stage_rows(dol, dout + (int64_t)q0 * lddo + head * 128, lddo, S - q0, tid);
+    stage_tile(qtl, qt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+    stage_tile(dotl, dot + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+    if (tid < 64) stat[tid] = tid < 32 ? lse[hb + q0 + tid] : dsum[hb + q0 + tid - 32];
+    __syncthreads();
+    f32x4 lv[2], dvv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      lv[t] = *(const f32x4*)(stat + 16 * t + 4 * g);
+      dvv[t] = *(const f32x4*)(stat + 32 + 16 * t + 4 * g);
+    }
+    bf16x8 pf[KT], gf[KT];
+#pragma unroll
+    for (int kt_ = 0; kt_ < KT; ++kt_) {
+      float pv[8], gv[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma16(frag_rows(ql, t, ks, l15, g), kf[kt_][ks], s);          // S[q = 16 t + 4 g + r][key = l15]
+          dp = mfma16(frag_rows(dol, t, ks, l15, g), vf[kt_][ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[r] - lv[t][r]);          // padded queries: lse = 1e30 -> 0
+          pv[4 * t + r] = p;
+          gv[4 * t + r] = LN2 * p * (dp[r] - dvv[t][r]);
+        }
+      }
+      pf[kt_] = __builtin_bit_cast(bf16x8, pack8(pv));
+      gf[kt_] = __builtin_bit_cast(bf16x8, pack8(gv));
+    }
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16x8 a_do = frag_tile(dotl, dt, l15, g), a_q = frag_tile(qtl, dt, l15, g);
+#pragma unroll
+      for (int kt_ = 0; kt_ < KT; ++kt_) {
+        avv[kt_][dt] = mfma16(a_do, pf[kt_], avv[kt_][dt]);                  // dV^T[d][key] += dO^T[d][q slots] P[q slots][key]
+        akv[kt_][dt] = mfma16(a_q, gf[kt_], akv[kt_][dt]);                   // dK^T[d][key] += q~^T[d][q slots] g[q slots][key]
+      }
+    }
+  }
+#pragma unroll
+  for (int kt_ = 0; kt_ < KT; ++kt_) {
+    const int kr = kv0 + 16 * kt_ + l15;
+    if (kr < s_pad) {
+      const bool live = kr < S;                                              // padded keys: zeros (they took part as zero rows)
+      bf16_t* krow = dk + (hb + kr) * 128 + 4 * g;
+      bf16_t* vrow = dv + (hb + kr) * 128 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        u32x2 a, b;
+        a[0] = live ? pack2(akv[kt_][dt][0], akv[kt_][dt][1]) : 0u;
+        a[1] = live ? pack2(akv[kt_][dt][2], akv[kt_][dt][3]) : 0u;
+        b[0] = live ? pack2(avv[kt_][dt][0], avv[kt_][dt][1]) : 0u;
+        b[1] = live ? pack2(avv[kt_][dt][2], avv[kt_][dt][3]) : 0u;
+        *(u32x2*)(krow + 16 * dt) = a;
+        *(u32x2*)(vrow + 16 * dt) = b;
+      }
+    }
+  }
+}
+
+}  // namespace rf
+
+extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
+  using namespace rf;
+  RF_REQUIRE(d != nullptr, RF_ERR_NULL, "rf_attention_bwd: NULL descriptor");
+  RF_REQUIRE(d->q && d->k && d->v && d->qt && d->kt && d->o && d->dout && d->dq && d->dk && d->dv && d->dot && d->lse && d->dsum,
+             RF_ERR_NULL, "rf_attention_bwd: NULL operand");
+  RF_REQUIRE(d->heads > 0 && d->S > 0 && d->s_pad >= d->S && d->s_pad % 64 == 0, RF_ERR_SHAPE,
+             "rf_attention_bwd: heads=%d S=%d s_pad=%d (need s_pad %% 64 == 0, s_pad >= S)", d->heads, d->S, d->s_pad);
+  RF_REQUIRE(d->mode == 0, RF_ERR_UNSUPPORTED, "rf_attention_bwd: only the plain joint attention (mode 0) has a backward");
+  RF_REQUIRE(d->ldo % 8 == 0 && d->lddo % 8 == 0 && aligned16(d->o) && aligned16(d->dout) && aligned16(d->q) && aligned16(d->k) &&
+                 aligned16(d->v) && aligned16(d->qt) && aligned16(d->kt) && aligned16(d->dot) && aligned16(d->dq) && aligned16(d->dk) &&
+                 aligned16(d->dv),
+             RF_ERR_ALIGN, "rf_attention_bwd: operands must be 16-byte aligned with row pitches %% 8 == 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int S = d->S, sp = d->s_pad, H = d->heads;
+  // algorithmic work = the 5 products of a flash backward (S, dP, dV, dK, dq~) x 2 S^2 128 per head = 2.5 x the forward's;
+  // this two-kernel, atomics-free form EXECUTES 8 (S three times: statistics, dq~ pass, dK / dV pass; dP twice)
+  ProfScope ps(RF_KC_ATTN_BWD, 5.0 * 2.0 * (double)S * (double)S * 128.0 * (double)H, st);
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(sp / 32, H), dim3(256), 0, st, (const bf16_t*)d->o, d->ldo, (const bf16_t*)d->dout,
+                     d->lddo, (bf16_t*)d->dot, d->dsum, S, sp);
+  RF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(sp / 64, H), dim3(256), 0, st, (const bf16_t*)d->q, (const bf16_t*)d->k,
+                     (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo, (const float*)d->dsum, d->lse,
+                     (bf16_t*)d->dq, S, sp);
+  RF_LAUNCH_CHECK();
+  constexpr int KT = 2;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<KT>, dim3((sp + 64 * KT - 1) / (64 * KT), H), dim3(256), 0, st, (const bf16_t*)d->q,
+                     (const bf16_t*)d->qt, (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->dout, d->lddo,
+                     (const bf16_t*)d->dot, (const float*)d->lse, (const float*)d->dsum, (bf16_t*)d->dk, (bf16_t*)d->dv, S, sp);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}

@@ -1,0 +1,539 @@
+// Row kernels of the TRAINING path (train_flux/train/model.py:164-238 back-propagates through block.py's
+// block_forward / single_block_forward).  HBM-bound: 16-byte accesses, fp32 math, one bf16 rounding on the way out; every
+// column reduction (the modulation / gate gradients) is a fixed-order two-stage sum -> bit-reproducible, no atomics.
+//
+//   rf_qkv_train_fwd          raw q|k|v rows of the joint sequence -> the attention operands of forward AND backward:
+//                             per-head RMSNorm + RoPE (block.py:38-41,60-67,74-78,92-99), q~ = q * softmax_scale * log2 e,
+//                             head-major rows q~, k, v; the forward kernel's V^T tiles; the backward kernels' q~^T / k^T tiles
+//   rf_qkv_train_bwd          (dq~, dk, dv) head-major -> d raw q|k|v token-major (RoPE^T, RMSNorm backward)
+//   rf_layernorm_modulate_bwd y = LN(x) (1 + scale) + shift:  dx (+ residual gradient), d scale, d shift
+//   rf_gate_bwd               y = res + gate o f:  df = gate o dy,  d gate = sum_rows dy o f
+//   rf_gelu / rf_gelu_bwd     h = gelu_tanh(z);  dz = dh gelu_tanh'(z)
+//   rf_transpose_bf16         [R][C] -> [C][R_pad] (zero padded): the token-contraction operands of the LoRA gradient GEMMs
+#include "common.hpp"
+
+namespace rf {
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sum8(float v) {   // over the 8 consecutive lanes that share a (token, head) row
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+__device__ __forceinline__ void load16(const bf16_t* p, float (&f)[16]) {
+  unpack8(*(const u32x4*)p, *reinterpret_cast<float(*)[8]>(&f[0]));
+  unpack8(*(const u32x4*)(p + 8), *reinterpret_cast<float(*)[8]>(&f[8]));
+}
+__device__ __forceinline__ void store16(bf16_t* p, const float (&f)[16]) {
+  *(u32x4*)p = pack8(*reinterpret_cast<const float(*)[8]>(&f[0]));
+  *(u32x4*)(p + 8) = pack8(*reinterpret_cast<const float(*)[8]>(&f[8]));
+}
+__device__ __forceinline__ void load16f(const float* p, float (&f)[16]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = *(const f32x4*)(p + 4 * j);
+    f[4 * j] = v[0], f[4 * j + 1] = v[1], f[4 * j + 2] = v[2], f[4 * j + 3] = v[3];
+  }
+}
+
+// ---- q|k|v -> attention operands -----------------------------------------------------------------------------------------------
+// grid (s_pad / 32, heads), 256 threads: thread (token i = tid / 8, 16 channels c = tid % 8) of head blockIdx.y.
+__global__ __launch_bounds__(256) void qkv_train_fwd_kernel(const bf16_t* __restrict__ raw, int64_t ld, int heads, int S, int s_pad,
+                                                            int n_added, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+                                                            const bf16_t* __restrict__ waq, const bf16_t* __restrict__ wak,
+                                                            const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                            float eps, float q_scale, bf16_t* __restrict__ q, bf16_t* __restrict__ k,
+                                                            bf16_t* __restrict__ v, bf16_t* __restrict__ vt, bf16_t* __restrict__ qt,
+                                                            bf16_t* __restrict__ kt) {
+  __shared__ bf16_t tl[3][32][130];
+  const int tid = threadIdx.x, head = blockIdx.y, t0 = blockIdx.x * 32;
+  const int i = tid >> 3, c = tid & 7, tok = t0 + i, D = heads * 128;
+  float o[3][16];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[a][e] = 0.f;
+  if (tok < S) {
+    const bf16_t* row = raw + (int64_t)tok * ld + head * 128 + c * 16;
+    float cs[16], sn[16];
+    load16f(cos_tab + (int64_t)tok * 128 + c * 16, cs);
+    load16f(sin_tab + (int64_t)tok * 128 + c * 16, sn);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float x[16], w[16];
+      load16(row + a * D, x);
+      load16((tok < n_added ? (a ? wak : waq) : (a ? wk : wq)) + c * 16, w);
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ss += x[e] * x[e];
+      const float rs = rsqrtf(sum8(ss) * (1.0f / 128.0f) + eps);
+      const float sc = a == 0 ? q_scale : 1.0f;
+#pragma unroll
+      for (int e = 0; e < 16; e += 2) {
+        const float ya = x[e] * rs * w[e], yb = x[e + 1] * rs * w[e + 1];
+        o[a][e] = (ya * cs[e] - yb * sn[e]) * sc;
+        o[a][e + 1] = (yb * cs[e + 1] + ya * sn[e + 1]) * sc;
+      }
+    }
+    load16(row + 2 * D, o[2]);
+  }
+  const int64_t hrow = ((int64_t)head * s_pad + tok) * 128 + c * 16;
+  store16(q + hrow, o[0]);
+  store16(k + hrow, o[1]);
+  store16(v + hrow, o[2]);
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tl[a][i][c * 16 + e] = f2bf(o[a][e]);
+  __syncthreads();
+  const int blk = blockIdx.x;
+  const int64_t tbase = ((int64_t)head * (s_pad >> 5) + blk) * (128 * 32);
+  bf16_t* const vtile = vt + ((int64_t)head * (s_pad >> 6) + (blk >> 1)) * (128 * 64) + (blk & 1) * 32;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int d = (tid >> 2) + 64 * p, g = tid & 3;
+    float a8[8], b8[8], v8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = e < 4 ? 4 * g + e : 16 + 4 * g + e - 4;              // token of slot 8 g + e (attention_bwd.hip slot32)
+      a8[e] = bf2f(tl[0][n][d]);
+      b8[e] = bf2f(tl[1][n][d]);
+      // forward kernels' V^T: position = token with bits 2 and 3 swapped; positions 8 g .. 8 g + 7 of this half tile
+      const int nv = 16 * (g >> 1) + 8 * (e >> 2) + 4 * (g & 1) + (e & 3);
+      v8[e] = bf2f(tl[2][nv][d]);
+    }
+    *(u32x4*)(qt + tbase + d * 32 + g * 8) = pack8(a8);
+    *(u32x4*)(kt + tbase + d * 32 + g * 8) = pack8(b8);
+    *(u32x4*)(vtile + d * 64 + g * 8) = pack8(v8);
+  }
+}
+
+// ---- backward of the same map ----------------------------------------------------------------------------------------------------
+// grid (ceil(S / 32), heads), 256 threads.
+__global__ __launch_bounds__(256) void qkv_train_bwd_kernel(const bf16_t* __restrict__ raw, int64_t ld, int heads, int S, int s_pad,
+                                                            int n_added, const bf16_t* __restrict__ wq, const bf16_t* __restrict__ wk,
+                                                            const bf16_t* __restrict__ waq, const bf16_t* __restrict__ wak,
+                                                            const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                                                            float eps, float q_scale, const bf16_t* __restrict__ dq,
+                                                            const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
+                                                            bf16_t* __restrict__ draw, int64_t ldd) {
+  const int tid = threadIdx.x, head = blockIdx.y;
+  const int i = tid >> 3, c = tid & 7, tok = blockIdx.x * 32 + i, D = heads * 128;
+  if (tok >= S) return;          // (whole 8-lane groups leave together: the shuffles below stay within a group)
+  const bf16_t* row = raw + (int64_t)tok * ld + head * 128 + c * 16;
+  bf16_t* drow = draw + (int64_t)tok * ldd + head * 128 + c * 16;
+  const int64_t hrow = ((int64_t)head * s_pad + tok) * 128 + c * 16;
+  float cs[16], sn[16];
+  load16f(cos_tab + (int64_t)tok * 128 + c * 16, cs);
+  load16f(sin_tab + (int64_t)tok * 128 + c * 16, sn);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    float x[16], w[16], go[16], dx[16];
+    load16(row + a * D, x);
+    load16((tok < n_added ? (a ? wak : waq) : (a ? wk : wq)) + c * 16, w);
+    load16((a ? dk : dq) + hrow, go);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ss += x[e] * x[e];
+    const float rs = rsqrtf(sum8(ss) * (1.0f / 128.0f) + eps);
+    const float sc = a == 0 ? q_scale : 1.0f;
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      const float ga = go[e] * sc, gb = go[e + 1] * sc;
+      // o[e] = ya cs[e] - yb sn[e],  o[e+1] = yb cs[e+1] + ya sn[e+1]
+      const float dya = ga * cs[e] + gb * sn[e + 1], dyb = gb * cs[e + 1] - ga * sn[e];
+      dx[e] = dya * w[e];            // d n
+      dx[e + 1] = dyb * w[e + 1];
+      dot += dx[e] * x[e] * rs + dx[e + 1] * x[e + 1] * rs;
+    }
+    const float mean = sum8(dot) * (1.0f / 128.0f);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dx[e] = rs * (dx[e] - x[e] * rs * mean);
+    store16(drow + a * D, dx);
+  }
+  *(u32x4*)(drow + 2 * D) = *(const u32x4*)(dv + hrow);
+  *(u32x4*)(drow + 2 * D + 8) = *(const u32x4*)(dv + hrow + 8);
+}
+
+// ---- LayerNorm + modulate, backward --------------------------------------------------------------------------------------------
+// One wave per row, grid-stride over the rows; a lane keeps the column sums of ITS columns over ITS rows and writes them to
+// partials[wave][2][D] (d shift | d scale); colsum_reduce_kernel adds the waves in index order.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                                         int64_t lddy, const bf16_t* __restrict__ dres, int64_t lddres,
+                                                         bf16_t* __restrict__ dx, int64_t lddx, int rows, int D,
+                                                         const bf16_t* __restrict__ scale, float eps, float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float a_shift[NCH][8], a_scale[NCH][8], sc1[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0.f;
+    if (col < D) unpack8(*(const u32x4*)(scale + col), t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a_shift[c][j] = 0.f, a_scale[c][j] = 0.f, sc1[c][j] = 1.0f + t[j];
+  }
+  for (int row = wave; row < rows; row += nwaves) {
+    const bf16_t* xr = x + (int64_t)row * ldx;
+    const bf16_t* gr = dy + (int64_t)row * lddy;
+    float v[NCH][8], gy[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+        unpack8(*(const u32x4*)(xr + col), v[c]);
+        unpack8(*(const u32x4*)(gr + col), gy[c]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c][j] = 0.f, gy[c][j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    }
+    const float mean = wave_sum_t(s) / (float)D;
+    float qv = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dlt = v[c][j] - mean;
+          qv += dlt * dlt;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum_t(qv) / (float)D + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (v[c][j] - mean) * rstd;
+          a_shift[c][j] += gy[c][j];
+          a_scale[c][j] += gy[c][j] * xh;
+          const float dxh = gy[c][j] * sc1[c][j];
+          v[c][j] = xh;
+          gy[c][j] = dxh;
+          m1 += dxh;
+          m2 += dxh * xh;
+        }
+      }
+    }
+    m1 = wave_sum_t(m1) / (float)D;
+    m2 = wave_sum_t(m2) / (float)D;
+    bf16_t* orow = dx + (int64_t)row * lddx;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+        float r8[8], o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r8[j] = 0.f;
+        if (dres != nullptr) unpack8(*(const u32x4*)(dres + (int64_t)row * lddres + col), r8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = r8[j] + rstd * (gy[c][j] - m1 - v[c][j] * m2);
+        *(u32x4*)(orow + col) = pack8(o8);
+      }
+    }
+  }
+  float* pw = partials + (int64_t)wave * 2 * D;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pw[col + j] = a_shift[c][j], pw[D + col + j] = a_scale[c][j];
+    }
+  }
+}
+
+// out[c] = sum_w partials[w][c], w in index order; `cols` columns (2 D for the LayerNorm kernel, D for the gate kernel)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partials, int nw, int cols, float* __restrict__ out0,
+                                                            float* __restrict__ out1, int split) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int w = 0; w < nw; ++w) s += partials[(int64_t)w * cols + c];
+  if (c < split) out0[c] = s;
+  else out1[c - split] = s;
+}
+
+// ---- gated residual, backward ------------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict__ dy, int64_t lddy, const bf16_t* __restrict__ f, int64_t ldf,
+                                                       const bf16_t* __restrict__ gate, bf16_t* __restrict__ df, int64_t lddf, int rows, int D,
+                                                       float* __restrict__ partials) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  float acc[NCH][8], gt[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[c][j] = 0.f, gt[c][j] = 0.f;
+    if (col < D) unpack8(*(const u32x4*)(gate + col), gt[c]);
+  }
+  for (int row = wave; row < rows; row += nwaves) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < D) {
+        float g8[8], f8[8], o8[8];
+        unpack8(*(const u32x4*)(dy + (int64_t)row * lddy + col), g8);
+        unpack8(*(const u32x4*)(f + (int64_t)row * ldf + col), f8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[c][j] += g8[j] * f8[j];
+          o8[j] = g8[j] * gt[c][j];
+        }
+        *(u32x4*)(df + (int64_t)row * lddf + col) = pack8(o8);
+      }
+    }
+  }
+  float* pw = partials + (int64_t)wave * D;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pw[col + j] = acc[c][j];
+    }
+  }
+}
+
+// y = res + gate o f (the training path keeps f = the projection's bf16 output for the gate gradient, so the gated residual is its
+// own pass here instead of the RF_EPI_GATE_RES epilogue)
+__global__ __launch_bounds__(256) void gate_res_kernel(const bf16_t* __restrict__ f, int64_t ldf, const bf16_t* __restrict__ gate,
+                                                       const bf16_t* __restrict__ res, int64_t ldr, bf16_t* __restrict__ out, int64_t ldo,
+                                                       int rows, int cols8) {
+  const int64_t total = (int64_t)rows * cols8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / cols8;
+    const int c = (int)(idx - r * cols8) * 8;
+    float fv[8], gv[8], rv[8], o[8];
+    unpack8(*(const u32x4*)(f + r * ldf + c), fv);
+    unpack8(*(const u32x4*)(gate + c), gv);
+    unpack8(*(const u32x4*)(res + r * ldr + c), rv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rv[j] + gv[j] * fv[j];
+    *(u32x4*)(out + r * ldo + c) = pack8(o);
+  }
+}
+
+// ---- GELU (tanh) and its derivative ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_tanh_grad(float z) {
+  // gelu(z) = z s(z), s = sigmoid(2u), u = sqrt(2/pi) (z + 0.044715 z^3):  d/dz = s + z s (1 - s) 2 u'(z)
+  const float z2 = z * z;
+  const float e = __builtin_amdgcn_exp2f(z * (-2.3022082f - 0.1029432f * z2));      // exp(-2u)
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  const float du2 = 1.5957691216f * (1.0f + 0.134145f * z2);                        // 2 u'
+  return s + z * s * (1.0f - s) * du2;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ z, int64_t ldz, const bf16_t* __restrict__ dh, int64_t lddh,
+                                                   bf16_t* __restrict__ out, int64_t ldo, int rows, int cols8) {
+  const int64_t total = (int64_t)rows * cols8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx / cols8;
+    const int c = (int)(idx - r * cols8) * 8;
+    float zv[8], o[8];
+    unpack8(*(const u32x4*)(z + r * ldz + c), zv);
+    if (BWD) {
+      float g[8];
+      unpack8(*(const u32x4*)(dh + r * lddh + c), g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = g[j] * gelu_tanh_grad(zv[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = gelu_tanh(zv[j]);
+    }
+    *(u32x4*)(out + r * ldo + c) = pack8(o);
+  }
+}
+
+// ---- transpose with zero padding ---------------------------------------------------------------------------------------------------
+// dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < rows_pad.  grid (ceil(rows_pad / 64), ceil(cols / 64)), 256 threads.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, int64_t lds_, int rows, int cols,
+                                                        bf16_t* __restrict__ dst, int64_t ldd, int rows_pad) {
+  __shared__ bf16_t t[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    t[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(int64_t)(r0 + r) * lds_ + c0 + c] : f2bf(0.f);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 64 * 64; idx += 256) {
+    const int c = idx >> 6, r = idx & 63;
+    if (c0 + c < cols && r0 + r < rows_pad) dst[(int64_t)(c0 + c) * ldd + r0 + r] = t[r][c];
+  }
+}
+
+static int row_blocks(int rows) {
+  const int b = cdiv(rows, 4);
+  return b < 128 ? b : 128;      // <= 512 waves: 512 x 2 x D fp32 partials
+}
+
+}  // namespace rf
+
+using namespace rf;
+
+extern "C" int rf_qkv_train_fwd(const void* raw, int64_t ld_raw, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,
+                                const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k, const float* cos_tab,
+                                const float* sin_tab, float eps, float q_scale, void* q, void* k, void* v, void* vt, void* qt, void* kt,
+                                void* stream) {
+  RF_REQUIRE(raw && w_q && w_k && cos_tab && sin_tab && q && k && v && vt && qt && kt, RF_ERR_NULL, "rf_qkv_train_fwd: NULL operand");
+  RF_REQUIRE(n_added == 0 || (w_added_q && w_added_k), RF_ERR_NULL, "rf_qkv_train_fwd: text rows need norm_added_q / norm_added_k");
+  RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0 && ld_raw % 8 == 0 && ld_raw >= 3 * heads * 128, RF_ERR_SHAPE,
+             "rf_qkv_train_fwd: heads=%d S=%d s_pad=%d ld=%lld", heads, S, s_pad, (long long)ld_raw);
+  RF_REQUIRE(aligned16(raw) && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(vt) && aligned16(qt) && aligned16(kt),
+             RF_ERR_ALIGN, "rf_qkv_train_fwd: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)S * heads * 128.0 * 2.0 * (3.0 + 6.0), st);
+  hipLaunchKernelGGL(qkv_train_fwd_kernel, dim3(s_pad / 32, heads), dim3(256), 0, st, (const bf16_t*)raw, ld_raw, heads, S, s_pad, n_added,
+                     (const bf16_t*)w_q, (const bf16_t*)w_k, (const bf16_t*)w_added_q, (const bf16_t*)w_added_k, cos_tab, sin_tab, eps,
+                     q_scale == 0.f ? 1.0f : q_scale, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, (bf16_t*)vt, (bf16_t*)qt, (bf16_t*)kt);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int rf_qkv_train_bwd(const void* raw, int64_t ld_raw, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,
+                                const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k, const float* cos_tab,
+                                const float* sin_tab, float eps, float q_scale, const void* dq, const void* dk, const void* dv,
+                                void* d_raw, int64_t ld_draw, void* stream) {
+  RF_REQUIRE(raw && w_q && w_k && cos_tab && sin_tab && dq && dk && dv && d_raw, RF_ERR_NULL, "rf_qkv_train_bwd: NULL operand");
+  RF_REQUIRE(n_added == 0 || (w_added_q && w_added_k), RF_ERR_NULL, "rf_qkv_train_bwd: text rows need norm_added_q / norm_added_k");
+  RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0 && ld_raw % 8 == 0 && ld_draw % 8 == 0, RF_ERR_SHAPE,
+             "rf_qkv_train_bwd: heads=%d S=%d s_pad=%d", heads, S, s_pad);
+  RF_REQUIRE(aligned16(raw) && aligned16(dq) && aligned16(dk) && aligned16(dv) && aligned16(d_raw), RF_ERR_ALIGN,
+             "rf_qkv_train_bwd: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)S * heads * 128.0 * 2.0 * (2.0 + 3.0 + 3.0), st);
+  hipLaunchKernelGGL(qkv_train_bwd_kernel, dim3(cdiv(S, 32), heads), dim3(256), 0, st, (const bf16_t*)raw, ld_raw, heads, S, s_pad, n_added,
+                     (const bf16_t*)w_q, (const bf16_t*)w_k, (const bf16_t*)w_added_q, (const bf16_t*)w_added_k, cos_tab, sin_tab, eps,
+                     q_scale == 0.f ? 1.0f : q_scale, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, (bf16_t*)d_raw, ld_draw);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int64_t rf_train_partials_bytes(int32_t D) { return (int64_t)512 * 2 * D * 4; }
+
+extern "C" int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* dres, int64_t lddres,
+                                         void* dx, int64_t lddx, int32_t rows, int32_t D, const void* scale, float eps, float* d_scale,
+                                         float* d_shift, float* partials, int64_t partials_bytes, void* stream) {
+  RF_REQUIRE(x && dy && dx && scale && d_scale && d_shift && partials, RF_ERR_NULL, "rf_layernorm_modulate_bwd: NULL operand");
+  RF_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 6 * 512 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && lddres % 8 == 0,
+             RF_ERR_SHAPE, "rf_layernorm_modulate_bwd: rows=%d D=%d (D %% 8 == 0, D <= 3072)", rows, D);
+  RF_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(scale) && (dres == nullptr || aligned16(dres)), RF_ERR_ALIGN,
+             "rf_layernorm_modulate_bwd: 16-byte alignment");
+  const int blocks = row_blocks(rows), nw = blocks * 4;
+  RF_REQUIRE(partials_bytes >= (int64_t)nw * 2 * D * 4, RF_ERR_WORKSPACE, "rf_layernorm_modulate_bwd: partials need %lld bytes",
+             (long long)nw * 2 * D * 4);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)rows * D * 2.0 * (dres ? 4.0 : 3.0), st);
+  const int nch = cdiv(D, 512);
+#define RF_LNB(N)                                                                                                                    \
+  hipLaunchKernelGGL(ln_mod_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,           \
+                     (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, rows, D, (const bf16_t*)scale, eps, partials)
+  if (nch <= 1) RF_LNB(1);
+  else if (nch <= 2) RF_LNB(2);
+  else if (nch <= 4) RF_LNB(4);
+  else RF_LNB(6);
+#undef RF_LNB
+  RF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, st, (const float*)partials, nw, 2 * D, d_shift, d_scale, D);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int rf_gate_bwd(const void* dy, int64_t lddy, const void* f, int64_t ldf, const void* gate, void* df, int64_t lddf, int32_t rows,
+                           int32_t D, float* d_gate, float* partials, int64_t partials_bytes, void* stream) {
+  RF_REQUIRE(dy && f && gate && df && d_gate && partials, RF_ERR_NULL, "rf_gate_bwd: NULL operand");
+  RF_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 6 * 512 && lddy % 8 == 0 && ldf % 8 == 0 && lddf % 8 == 0, RF_ERR_SHAPE,
+             "rf_gate_bwd: rows=%d D=%d", rows, D);
+  RF_REQUIRE(aligned16(dy) && aligned16(f) && aligned16(gate) && aligned16(df), RF_ERR_ALIGN, "rf_gate_bwd: 16-byte alignment");
+  const int blocks = row_blocks(rows), nw = blocks * 4;
+  RF_REQUIRE(partials_bytes >= (int64_t)nw * D * 4, RF_ERR_WORKSPACE, "rf_gate_bwd: partials need %lld bytes", (long long)nw * D * 4);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)rows * D * 2.0 * 3.0, st);
+  const int nch = cdiv(D, 512);
+#define RF_GB(N)                                                                                                                    \
+  hipLaunchKernelGGL(gate_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, lddy, (const bf16_t*)f, ldf,            \
+                     (const bf16_t*)gate, (bf16_t*)df, lddf, rows, D, partials)
+  if (nch <= 1) RF_GB(1);
+  else if (nch <= 2) RF_GB(2);
+  else if (nch <= 4) RF_GB(4);
+  else RF_GB(6);
+#undef RF_GB
+  RF_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, (const float*)partials, nw, D, d_gate, d_gate, D);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+static int gelu_launch(bool bwd, const void* z, int64_t ldz, const void* dh, int64_t lddh, void* out, int64_t ldo, int32_t rows, int32_t cols,
+                       void* stream) {
+  RF_REQUIRE(z && out && (!bwd || dh), RF_ERR_NULL, "rf_gelu: NULL operand");
+  RF_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ldz % 8 == 0 && ldo % 8 == 0 && lddh % 8 == 0, RF_ERR_SHAPE, "rf_gelu: rows=%d cols=%d",
+             rows, cols);
+  RF_REQUIRE(aligned16(z) && aligned16(out) && (!bwd || aligned16(dh)), RF_ERR_ALIGN, "rf_gelu: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)rows * cols * 2.0 * (bwd ? 3.0 : 2.0), st);
+  const int64_t total = (int64_t)rows * (cols / 8);
+  const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  if (bwd)
+    hipLaunchKernelGGL(gelu_kernel<true>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, ldz, (const bf16_t*)dh, lddh, (bf16_t*)out, ldo,
+                       rows, cols / 8);
+  else
+    hipLaunchKernelGGL(gelu_kernel<false>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, ldz, (const bf16_t*)nullptr, 0, (bf16_t*)out, ldo,
+                       rows, cols / 8);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+extern "C" int rf_gelu(const void* z, int64_t ldz, void* h, int64_t ldh, int32_t rows, int32_t cols, void* stream) {
+  return gelu_launch(false, z, ldz, nullptr, 0, h, ldh, rows, cols, stream);
+}
+extern "C" int rf_gelu_bwd(const void* z, int64_t ldz, const void* dh, int64_t lddh, void* dz, int64_t lddz, int32_t rows, int32_t cols,
+                           void* stream) {
+  return gelu_launch(true, z, ldz, dh, lddh, dz, lddz, rows, cols, stream);
+}
+
+extern "C" int rf_gate_residual(const void* f, int64_t ldf, const void* gate, const void* res, int64_t ldr, void* out, int64_t ldo, int32_t rows,
+                                int32_t D, void* stream) {
+  RF_REQUIRE(f && gate && res && out, RF_ERR_NULL, "rf_gate_residual: NULL operand");
+  RF_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && ldf % 8 == 0 && ldr % 8 == 0 && ldo % 8 == 0, RF_ERR_SHAPE, "rf_gate_residual: rows=%d D=%d", rows, D);
+  RF_REQUIRE(aligned16(f) && aligned16(gate) && aligned16(res) && aligned16(out), RF_ERR_ALIGN, "rf_gate_residual: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)rows * D * 2.0 * 3.0, st);
+  const int64_t total = (int64_t)rows * (D / 8);
+  const int blocks = (int)(cdiv64(total, 256) < 4096 ? cdiv64(total, 256) : 4096);
+  hipLaunchKernelGGL(gate_res_kernel, dim3(blocks), dim3(256), 0, st, (const bf16_t*)f, ldf, (const bf16_t*)gate, (const bf16_t*)res, ldr,
+                     (bf16_t*)out, ldo, rows, D / 8);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, int32_t cols, void* dst, int64_t ld_dst, int32_t rows_pad,
+                                 void* stream) {
+  RF_REQUIRE(src && dst, RF_ERR_NULL, "rf_transpose_bf16: NULL operand");
+  RF_REQUIRE(rows > 0 && cols > 0 && rows_pad >= rows && ld_dst >= rows_pad && ld_src >= cols, RF_ERR_SHAPE,
+             "rf_transpose_bf16: rows=%d cols=%d rows_pad=%d", rows, cols, rows_pad);
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_ROWOP, (double)rows * cols * 4.0, st);
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(rows_pad, 64), cdiv(cols, 64)), dim3(256), 0, st, (const bf16_t*)src, ld_src, rows, cols,
+                     (bf16_t*)dst, ld_dst, rows_pad);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}

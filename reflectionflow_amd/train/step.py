@@ -1,0 +1,192 @@
+"""The flow-matching training step of the reflection LoRA (train_flux/train/model.py:164-238, `OminiModel.step`), with the
+57-block stack on the HIP kernels and their backward (train/blocks.py).
+
+What is PyTorch here, as in the inference path (north star: "timestep embed ... left in PyTorch-ROCm"): the timestep / guidance /
+pooled-text embedding, the LoRA terms of the AdaLN linears and of x_embedder (a [1, D] x [D, r] product each), the final
+AdaLayerNormContinuous + proj_out (64 output channels) and the MSE.  torch.autograd links those pieces and the block Functions;
+every block re-computes itself in its backward (train_flux/flux/transformer.py:139-157, `gradient_checkpointing: true`).
+
+Data parallelism ("DDP all-reduce of ~116 M LoRA grads"): `allreduce_lora_grads` -- ONE flat bf16 bucket over all
+LoRA gradients (232 MB at r = 32: a single ring all-reduce is per-link bound on xGMI, so fewer, larger collectives), averaged.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .. import engine as E
+from .. import ops
+from ..flux.modules import LoraLinear
+from .blocks import DoubleBlockFn, SingleBlockFn, double_weights, fused_lora, single_weights
+
+BF = torch.bfloat16
+
+
+def lora_parameters(transformer) -> List[torch.nn.Parameter]:
+    """The trainable set of train/model.py:62-66,94-103: every LoRA factor, nothing else."""
+    return [p for n, p in transformer.named_parameters() if "lora_" in n]
+
+
+def _lora_term(lin, s: torch.Tensor) -> Optional[torch.Tensor]:
+    """scaling * lora_B(lora_A(s)) of a LoraLinear as torch ops (autograd), or None."""
+    if not isinstance(lin, LoraLinear):
+        return None
+    out = None
+    for a in lin.active_adapters:
+        t = F.linear(F.linear(s, lin.lora_A[a].weight), lin.lora_B[a].weight) * lin.scaling[a]
+        out = t if out is None else out + t
+    return out
+
+
+class FluxTrainer:
+    """Forward with a backward through the HIP blocks for ONE transformer; `model_config` as in config.yaml:5-8."""
+
+    def __init__(self, transformer, model_config: Optional[dict] = None):
+        self.tr = transformer
+        self.cfg = dict(model_config or {})
+        if self.cfg.get("add_cond_attn", False) or not self.cfg.get("union_cond_attn", True):
+            raise ops.RFError("the training path covers the shipped training config (union_cond_attn: true, add_cond_attn: false)")
+        E.check_lora_placement(transformer)
+        bad = [n for n, m in transformer.named_modules() if isinstance(m, LoraLinear) and
+               (n.endswith("norm1_context.linear") or n.endswith("norm_out.linear"))]
+        if bad:
+            raise ops.RFError(f"LoRA on {bad[:2]} is outside the FLUX-Corrector target list (config.yaml:53): not trainable here")
+        for p in transformer.parameters():
+            p.requires_grad_(False)                         # train/model.py:96
+        for p in lora_parameters(transformer):
+            p.requires_grad_(True)                          # :102-103
+        self.eng = E.engine_for(transformer)
+        self.latent_lora = bool(self.cfg.get("latent_lora", False))
+
+    # -------------------------------------------------------------------------------------------------- pieces
+    def _mods(self, temb: torch.Tensor, lora_on: bool):
+        """Per-block modulation rows for one conditioning row temb [1, D]: the base AdaLN linears through the HIP GEMM (no grad),
+        plus -- when LoRA is on for this token stream -- the LoRA terms of norm1.linear / norm.linear as autograd ops."""
+        tr, D = self.tr, self.eng.D
+        with torch.no_grad():
+            table = self.eng.mod_table(temb, lora=False)[0]
+            s = ops.silu(temb.to(BF).contiguous())
+        nd = len(tr.transformer_blocks)
+        dbl_img, dbl_txt, sgl = [], [], []
+        for i, b in enumerate(tr.transformer_blocks):
+            m = table[i * 12 * D:i * 12 * D + 6 * D]
+            lt = _lora_term(b.norm1.linear, s) if lora_on else None
+            dbl_img.append(m if lt is None else m + lt[0])
+            dbl_txt.append(table[i * 12 * D + 6 * D:(i + 1) * 12 * D])
+        for j, b in enumerate(tr.single_transformer_blocks):
+            m = table[nd * 12 * D + j * 3 * D:nd * 12 * D + (j + 1) * 3 * D]
+            lt = _lora_term(b.norm.linear, s) if lora_on else None
+            sgl.append(m if lt is None else m + lt[0])
+        out = table[-2 * D:]
+        return dbl_img, dbl_txt, sgl, out
+
+    def _embed(self, lin, x: torch.Tensor, lora_on: bool) -> torch.Tensor:
+        base = E._base(lin)
+        with torch.no_grad():
+            y = ops.linear(x.contiguous(), base.weight, base.bias)
+        lt = _lora_term(lin, x) if lora_on else None
+        return y if lt is None else y + lt
+
+    # -------------------------------------------------------------------------------------------------- forward
+    def forward(self, hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, txt_ids, img_ids,
+                condition_latents=None, condition_ids=None, c_t: float = 0.0) -> torch.Tensor:
+        """tranformer_forward (train_flux/flux/transformer.py:47-252) with autograd: hidden_states [B, S_img, in_ch] (= x_t),
+        timestep in [0, 1] as the training step passes it (model.py:221).  Returns the prediction [B, S_img, in_ch]."""
+        tr, eng, D = self.tr, self.eng, self.eng.D
+        dtype = tr.dtype
+        use_cond = condition_latents is not None
+        with torch.no_grad():
+            ts = timestep.to(dtype) * 1000                                                   # transformer.py:95-114
+            gd = guidance.to(dtype) * 1000 if guidance is not None else None
+            temb = eng.temb(ts, gd, pooled_projections.to(dtype))
+            if use_cond:
+                ct = torch.ones_like(ts) * c_t * 1000
+                cg = torch.ones_like(gd) * 1000 if gd is not None else None
+                cond_temb = eng.temb(ct, cg, pooled_projections.to(dtype))
+            if txt_ids.ndim == 3:
+                txt_ids = txt_ids[0]
+            if img_ids.ndim == 3:
+                img_ids = img_ids[0]
+            cos, sin = eng.rope_tables(txt_ids, img_ids, condition_ids if use_cond else None)
+        outs = []
+        for b in range(hidden_states.shape[0]):
+            m_img, m_txt, m_sgl, m_out = self._mods(temb[b:b + 1], self.latent_lora)
+            if use_cond:
+                c_img, _, c_sgl, _ = self._mods(cond_temb[b:b + 1], True)
+            x_img = self._embed(tr.x_embedder, hidden_states[b].to(dtype), self.latent_lora)
+            x_cond = self._embed(tr.x_embedder, condition_latents[b].to(dtype), True) if use_cond else None
+            with torch.no_grad():
+                x_txt = ops.linear(encoder_hidden_states[b].to(dtype).contiguous(), tr.context_embedder.weight, tr.context_embedder.bias)
+            St = x_txt.shape[0]
+            for i, blk in enumerate(tr.transformer_blocks):
+                a = blk.attn
+                lo = (*fused_lora([a.to_q, a.to_k, a.to_v]), *fused_lora([a.to_out[0]]), *fused_lora([blk.ff.net[2]]))
+                x_txt, x_img, x_cond = DoubleBlockFn.apply(double_weights(blk), self.latent_lora, x_txt, x_img, x_cond, m_txt[i], m_img[i],
+                                                           c_img[i] if use_cond else None, cos, sin, *lo)
+            x_main = torch.cat([x_txt, x_img], 0)
+            for j, blk in enumerate(tr.single_transformer_blocks):
+                a = blk.attn
+                lo = (*fused_lora([a.to_q, a.to_k, a.to_v, blk.proj_mlp]), *fused_lora([blk.proj_out]))
+                x_main, x_cond = SingleBlockFn.apply(single_weights(blk), self.latent_lora, x_main, x_cond, m_sgl[j],
+                                                     c_sgl[j] if use_cond else None, cos, sin, *lo)
+            x_img = x_main[St:]
+            # norm_out (AdaLayerNormContinuous: scale FIRST) + proj_out, transformer.py:243-244 -- torch ops, autograd
+            scale, shift = m_out[:D], m_out[D:]
+            xn = (F.layer_norm(x_img.float(), (D,), eps=1e-6) * (1.0 + scale.float()) + shift.float()).to(dtype)
+            outs.append(F.linear(xn, tr.proj_out.weight, tr.proj_out.bias))
+        return torch.stack(outs, 0)
+
+    # -------------------------------------------------------------------------------------------------- the step
+    def step(self, batch: Dict[str, torch.Tensor], generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """train/model.py:164-238.  `batch`: x_0 [B, S_img, 64] + img_ids (the VAE-encoded target, encode_images), prompt_embeds,
+        pooled_prompt_embeds, text_ids, condition_latents [B, S_c, 64] + condition_ids (position delta applied).  Optional `t` /
+        `x_1` pin the draws (tests); otherwise t = sigmoid(randn), x_1 = randn as the reference.  Returns the loss (call .backward())."""
+        x_0 = batch["x_0"]
+        dev, dtype = x_0.device, self.tr.dtype
+        Bn = x_0.shape[0]
+        with torch.no_grad():
+            t = batch.get("t")
+            if t is None:
+                t = torch.sigmoid(torch.randn((Bn,), device=dev, generator=generator))
+            x_1 = batch.get("x_1")
+            if x_1 is None:
+                x_1 = torch.randn(x_0.shape, device=dev, dtype=x_0.dtype, generator=generator)
+            t_ = t[:, None, None]
+            x_t = ((1 - t_) * x_0 + t_ * x_1).to(dtype)                                      # :188
+            guidance = torch.ones_like(t) if self.tr.config.guidance_embeds else None        # :209-213
+            target = (x_1 - x_0)
+        pred = self.forward(x_t, batch["prompt_embeds"], batch["pooled_prompt_embeds"], t, guidance, batch["text_ids"], batch["img_ids"],
+                            batch.get("condition_latents"), batch.get("condition_ids"))
+        return F.mse_loss(pred, target.to(pred.dtype), reduction="mean")                     # :235
+
+
+# ------------------------------------------------------------------------------------------------------ data parallel
+def allreduce_lora_grads(params: Sequence[torch.nn.Parameter], world_size: int, group=None) -> int:
+    """Average the LoRA gradients over the data-parallel ranks with ONE all-reduce of a flat bucket (DDP's job in the reference's
+    Lightning trainer).  Parameters without a gradient contribute zeros, so every rank reduces the same layout.  Returns the
+    bucket size in bytes."""
+    import torch.distributed as dist
+    ps = [p for p in params if p.requires_grad]
+    if not ps:
+        return 0
+    dt, dev = ps[0].dtype, ps[0].device
+    flat = torch.zeros(sum(p.numel() for p in ps), dtype=dt, device=dev)
+    off = 0
+    for p in ps:
+        if p.grad is not None:
+            flat[off:off + p.numel()] = p.grad.reshape(-1)
+        off += p.numel()
+    if world_size > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world_size
+    off = 0
+    for p in ps:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+    return flat.numel() * flat.element_size()

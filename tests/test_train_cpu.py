@@ -1,0 +1,91 @@
+"""SURVEY 8f row 4 (training), CPU side: the oracle of the training step against the fixture RECORDED FROM THE REFERENCE's own
+`OminiModel.step` (tests/golden/make_train_golden.py), and the data-parallel LoRA-gradient all-reduce over gloo at world size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import train_oracle as TO
+from tests.golden_util import T, build, load, wsum
+
+
+def _fixture_step():
+    z = load("train_step_hd128")
+    m = TO.set_trainable(build("hd128", lora=True).train())
+    assert np.array_equal(np.frombuffer(bytes.fromhex(wsum(m)), dtype=np.uint8), z["weights_sha256"])
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    loss, pred = TO.training_step(m, T(z["x_0"]), T(z["img_ids"]), T(z["pe"]), T(z["pooled"]), T(z["txt_ids"]), T(z["cond"]),
+                                  T(z["cond_ids"]), T(z["t"]), T(z["x_1"]), cfg)
+    loss.backward()
+    return z, m, loss, pred
+
+
+def test_oracle_training_step_equals_the_reference_fixture():
+    """loss, prediction and EVERY LoRA gradient of the restated step == what the reference's own step produced (fp32, bit-exact)."""
+    z, m, loss, pred = _fixture_step()
+    assert torch.equal(loss.detach(), T(z["loss"]))
+    assert torch.equal(pred.detach(), T(z["pred"]))
+    grads = TO.lora_parameters(m)
+    assert len(grads) == 50 and sorted("grad/" + n for n in grads) == sorted(k for k in z if k.startswith("grad/"))
+    for n, p in grads.items():
+        assert torch.equal(p.grad, T(z["grad/" + n])), n
+    # the draws follow the reference's order: t first, then x_1 (model.py:185-186)
+    torch.manual_seed(1234)
+    t, x_1 = TO.draw_t_x1(T(z["x_0"]))
+    assert torch.equal(t, T(z["t"])) and torch.equal(x_1, T(z["x_1"]))
+
+
+def test_only_lora_factors_are_trainable():
+    m = TO.set_trainable(build("hd128", lora=True))
+    tr = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert tr and all("lora_" in n for n in tr)
+
+
+# ------------------------------------------------------------------------------------------------- world size 2
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reflectionflow_amd.train.step import allreduce_lora_grads
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.nn.Parameter(torch.randn(4, 16, generator=g).to(torch.bfloat16)), torch.nn.Parameter(torch.randn(16, 4, generator=g).to(torch.bfloat16)),
+          torch.nn.Parameter(torch.randn(3, generator=g).to(torch.bfloat16))]
+    gr = torch.Generator().manual_seed(100 + rank)
+    ps[0].grad = torch.randn(4, 16, generator=gr).to(torch.bfloat16)
+    ps[1].grad = torch.randn(16, 4, generator=gr).to(torch.bfloat16)
+    if rank == 0:
+        ps[2].grad = torch.ones(3, dtype=torch.bfloat16)            # rank 1 has none: it must still take part with zeros
+    nbytes = allreduce_lora_grads(ps, world)
+    q.put((rank, nbytes, [p.grad.float().clone() for p in ps]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_lora_gradient_allreduce_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (n, g) for r, n, g in (q.get(timeout=100) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] == (64 + 64 + 3) * 2              # ONE flat bf16 bucket
+    for a, b in zip(got[0][1], got[1][1]):
+        assert torch.equal(a, b), "ranks hold different averaged gradients"
+    want = []
+    for rank in range(2):
+        gr = torch.Generator().manual_seed(100 + rank)
+        want.append([torch.randn(4, 16, generator=gr).to(torch.bfloat16).float(), torch.randn(16, 4, generator=gr).to(torch.bfloat16).float()])
+    for i in range(2):
+        exp = ((want[0][i].to(torch.bfloat16) + want[1][i].to(torch.bfloat16)) / 2).float()
+        assert torch.allclose(got[0][1][i], exp, atol=2e-2)
+    assert torch.allclose(got[0][1][2], torch.full((3,), 0.5))

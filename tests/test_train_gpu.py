@@ -1,0 +1,271 @@
+"""SURVEY 8f row 4 on the GPU: the backward kernels against torch fp32 autograd of the same maps, then gradient parity of the
+whole training step (train_flux/train/model.py:164-238) against
+
+  * the fixture tests/golden/train_step_hd128.npz -- loss and all 50 LoRA gradients RECORDED FROM THE REFERENCE's own step, fp32;
+  * the fp32 oracle on the fly at FLUX width (one DoubleStream + one SingleStream block, D = 3072, r = 32).
+
+Tolerance (stated): the HIP path computes in bf16 with fp32 accumulation and hands bf16 gradients between kernels, exactly where
+torch's bf16 autograd rounds.  A gradient g is accepted when  rel-L2(g_hip, g_fp32) <= 2 x rel-L2(g_torch_bf16, g_fp32) + 1e-2,
+torch_bf16 = the oracle itself run in bf16 on the same GPU; single kernels against fp32 math: rel-L2 <= 1e-2 (bf16 outputs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import flux_oracle as O
+from oracle import train_oracle as TO
+from tests.golden_util import GEOMS, SHAPES, T, build, load
+from tests.test_model_gpu import bf16_oracle, rel_l2, to_product
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+LN2 = math.log(2.0)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from reflectionflow_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def rnd(dev, *shape, seed=0, sc=1.0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=dev) * sc).to(BF)
+
+
+# ------------------------------------------------------------------------------------------------- row kernels
+def test_transpose_gelu_gate(dev):
+    from reflectionflow_amd.train import kernels as K
+    x = rnd(dev, 100, 328, seed=1)
+    xt = K.transpose(x)
+    assert xt.shape == (328, 128) and torch.equal(xt[:, :100], x.t()) and float(xt[:, 100:].abs().max()) == 0.0
+    assert torch.equal(K.transpose(x[:, 8:72], rows_pad=100), x[:, 8:72].t().contiguous())
+    z = rnd(dev, 77, 512, seed=2, sc=2.0)
+    zf = z.float().requires_grad_(True)
+    h = torch.nn.functional.gelu(zf, approximate="tanh")
+    dh = rnd(dev, 77, 512, seed=3)
+    h.backward(dh.float())
+    assert rel_l2(K.gelu(z), h.detach()) < 4e-3
+    assert rel_l2(K.gelu_bwd(z, dh), zf.grad) < 6e-3
+    big = z[:, :256]                                                   # a column slice (the single block's mlp half)
+    assert torch.equal(K.gelu(big), K.gelu(big.contiguous()))
+    f, gate, res, dy = rnd(dev, 300, 256, seed=4), rnd(dev, 256, seed=5), rnd(dev, 300, 256, seed=6), rnd(dev, 300, 256, seed=7)
+    y = K.gate_residual(f, gate, res)
+    assert rel_l2(y, res.float() + gate.float() * f.float()) < 4e-3
+    df, dg = K.gate_bwd(dy, f, gate)
+    assert rel_l2(df, dy.float() * gate.float()) < 4e-3
+    assert rel_l2(dg, (dy.float() * f.float()).sum(0)) < 1e-5 and dg.dtype == torch.float32
+    df2, dg2 = K.gate_bwd(dy, f, gate)
+    assert torch.equal(dg, dg2), "column sums must be bit-reproducible"
+
+
+@pytest.mark.parametrize("rows,D", [(50, 256), (777, 3072), (4608, 3072)])
+def test_layernorm_modulate_bwd(dev, rows, D):
+    from reflectionflow_amd import ops
+    from reflectionflow_amd.train import kernels as K
+    x, dy, dres = rnd(dev, rows, D, seed=1, sc=2.0), rnd(dev, rows, D, seed=2), rnd(dev, rows, D, seed=3)
+    sc, sh = rnd(dev, D, seed=4, sc=0.5), rnd(dev, D, seed=5)
+    xf, scf, shf = x.float().requires_grad_(True), sc.float().requires_grad_(True), sh.float().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xf, (D,), eps=1e-6) * (1 + scf) + shf
+    assert rel_l2(ops.layernorm_modulate(x, sc, sh), y.detach()) < 4e-3
+    y.backward(dy.float())
+    dx, dsc, dsh = K.layernorm_modulate_bwd(x, dy, sc, dres=dres)
+    assert rel_l2(dx, xf.grad + dres.float()) < 5e-3
+    assert rel_l2(dsc, scf.grad) < 1e-4 and rel_l2(dsh, shf.grad) < 1e-4
+    dx0, _, _ = K.layernorm_modulate_bwd(x, dy, sc)
+    assert rel_l2(dx0, xf.grad) < 5e-3
+    assert torch.equal(K.layernorm_modulate_bwd(x, dy, sc, dres=dres)[1], dsc)
+
+
+def _ref_norm_rope(x, w, cos, sin, eps, scale):
+    """x [S, H, 128] fp32 -> RoPE(RMSNorm(x) * w) * scale (block.py:38-41,60-67 + apply_rotary_emb)"""
+    y = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
+    a, b = y[..., 0::2], y[..., 1::2]
+    c0, c1, s0, s1 = cos[:, None, 0::2], cos[:, None, 1::2], sin[:, None, 0::2], sin[:, None, 1::2]
+    return torch.stack([a * c0 - b * s0, b * c1 + a * s1], -1).flatten(-2) * scale
+
+
+@pytest.mark.parametrize("H,S,n_added,extra", [(2, 112, 32, 0), (3, 300, 0, 512)])
+def test_qkv_train_fwd_bwd(dev, H, S, n_added, extra):
+    from reflectionflow_amd import ops
+    from reflectionflow_amd.train import kernels as K
+    D = H * 128
+    raw = rnd(dev, S, 3 * D + extra, seed=1)
+    norms = tuple((1 + 0.1 * rnd(dev, 128, seed=10 + i).float()).to(BF) for i in range(4))
+    ids = torch.stack([torch.zeros(S), torch.arange(S) // 8, torch.arange(S) % 8], 1).to(dev)
+    cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
+    a = K.qkv_train_fwd(raw, H, n_added, norms if n_added else (norms[0], norms[1], None, None), cos, sin)
+    rf = raw.float().requires_grad_(True)
+    tok = torch.arange(S, device=dev)[:, None, None]
+    wq = torch.where(tok < n_added, norms[2].float(), norms[0].float())
+    wk = torch.where(tok < n_added, norms[3].float(), norms[1].float())
+    q = _ref_norm_rope(rf[:, :D].view(S, H, 128), wq, cos, sin, 1e-6, ops.QK_PRESCALE)
+    k = _ref_norm_rope(rf[:, D:2 * D].view(S, H, 128), wk, cos, sin, 1e-6, 1.0)
+    v = rf[:, 2 * D:3 * D].view(S, H, 128)
+    for got, want in ((a.q, q), (a.k, k), (a.v, v)):
+        assert rel_l2(got[:, :S], want.detach().permute(1, 0, 2)) < 4e-3
+        assert float(got[:, S:].abs().max() if a.s_pad > S else 0.0) == 0.0
+    # transposed tiles: element (d, slot(n)) of block n // 32 = x[n][d]
+    n = torch.arange(a.s_pad, device=dev)
+    slot = 8 * ((n % 16) // 4) + 4 * ((n % 32) // 16) + n % 4
+    for tiles, rows in ((a.qt, a.q), (a.kt, a.k)):
+        back = tiles[:, n // 32, :, slot]                              # advanced indices split by a slice: result is [s_pad, H, 128]
+        assert torch.equal(back.permute(1, 0, 2), rows)
+    # vt must be what the forward attention kernel expects: compare attention on it with fp32 softmax
+    out = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True)
+    qf, kf, vf = (t[:, :S].float() for t in (a.q, a.k, a.v))
+    ref = torch.softmax(qf @ kf.transpose(1, 2) * LN2, -1) @ vf
+    assert rel_l2(out, ref.permute(1, 0, 2).reshape(S, D)) < 1e-2
+    # backward
+    dq, dk, dv = rnd(dev, H, a.s_pad, 128, seed=21), rnd(dev, H, a.s_pad, 128, seed=22), rnd(dev, H, a.s_pad, 128, seed=23)
+    (q * dq[:, :S].float().permute(1, 0, 2)).sum().backward(retain_graph=True)
+    (k * dk[:, :S].float().permute(1, 0, 2)).sum().backward(retain_graph=True)
+    (v * dv[:, :S].float().permute(1, 0, 2)).sum().backward()
+    d_raw = torch.zeros_like(raw)
+    K.qkv_train_bwd(raw, H, n_added, norms if n_added else (norms[0], norms[1], None, None), cos, sin, dq, dk, dv, d_raw)
+    assert rel_l2(d_raw[:, :3 * D], rf.grad[:, :3 * D]) < 6e-3
+    assert float(d_raw[:, 3 * D:].abs().max() if extra else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("H,S", [(2, 112), (3, 256), (2, 1000), (24, 1024), (4, 4608)])
+def test_attention_bwd_vs_fp32_autograd(dev, H, S):
+    from reflectionflow_amd import ops
+    from reflectionflow_amd.train import kernels as K
+    D = H * 128
+    raw = rnd(dev, S, 3 * D, seed=3, sc=1.5)
+    w = (torch.ones(128, device=dev) * 1.0).to(BF)
+    ids = torch.stack([torch.zeros(S), torch.arange(S) // 32, torch.arange(S) % 32], 1).to(dev)
+    cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
+    a = K.qkv_train_fwd(raw, H, 0, (w, w, None, None), cos, sin)
+    out = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True)
+    dout = rnd(dev, S, D, seed=4)
+    dq, dk, dv = K.attention_bwd(a, out, dout)
+    qf, kf, vf = (t[:, :S].float().detach().requires_grad_(True) for t in (a.q, a.k, a.v))
+    ref = torch.softmax(qf @ kf.transpose(1, 2) * LN2, -1) @ vf                  # [H, S, 128]
+    assert rel_l2(out, ref.detach().permute(1, 0, 2).reshape(S, D)) < 1e-2
+    ref.backward(dout.float().view(S, H, 128).permute(1, 0, 2))
+    e = [rel_l2(dq[:, :S], qf.grad), rel_l2(dk[:, :S], kf.grad), rel_l2(dv[:, :S], vf.grad)]
+    print(f"  attention bwd H={H} S={S}: rel-L2 dq {e[0]:.2e} dk {e[1]:.2e} dv {e[2]:.2e}")
+    assert max(e) < 1.2e-2
+    if a.s_pad > S:
+        assert float(dq[:, S:].abs().max()) == 0.0 and float(dk[:, S:].abs().max()) == 0.0 and float(dv[:, S:].abs().max()) == 0.0
+    again = K.attention_bwd(a, out, dout)
+    assert all(torch.equal(x, y) for x, y in zip((dq, dk, dv), again)), "the backward must be bit-reproducible (no atomics)"
+
+
+# ------------------------------------------------------------------------------------------------- the whole step
+def _product_step(pipe, batch, cfg):
+    from reflectionflow_amd.train.step import FluxTrainer, lora_parameters
+    tr = FluxTrainer(pipe.transformer, cfg)
+    for p in lora_parameters(pipe.transformer):
+        p.grad = None
+    loss = tr.step(batch)
+    loss.backward()
+    grads = {}
+    for n, p in pipe.transformer.named_parameters():
+        if "lora_" in n:
+            grads[n.replace(".lora_A.default.weight", ".lora_A").replace(".lora_B.default.weight", ".lora_B")] = \
+                None if p.grad is None else p.grad.float().clone()
+    return loss.detach().float(), grads
+
+
+def _oracle_grads(m, key=lambda n: n.replace(".lora_A.default.weight", ".lora_A").replace(".lora_B.default.weight", ".lora_B")):
+    return {key(n): (None if p.grad is None else p.grad.float().clone()) for n, p in TO.lora_parameters(m).items()}
+
+
+def _compare(name, hip, ref32, tbf):
+    worst = 0.0
+    checked = 0
+    for n, g32 in ref32.items():
+        gh, gb = hip[n], tbf[n]
+        if float(g32.abs().max()) == 0.0:
+            assert gh is None or float(gh.abs().max()) == 0.0, f"{n}: the reference gradient is exactly zero"
+            continue
+        assert gh is not None, f"{n}: no gradient"
+        e_h, e_b = rel_l2(gh, g32), rel_l2(gb, g32)
+        worst = max(worst, e_h / (2 * e_b + 1e-2))
+        assert e_h <= 2 * e_b + 1e-2, f"{name} {n}: rel-L2 hip {e_h:.3e} vs torch-bf16 {e_b:.3e}"
+        checked += 1
+    return checked, worst
+
+
+def test_training_step_hd128_against_the_reference_fixture(dev):
+    """2 double + 2 single blocks, LoRA r = 4 on the FLUX-Corrector target list, batch of 2, condition tokens: the loss and all 50
+    LoRA gradients of the HIP path vs the gradients the REFERENCE's own step produced (fp32 fixture)."""
+    z = load("train_step_hd128")
+    om = TO.set_trainable(build("hd128", lora=True).train())
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    ref = {k[5:].replace(".lora_A.default.weight", ".lora_A").replace(".lora_B.default.weight", ".lora_B"): T(z[k]) for k in z if k.startswith("grad/")}
+    # torch-bf16 yardstick: the oracle in bf16 on this GPU
+    ob = TO.set_trainable(bf16_oracle(om).to(dev).train())
+    tb = lambda k: T(z[k]).to(dev)   # noqa: E731
+    loss_b, _ = TO.training_step(ob, tb("x_0").to(BF), tb("img_ids"), tb("pe").to(BF), tb("pooled").to(BF), tb("txt_ids"), tb("cond").to(BF),
+                                 tb("cond_ids"), tb("t"), tb("x_1").to(BF), cfg, dtype=BF)
+    loss_b.backward()
+    tbf = {k: (None if v is None else v.cpu()) for k, v in _oracle_grads(ob).items()}
+    pipe = to_product(om, dev)
+    batch = dict(x_0=tb("x_0").to(BF), img_ids=tb("img_ids"), prompt_embeds=tb("pe").to(BF), pooled_prompt_embeds=tb("pooled").to(BF),
+                 text_ids=tb("txt_ids"), condition_latents=tb("cond").to(BF), condition_ids=tb("cond_ids"), t=tb("t"), x_1=tb("x_1").to(BF))
+    loss, grads = _product_step(pipe, batch, cfg)
+    grads = {k: (None if v is None else v.cpu()) for k, v in grads.items()}
+    l32 = float(T(z["loss"]))
+    print(f"  loss: hip {float(loss):.5f} torch-bf16 {float(loss_b):.5f} reference fp32 {l32:.5f}")
+    assert abs(float(loss) - l32) <= 2 * abs(float(loss_b) - l32) + 2e-2 * l32
+    n, worst = _compare("hd128", grads, ref, tbf)
+    print(f"  {n} non-zero LoRA gradients within tolerance (worst ratio to the bound {worst:.2f})")
+    assert n == 44
+    # bit-reproducible: the same step again
+    loss2, grads2 = _product_step(pipe, batch, cfg)
+    assert torch.equal(loss, loss2)
+    for k, v in grads.items():
+        assert (v is None and grads2[k] is None) or torch.equal(v, grads2[k].cpu()), k
+
+
+def test_training_step_flux_width_blocks_vs_fp32_oracle(dev):
+    """One DoubleStream + one SingleStream block at FLUX.1-dev width (D = 3072, 24 heads, mlp 12288, LoRA r = 32), 512 text +
+    1024 image + 256 condition tokens: loss and LoRA gradients vs the fp32 oracle (run on the GPU), torch-bf16 as the yardstick."""
+    torch.manual_seed(0)
+    om = O.FluxTransformer2DModel(num_layers=1, num_single_layers=1).float()
+    O.inject_lora(om, r=32, alpha=32.0)
+    O.init_synthetic_(om, seed=3, std=0.02)
+    TO.set_trainable(om.train())
+    St, gh, gc = 512, 32, 16
+    Si, Sc = gh * gh, gc * gc
+    g = torch.Generator().manual_seed(5)
+    x_0, cond = torch.randn(1, Si, 64, generator=g), torch.randn(1, Sc, 64, generator=g)
+    pe, pooled = torch.randn(1, St, 4096, generator=g), torch.randn(1, 768, generator=g)
+    txt_ids, img_ids = torch.zeros(St, 3), O.prepare_latent_image_ids(gh, gh)
+    cond_ids = O.prepare_latent_image_ids(gc, gc)
+    cond_ids[:, 2] -= gc
+    t, x_1 = torch.tensor([0.5]), torch.randn(1, Si, 64, generator=g)                    # t * 1000 exact in bf16
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    pipe = to_product(om, dev)
+    o32 = om.to(dev)
+    d = lambda x: x.to(dev)   # noqa: E731
+    loss32, _ = TO.training_step(o32, d(x_0), d(img_ids), d(pe), d(pooled), d(txt_ids), d(cond), d(cond_ids), d(t), d(x_1), cfg,
+                                 conditioning_dtype=BF)
+    loss32.backward()
+    ref = {k: v.cpu() for k, v in _oracle_grads(o32).items()}
+    ob = TO.set_trainable(bf16_oracle(o32).train())
+    for p in ob.parameters():
+        p.grad = None
+    loss_b, _ = TO.training_step(ob, d(x_0).to(BF), d(img_ids), d(pe).to(BF), d(pooled).to(BF), d(txt_ids), d(cond).to(BF), d(cond_ids), d(t),
+                                 d(x_1).to(BF), cfg, dtype=BF)
+    loss_b.backward()
+    tbf = {k: (None if v is None else v.cpu()) for k, v in _oracle_grads(ob).items()}
+    del o32, ob
+    torch.cuda.empty_cache()
+    batch = dict(x_0=d(x_0).to(BF), img_ids=d(img_ids), prompt_embeds=d(pe).to(BF), pooled_prompt_embeds=d(pooled).to(BF), text_ids=d(txt_ids),
+                 condition_latents=d(cond).to(BF), condition_ids=d(cond_ids), t=d(t), x_1=d(x_1).to(BF))
+    loss, grads = _product_step(pipe, batch, cfg)
+    grads = {k: (None if v is None else v.cpu()) for k, v in grads.items()}
+    l32 = float(loss32)
+    print(f"  FLUX-width 1+1: loss hip {float(loss):.5f} torch-bf16 {float(loss_b):.5f} fp32 {l32:.5f}")
+    assert abs(float(loss) - l32) <= 2 * abs(float(loss_b) - l32) + 2e-2 * l32
+    n, worst = _compare("flux-width", grads, ref, tbf)
+    print(f"  {n} non-zero LoRA gradients within tolerance (worst ratio to the bound {worst:.2f})")
+    assert n >= 20
