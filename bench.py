@@ -739,10 +739,10 @@ def main():
     n_round = args.steps * shard.world_size
     torch.cuda.synchronize()                             # (so that round_boundary_ms is the boundary's own cost, not the last denoise draining)
     t_rb = time.perf_counter()
+    dt_local = t_rb - t0                                 # this rank's own candidates, before it meets the others in the boundary's collective
     scores, best = round_boundary(outs, seeds[args.warmup:], n_round)
     torch.cuda.synchronize()
     round_boundary_s = time.perf_counter() - t_rb
-    dt_local = time.perf_counter() - t0                  # this rank's own time, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     t_end = t0 + dt
