@@ -476,6 +476,58 @@ def cpu_baseline(S_txt, S_img, T, D=3072, heads=24, nd=19, ns=38):
 # ------------------------------------------------------------------------------------------------------
 # power / clock / temperature telemetry (attribute box-to-box differences)
 # ------------------------------------------------------------------------------------------------------
+def amdsmi_snapshot(card=0):
+    """One `amd-smi metric --json` reading reduced to the numbers that attribute a clock: the firmware's THROTTLE ACCUMULATORS (time
+    spent limited by package power tracking = PPT, by temperature, per-XCD "gfx clock below the host limit" split by cause), the
+    energy counter (joules, unfiltered), socket power and the per-XCD shader clocks.  None when amd-smi is missing / fails."""
+    import shutil
+    if not shutil.which("amd-smi"):
+        return None
+    try:
+        r = subprocess.run(["amd-smi", "metric", "-g", str(card), "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        g = (j.get("gpu_data") if isinstance(j, dict) else j)[0]
+        val = lambda x: x.get("value") if isinstance(x, dict) else (None if x == "N/A" else x)   # noqa: E731
+        th, ck = g.get("throttle", {}), g.get("clock", {})
+        xcp = lambda k: (th.get(k) or {}).get("xcp_0") if isinstance(th.get(k), dict) else None   # noqa: E731
+        return {"t": time.perf_counter(), "energy_j": val(g.get("energy", {}).get("total_energy_consumption")),
+                "socket_power_w": val(g.get("power", {}).get("socket_power")),
+                "accumulation_counter": th.get("accumulation_counter"), "ppt_accumulated": th.get("ppt_accumulated"),
+                "socket_thermal_accumulated": th.get("socket_thermal_accumulated"), "hbm_thermal_accumulated": th.get("hbm_thermal_accumulated"),
+                "vr_thermal_accumulated": th.get("vr_thermal_accumulated"), "prochot_accumulated": th.get("prochot_accumulated"),
+                "gfx_below_host_limit_power": xcp("gfx_clk_below_host_limit_power_accumulated"),
+                "gfx_below_host_limit_thermal": xcp("gfx_clk_below_host_limit_thermal_accumulated"),
+                "gfx_below_host_limit_total": xcp("total_gfx_clk_below_host_limit_accumulated"),
+                "low_utilization": xcp("low_utilization_accumulated"),
+                "ppt_violation_activity_pct": val(th.get("ppt_violation_activity")),
+                "gfx_clk_mhz": [val(ck.get(f"gfx_{i}", {}).get("clk")) for i in range(8)],
+                "hotspot_c": val(g.get("temperature", {}).get("hotspot")), "mem_c": val(g.get("temperature", {}).get("mem"))}
+    except Exception:                                          # noqa: BLE001 -- telemetry must never fail the bench
+        return None
+
+
+def amdsmi_delta(a, b):
+    """What happened between two snapshots: joules -> average power, and the share of the firmware's accumulation ticks in which each
+    limiter was active (ppt = package power limit; *_thermal; per-XCD gfx clock held below the host limit, by cause)."""
+    if not a or not b:
+        return None
+    out = {"seconds": round(b["t"] - a["t"], 3)}
+    if a.get("energy_j") is not None and b.get("energy_j") is not None and b["t"] > a["t"]:
+        out["energy_j"] = round(b["energy_j"] - a["energy_j"], 1)
+        out["avg_power_w_from_energy_counter"] = round((b["energy_j"] - a["energy_j"]) / (b["t"] - a["t"]), 1)
+    ticks = (b.get("accumulation_counter") or 0) - (a.get("accumulation_counter") or 0)
+    out["accumulation_ticks"] = ticks
+    if ticks > 0:
+        for k in ("ppt_accumulated", "socket_thermal_accumulated", "hbm_thermal_accumulated", "vr_thermal_accumulated", "prochot_accumulated"):
+            if a.get(k) is not None and b.get(k) is not None:
+                out[k.replace("_accumulated", "_limited_frac")] = round((b[k] - a[k]) / ticks, 4)
+        for k in ("gfx_below_host_limit_power", "gfx_below_host_limit_thermal", "gfx_below_host_limit_total", "low_utilization"):
+            if a.get(k) and b.get(k):
+                out[k + "_frac_per_xcd"] = [round((y - x) / ticks, 4) for x, y in zip(a[k], b[k])]
+    out["end_state"] = {k: b.get(k) for k in ("socket_power_w", "gfx_clk_mhz", "hotspot_c", "mem_c", "ppt_violation_activity_pct")}
+    return out
+
+
 class Telemetry:
     """Samples the GPU's socket power, temperatures and shader clock in a background thread while the bench runs: sysfs hwmon when the
     box exposes it (cheap, ~20 Hz), else `rocm-smi --json` (~3 Hz).  `window(t0, t1)` summarises the samples inside a wall-clock
@@ -732,6 +784,7 @@ def main():
         torch.cuda.empty_cache()
     torch.cuda.synchronize()
     barrier()
+    smi0 = amdsmi_snapshot(local) if shard.rank == 0 else None
     t0 = time.perf_counter()
     outs = []
     for i in range(args.steps):
@@ -746,6 +799,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t_end = t0 + dt
+    smi1 = amdsmi_snapshot(local) if shard.rank == 0 else None
     per_rank = None
     if shard.world_size > 1:
         # MAX over ranks: a device tensor over RCCL, a host tensor over gloo (gloo has no GPU all_reduce here)
@@ -859,6 +913,7 @@ def main():
             if getattr(in_sequence_roofline, "window", None):
                 wins["in_sequence_profile"] = in_sequence_roofline.window
             res["telemetry"] = tele.report(wins)
+            res["telemetry"]["timed_region_firmware_counters"] = amdsmi_delta(smi0, smi1)
         print(json.dumps(res), flush=True)
     if shard.world_size > 1:
         torch.distributed.destroy_process_group()

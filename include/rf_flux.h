@@ -66,7 +66,8 @@ typedef enum rf_gemm_schedule {
   RF_SCHED_TILE256 = 2,     /* 256x256x64 tiles, one per workgroup, never stream-K                                          */
   RF_SCHED_STREAMK = 3,     /* 256x256 stream-K whenever feasible (needs splitk_ws; else as TILE256)                        */
   RF_SCHED_PERSISTENT = 4,  /* one persistent workgroup per CU walking whole 256x256 tiles (needs splitk_ws)                */
-  RF_SCHED_PLAIN256 = 5     /* 256x256 tiles on the plain double-buffered loop: bit-exact reference of the ping-pong loops  */
+  RF_SCHED_PLAIN256 = 5,    /* 256x256 tiles on the plain double-buffered loop: bit-exact reference of the ping-pong loops  */
+  RF_SCHED_W4 = 6           /* 256x256 tiles, ONE wave per SIMD (4 waves x 128x128 wave tiles): fewer LDS bytes per MFMA     */
 } rf_gemm_schedule;
 
 typedef struct rf_kseg {

@@ -1166,6 +1166,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p
 }
 __global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) { gemm_pp16_body<true>(p); }
 
+#include "gemm_w4.hpp"
+
 #ifdef RF_EXPERIMENTS
 #include "experiments/gemm_kernels_exp.inc"
 #include "experiments/gemm_pp4_exp.inc"
@@ -1391,6 +1393,21 @@ static int launch_gemm(GemmParams& p, hipStream_t stream) {
   return RF_OK;
 }
 
+static int launch_gemm_w4m16(GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 2 * 2 * 256 * 128;   // two stages of {A, W} images; the epilogue's 4 x 16.5 KiB regions fit inside
+  static_assert(4 * EPI_REGION <= LDS, "epilogue staging must fit the main loop's LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4m16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  layout_tiles<256, 256>(p);
+  if (p.total_tiles == 0) return RF_OK;
+  hipLaunchKernelGGL(gemm_bf16_w4m16_kernel, dim3(p.total_tiles), dim3(256), LDS, stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
 static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * 4 * 128 * 128, LDS_EPI = 8 * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
@@ -1603,7 +1620,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
   memset(&p, 0, sizeof(p));
   p.w8 = w8 ? 1 : 0;
   p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
-  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_PLAIN256, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
+  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_W4, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
   p.sched = d->schedule;
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
@@ -1704,6 +1721,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
       case RF_SCHED_TILE128: tile = 128; break;
       case RF_SCHED_TILE256: case RF_SCHED_STREAMK: case RF_SCHED_PERSISTENT: tile = 256; break;
       case RF_SCHED_PLAIN256: tile = 257; break;
+      case RF_SCHED_W4: tile = 260; break;
       default: {
         // 256^2 tiles only pay when they still fill the 256 CUs; small problems get 128^2.
         const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
@@ -1729,6 +1747,8 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
     return launch_gemm_skinny(p, stream);
   }
 #endif
+  if (tile == 260)
+    RF_REQUIRE(p.vec_ok && !p.w8, RF_ERR_UNSUPPORTED, "rf_gemm: RF_SCHED_W4 needs bf16 operands and the 16-byte aligned epilogue path");
   if (tile >= 257 && (!p.vec_ok || p.w8)) tile = 256;
   if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
   if (tile == 256 && p.vec_ok && sk_mode(p) != 0) {   // (the plain reference loop / experimental kernels skip the stream-K paths)
@@ -1761,6 +1781,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   g_last_path = 0;
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
   if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (bit-exact reference)
+  if (tile == 260) return launch_gemm_w4m16(p, stream);                   // one wave per SIMD, 128 x 128 wave tiles
 #ifdef RF_EXPERIMENTS
   if (tile == 258) return launch_gemm_w4(p, stream);                       // one wave per SIMD (experimental A/B)
   if (tile == 259) return launch_gemm_ppx(p, stream);                      // ping-pong loop experiments

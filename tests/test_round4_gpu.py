@@ -1,0 +1,93 @@
+"""Round 4: the one-wave-per-SIMD GEMM loop (RF_SCHED_W4: 4 waves x 128x128 wave tiles on 16x16x32 MFMAs, csrc/gemm_w4.hpp) must
+agree BIT FOR BIT with the 8-wave tile-per-block kernel (same MFMA shape, same K order) on every epilogue, on ragged M / N (its
+operand rows beyond M / N come from the buffer range check, not from clamped rows), on K-segment boundaries and token groups."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_kernels_gpu import assert_close, rnd
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from reflectionflow_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _both(fn):
+    from reflectionflow_amd import _lib as L, ops
+    outs = []
+    for sched in (L.RF_SCHED_TILE256, L.RF_SCHED_W4):
+        with ops.gemm_schedule(sched):
+            outs.append(fn())
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (700, 1032, 128), (1000, 768, 512), (4608, 3072, 3072), (130, 104, 192), (513, 3080, 64), (300, 512, 64), (64, 8, 128)])
+def test_w4_store_equals_tile256(dev, M, N, K):
+    from reflectionflow_amd import ops
+    x, W, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.05), rnd(N, dev=dev)
+    a, c = _both(lambda: ops.linear(x, W, b, splitk_ws=False))
+    assert_close(c, x.float() @ W.float().t() + b.float(), f"w4 {M}x{N}x{K}")
+    assert torch.equal(a, c), "W4 and the 8-wave kernel disagree"
+
+
+@pytest.mark.parametrize("Ks", [(64,), (128,), (64, 64), (64, 128, 64), (192, 64), (320, 64, 128), (1024, 128)])
+def test_w4_k_segments_and_epilogues(dev, Ks):
+    from reflectionflow_amd import ops
+    M, N = 700, 1032
+    segs, ref = [], torch.zeros(M, N, device=dev)
+    for i, K in enumerate(Ks):
+        x, W = rnd(M, K, dev=dev, seed=3 * i + len(Ks)), rnd(N, K, dev=dev, scale=0.05, seed=3 * i + 1)
+        segs.append(ops.Seg(x, W))
+        ref += x.float() @ W.float().t()
+    b, gate, res = rnd(N, dev=dev, seed=99), rnd(N, dev=dev, seed=98), rnd(M, N, dev=dev, seed=97)
+
+    def gelu():
+        y = torch.empty(M, N, dtype=BF, device=dev)
+        ops.gemm([ops.Group(segs, bias=b, out=y)], N, ops.RF_EPI_GELU, splitk_ws=False)
+        return y
+
+    def gate_res():
+        y = torch.empty(M, N, dtype=BF, device=dev)
+        ops.gemm([ops.Group(segs, bias=b, out=y, residual=res, gate=gate)], N, ops.RF_EPI_GATE_RES, splitk_ws=False)
+        return y
+    a, c = _both(gelu)
+    assert_close(c, F.gelu(ref + b.float(), approximate="tanh"), f"w4 gelu {Ks}")
+    assert torch.equal(a, c)
+    a, c = _both(gate_res)
+    assert_close(c, res.float() + gate.float() * (ref + b.float()), f"w4 gate_res {Ks}")
+    assert torch.equal(a, c)
+
+
+def test_w4_token_groups_and_qkv_epilogue(dev):
+    """Three token groups (text / image / condition) with a LoRA K-segment on the last, through the fused QKV + RMSNorm + RoPE epilogue."""
+    from oracle import flux_oracle as O
+    from reflectionflow_amd import ops
+    H, D = 2, 256
+    St, Si, Sc = 40, 300, 70
+    S = St + Si + Sc
+    xs = [rnd(m, D, dev=dev, seed=10 + i) for i, m in enumerate((St, Si, Sc))]
+    Ws = [rnd(3 * D, D, dev=dev, scale=0.05, seed=20 + i) for i in range(2)]
+    bs = [rnd(3 * D, dev=dev, seed=30 + i) for i in range(2)]
+    tl, Bl = rnd(Sc, 64, dev=dev, seed=40), rnd(3 * D, 64, dev=dev, scale=0.05, seed=41)
+    nw = [(1 + 0.1 * rnd(128, dev=dev, seed=50 + i).float()).to(BF) for i in range(4)]
+    ids = torch.stack([torch.zeros(S), torch.arange(S) // 16, torch.arange(S) % 16], 1).to(dev)
+    cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
+
+    def run():
+        q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+        groups = [ops.Group([ops.Seg(xs[0], Ws[0])], bias=bs[0], tok_offset=0, norm_q=nw[2], norm_k=nw[3]),
+                  ops.Group([ops.Seg(xs[1], Ws[1])], bias=bs[1], tok_offset=St, norm_q=nw[0], norm_k=nw[1]),
+                  ops.Group([ops.Seg(xs[2], Ws[1]), ops.Seg(tl, Bl)], bias=bs[1], tok_offset=St + Si, norm_q=nw[0], norm_k=nw[1])]
+        ops.gemm(groups, 3 * D, ops.RF_EPI_QKV, q=q, k=k, vt=vt, heads=H, s_pad=s_pad, rope=(cos, sin), q_scale=ops.QK_PRESCALE, splitk_ws=False)
+        return torch.cat([q.flatten(), k.flatten(), vt.flatten()])
+    a, c = _both(run)
+    assert torch.isfinite(c.float()).all() and float(c.float().abs().max()) > 0
+    assert torch.equal(a, c)
