@@ -108,7 +108,9 @@ typedef struct rf_gemm_desc {
                                          0 = 1.0.  The engine folds softmax_scale*log2(e) in here and tells
                                          rf_attention_fwd via q_prescaled, saving a multiply per score. */
   int32_t schedule;                   /* rf_gemm_schedule; 0 = RF_SCHED_AUTO */
-  int32_t _pad;
+  int32_t clock_probe;                /* != 0: block 0 of the 256x256 kernels stores {s_memtime, s_memrealtime} around its main loop
+                                         (read back by rf_debug_clock_probe; bench.py).  Also on while rf_profile_begin is open;
+                                         product launches pass 0. */
   /* optional GEMM scratch (caller-owned, 16-byte aligned; one per stream).  Layout: [0, 4096) flags, then fp32
    * partial tiles.  The first 4 KiB must be ZERO before the first launch that uses the buffer; every launch
    * leaves them zero again.  With it the library may

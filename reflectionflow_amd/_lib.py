@@ -42,7 +42,7 @@ class rf_gemm_desc(C.Structure):
     _fields_ = [("N", C.c_int32), ("epilogue", C.c_int32), ("num_groups", C.c_int32), ("n_split", C.c_int32),
                 ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("heads", C.c_int32), ("s_pad", C.c_int32),
                 ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("norm_eps", C.c_float), ("q_scale", C.c_float),
-                ("schedule", C.c_int32), ("_pad", C.c_int32),
+                ("schedule", C.c_int32), ("clock_probe", C.c_int32),
                 ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("g", rf_gemm_group * 4)]
 
 
@@ -217,19 +217,6 @@ _EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_gemm_pat
                "rf_debug_clock_probe": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
                "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)]),
                "rf_debug_attn_mix_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)])}
-# librf_flux_exp.so only (make -C reflectionflow_amd/csrc EXPERIMENTS=1; tools/kb_*.py): the A/B switches of the studies in profiles/
-_EXP_SIGS = {"rf_debug_force_gemm_tile": (C.c_int, [C.c_int]), "rf_debug_attn_v2": (C.c_int, [C.c_int]),
-             "rf_debug_attn_v4": (C.c_int, [C.c_int]), "rf_debug_attn_v5": (C.c_int, [C.c_int]),
-             "rf_debug_attn_sk": (C.c_int, [C.c_int]), "rf_debug_attn_knock": (C.c_int, [C.c_int]),
-             "rf_debug_attn_v6": (C.c_int, [C.c_int]), "rf_debug_attn_lag": (C.c_int, [C.c_int]),
-             "rf_debug_attn_stamps": (C.c_int, [C.c_void_p]), "rf_debug_attn_mix": (C.c_int, [C.c_int]), "rf_debug_attn_v7": (C.c_int, [C.c_int]), "rf_debug_attn_stamps7": (C.c_int, [C.c_void_p]),
-             "rf_debug_force_gemm_sk": (C.c_int, [C.c_int]), "rf_debug_gemm_persistent_rounds": (C.c_int, [C.c_int]),
-             "rf_debug_gemm_w4_knock": (C.c_int, [C.c_int]), "rf_debug_gemm_mi16": (C.c_int, [C.c_int]),
-             "rf_debug_gemm_even": (C.c_int, [C.c_int]), "rf_debug_gemm_pp4": (C.c_int, [C.c_int]), "rf_debug_gemm_skinny": (C.c_int, [C.c_int]),
-             "rf_debug_gemm_nt_store": (C.c_int, [C.c_int]),
-             "rf_debug_gemm_timeline": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_void_p, C.c_void_p])}
-EXP_LIB_PATH = os.path.join(_HERE, "librf_flux_exp.so")
-
 _lib = None
 
 
@@ -258,38 +245,6 @@ def load():
         raise RFError("librf_flux was not built for gfx950")
     _lib = lib
     return lib
-
-
-_product = None
-
-
-def load_experiments():
-    """tools/ and tests/test_experiments_gpu.py only: make librf_flux_exp.so (same entry points + the rf_debug_* A/B switches)
-    the library `load()` returns.  The product never calls this; `unload_experiments()` switches back."""
-    global _lib, _product
-    if _lib is not None and getattr(_lib, "_rf_exp", False):
-        return _lib
-    if not os.path.exists(EXP_LIB_PATH):
-        raise RFError(f"{EXP_LIB_PATH} not found: build it with `make -C reflectionflow_amd/csrc EXPERIMENTS=1`")
-    import torch  # noqa: F401
-    lib = C.CDLL(EXP_LIB_PATH)
-    for name, (res, args) in {**_SIGS, **_EXTRA_SIGS, **_EXP_SIGS}.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError:
-            raise RFError(f"{EXP_LIB_PATH} is stale (no symbol {name}): rebuild with `make -C reflectionflow_amd/csrc EXPERIMENTS=1`") from None
-        fn.restype, fn.argtypes = res, args
-    if lib.rf_abi_version() != ABI_VERSION:
-        raise RFError(f"{EXP_LIB_PATH} is stale (ABI {lib.rf_abi_version()} != binding {ABI_VERSION}): rebuild")
-    lib._rf_exp = True
-    _product, _lib = _lib, lib
-    return lib
-
-
-def unload_experiments():
-    global _lib, _product
-    if _lib is not None and getattr(_lib, "_rf_exp", False):
-        _lib, _product = _product, None
 
 
 def declared_symbols():

@@ -26,8 +26,9 @@
 // needs a proven score bound <= 100 (P = exp2(s)), LAG = true needs nothing (P = exp2(s - m) with a LAGGED row maximum m that
 // only moves when a tile overflows 2^30 -- checked on the row sums the kernel forms anyway).  attn_fwd_kernel_v4 is the
 // 32x32x16 form of the bounded kernel (shipped above 8192 keys).  The kernel of a launch is picked from the shape or by the
-// CALLER per launch (rf_attn_desc.kernel) -- no process-global switch.  Knock-out and one-wave-per-SIMD variants:
-// experiments/attention_exp.inc (-DRF_EXPERIMENTS only).  profiles/r02_attention.md / r03_attention.md have the story.
+// CALLER per launch (rf_attn_desc.kernel) -- no process-global switch.  The knock-out, ping-pong (v7) and one-wave-per-SIMD
+// variants of the round-2/3 studies are retired sources (experiments/retired/, git 6cfca97); profiles/r02_attention.md /
+// r03_attention.md have the story.
 #include "common.hpp"
 #include <algorithm>
 #include <type_traits>
@@ -44,6 +45,7 @@ struct AttnParams {
   float cross_bias_l2;  // bias * log2(e)
   float sl2;            // softmax scale * log2(e)
   float lag_thresh;     // lagged-max kernels: a lane's 16-key row sum above this re-centres the row (default 2^30)
+  int probe;            // block 0 stores its shader-clock probe (only while rf_profile_begin is open)
 };
 
 constexpr int ATT_QBLK = 128;        // query rows per workgroup (4 waves x 32)
@@ -510,15 +512,11 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&&
 }
 
 __device__ unsigned long long g_attn_clk_probe[4];   // see ClkProbe (common.hpp)
-#ifdef RF_EXPERIMENTS
-__device__ unsigned long long g_attn_stamps[8][8];   // VAR & 16: s_memtime of block 0's waves around the halves of key tile 40
-__device__ unsigned long long g_attn_stamps7[8][16];  // v7: at the phase boundaries of key tile 40
-#endif
 
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
-  clk.begin();
+  if (p.probe) clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -702,7 +700,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
     tile(t + 3, std::integral_constant<int, 3>{});
   }
 
-  clk.end(g_attn_clk_probe);
+  if (p.probe) clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
   wait_barrier(0);
   {
@@ -820,23 +818,23 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
 // NQT = q-tiles (16 queries) of THIS wave: 2 everywhere except in waves 4-7 of the 192-query workgroups of the mixed-size launch
 // (attn_fwd_kernel_v5mix), which carry one.  q0w = the wave's first query row.  Every wave of a workgroup executes the same
 // barriers whatever its NQT.  ROT: this wave runs the halves of an interval in the order G, F (waves 4-7); DMA: see below.
-// KNOCK = variant bits.  The product runs ATT5_VAR = 256 | 2048; everything else is reachable only from the experiments library:
-//   1, 2   timing knock-outs (wrong results): no fragment reads in the loop / no exp2, sums, packing
+// VAR = compile-time schedule options (every one computes the same result; the library instantiates ATT5_VAR = 256 | 2048 only):
 //   4, 32  fragment reads ONE / THREE groups ahead of their MFMAs instead of two (4 | 32: four)
-//   8      8-byte epilogue stores        16  s_memtime stamps around the halves of key tile 40 (rf_debug_attn_stamps)
+//   8      8-byte epilogue stores
 //   128, 256, 384, ... (bits 7-9)  wave-priority scheme 1..7 (256 = scheme 2: s_setprio 2 in G, 0 in F -- shipped)
 //   2048   row sums on the matrix pipe (SUMM; bounded form only -- shipped)
-template <bool PROBE, bool LAG, int KNOCK = 0, int NQT = 2, bool ROT = false, int DMA = 1>
+// (The timing knock-outs and s_memtime tile stamps of the round-3 studies in profiles/ are not in this tree: git 6cfca97.)
+template <bool PROBE, bool LAG, int VAR = 0, int NQT = 2, bool ROT = false, int DMA = 1>
 __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, const int tid, const int lane, const int w,
                                            const int head, const int q0w, const int t0, const int nt, float* partial, ClkProbe& clk) {
   const int l15 = lane & 15, g = lane >> 4;
   const int S = p.S;
-  constexpr int PRIO = (KNOCK >> 7) & 7;
+  constexpr int PRIO = (VAR >> 7) & 7;
   // SUMM: the row sums l = sum_k P ride on the matrix pipe -- O^T gets a ninth "d tile" whose V^T rows are all ones (a constant register
   // fragment, no LDS read): 2 NQT MFMAs per key tile instead of 16 NQT dependent v_add_f32 in the exp2 half (a wave's adds cost ~6 clocks
   // each on its critical path, DESIGN K3M; the matrix pipe is ~60 % busy).  l then sums the bf16-ROUNDED P, the values the numerator uses.
   // Not with LAG, whose overflow test needs the sums before P is packed.
-  constexpr bool SUMM = !LAG && (KNOCK & 2048) != 0;
+  constexpr bool SUMM = !LAG && (VAR & 2048) != 0;
   const bf16_t* Kh = p.k + (int64_t)head * p.s_pad * 128;
   const bf16_t* Vh = p.vt + (int64_t)head * (p.s_pad >> 6) * (128 * 64);
   const rsrc_t rsK = RF_MAKE_RSRC(Kh), rsV = RF_MAKE_RSRC(Vh);
@@ -1003,23 +1001,14 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     // pack P into the PV operand].  ROT = false: F(t), G(t) -- G reads K(t+1) in ring slot (TS+1) % 4.  ROT = true: G(t-1), F(t) --
     // G reads K(t) in slot TS.  Both read V(t-1) in slot (TS+3) % 4 and both leave the rings alone until the next barrier.
     constexpr int KSLOT = ROT ? TS : (TS + 1) % 4, VSLOT = (TS + 3) % 4;
-    [[maybe_unused]] unsigned long long stamps[5] = {0, 0, 0, 0, 0};
-    auto stamp = [&](const int i) {
-#ifdef RF_EXPERIMENTS
-      if constexpr ((KNOCK & 16) != 0)
-        if (t == 40 && blockIdx.x == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamps[i])::"memory");
-#endif
-    };
-    stamp(0);
     // needed now: K(t+1) [next scores], V(t-1) [pending PV]; may stay in flight: K(t+2), V(t)
     wait_barrier((t + 2 < nt) + 1);
-    stamp(1);
     if (t + 3 < nt) issue_k(t + 3, (TS + 3) % 4);
     if (t + 1 < nt) issue_v(t + 1, (TS + 1) % 4);
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int AHEAD = (KNOCK & 36) == 36 ? 4 : (KNOCK & 32) ? 3 : (KNOCK & 4) ? 1 : 2;   // fragment reads run AHEAD groups in front of their MFMAs (2: -2.3 % vs 1, profiles/r03_kb_attn_mix_v1.log)
+    constexpr int AHEAD = (VAR & 36) == 36 ? 4 : (VAR & 32) ? 3 : (VAR & 4) ? 1 : 2;   // fragment reads run AHEAD groups in front of their MFMAs (2: -2.3 % vs 1, profiles/r03_kb_attn_mix_v1.log)
     constexpr int NFR = AHEAD + 1;
-    // (experiments) s_setprio schemes, PRIO = (KNOCK >> 7) & 7.  The SIMD's arbiter favours the OLDER wave of a pair whenever both
+    // s_setprio schemes, PRIO = (VAR >> 7) & 7.  The SIMD's arbiter favours the OLDER wave of a pair whenever both
     // have an MFMA ready (tools/ubench/attn_group.py: wave 0 runs at its solo speed, its partner gets the gaps); the schemes shift
     // that: 1: F = 2, G = 0   2: F = 0, G = 2   3: plain waves F = 0, G = 2, rotated waves G = 2, F = 1   4: rotated waves 1, plain 0
     // 5: alternating per group, opposite phase in the rotated waves   6: plain F = 1, G = 2, rotated G = 2, F = 0
@@ -1043,9 +1032,6 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     auto load_pos = [&](auto ptag) {
       constexpr int P = decltype(ptag)::value;
       constexpr int G = ROT ? (P + 8) % 16 : P;
-      if constexpr (KNOCK & 1) {
-        if (t > 0) return;
-      }
       if constexpr (P >= 16) {
       } else if constexpr (G < 8) {
 #pragma unroll
@@ -1078,7 +1064,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) lsum[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[(G / 4) * NQT + qt], lsum[qt], 0, 0, 0);
       }
-      if constexpr (!(KNOCK & 2)) {
+      {
         if constexpr (NQT == 2) {   // score tile G = (b*2 + T)*2 + qt
           float e4[4];
 #pragma unroll
@@ -1201,7 +1187,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
           }
           s_nxt[bt * NQT + qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[P % NFR][e], qf[qt][dsb + e], s_nxt[bt * NQT + qt], 0, 0, 0);
         }
-      if constexpr (!(KNOCK & 2) && (NQT == 2 || ((G - 8) & 1) == 0)) {
+      if constexpr (NQT == 2 || ((G - 8) & 1) == 0) {
         // NQT == 2: score tile ti = G - 8 = (b*2 + T)*2 + qt; NQT == 1: tile (G - 8) / 2 = b*2 + T on the even groups
         constexpr int ti = NQT == 2 ? G - 8 : (G - 8) / 2;
         constexpr int bT = ti / NQT, qt_ = ti % NQT;
@@ -1221,19 +1207,11 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     };   // half_G
     if constexpr (ROT) {
       half_G();
-      stamp(2);
       half_F();
     } else {
       half_F();
-      stamp(2);
       half_G();
     }
-    stamp(3);
-#ifdef RF_EXPERIMENTS
-    if constexpr ((KNOCK & 16) != 0)
-      if (t == 40 && blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 4; ++i) g_attn_stamps[w][i] = stamps[i];
-#endif
   };
   for (int t = 0; t < nt; t += 4) {   // unrolled by the ring size (dispatch guarantees nt % 4 == 0): one exit
     tile(t, std::integral_constant<int, 0>{});
@@ -1243,7 +1221,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
   }
   if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(0);
 
-  if (PROBE) clk.end(g_attn_clk_probe);
+  if (PROBE && p.probe) clk.end(g_attn_clk_probe);
   // ---- epilogue: the last pending product O^T += V(nt-1)^T P(nt-1)^T ------------------------------------------------
   wait_barrier(0);
   if constexpr (ROT) {   // the rotated order has not packed P(nt-1) yet
@@ -1289,7 +1267,7 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     partial[16 * 2048 + 1536 + tid] = -negm[1][0];
     return;
   }
-  attn5_finish<NQT, (KNOCK & 8) != 0>(p, oacc, l_run, lane, head, q0w);
+  attn5_finish<NQT, (VAR & 8) != 0>(p, oacc, l_run, lane, head, q0w);
 }
 
 // The variant the product kernels run (the VAR bits of attn5_body): 256 = wave priority scheme 2 -- s_setprio 2 in G (scores + packing),
@@ -1301,7 +1279,7 @@ template <bool LAG>
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
-  clk.begin();
+  if (p.probe) clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1312,9 +1290,6 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5(const AttnParams p) {
   else attn5_body<false, LAG, ATT5_VAR, 2, true, 0>(p, smem, tid, lane, w, head, q0w, 0, p.S / ATT_KV, nullptr, clk);
 }
 
-#ifdef RF_EXPERIMENTS
-#include "experiments/attention_exp.inc"
-#endif
 
 // Mixed-size launch.  heads x S / 256 workgroups of 256 queries rarely come out as whole rounds of the 256 CUs (S = 4608: 432 =
 // 1.69 rounds run as 2; the split launch above fixes that at the price of ~70 MB of partial (O, l) through HBM and a second
@@ -1333,7 +1308,7 @@ template <bool LAG, int MIX_SMALL_DMA_A = 0>   // 192-query workgroups: 0 = wave
 __global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p, const AttnMixParams mx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
-  clk.begin();
+  if (p.probe) clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1354,9 +1329,6 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v5mix(const AttnParams p,
   }
 }
 
-#ifdef RF_EXPERIMENTS
-#include "experiments/attention_v7_exp.inc"
-#endif
 
 // Sizes of the mixed launch for `units` = S / 16 q-tiles per head: units = 16 a + 12 b.  Greedy in-order dispatch of the a * heads
 // big workgroups, then the b * heads small ones, onto P CUs, with a small workgroup costing `small_cost` of a big one (measured
@@ -1516,11 +1488,7 @@ struct AttnTuning {
   int mix;     // mixed-size launch: -1 = when the dispatch simulation predicts >= 4 %, 0 = never
   int v7;      // 1 = the ping-pong schedule (attn7_body) for the whole-key-axis launches of the 16x16x32 kernels, 0 = v5's
 };
-#ifdef RF_EXPERIMENTS
-static AttnTuning g_at = {-1, 1, 1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
-#else
 static constexpr AttnTuning g_at = {-1, 1, 1, 0, 0, -1, -1, -1, RF_ATT_V7_DEFAULT};
-#endif
 static int g_last_attn_path = 0;
 
 }  // namespace rf
@@ -1540,23 +1508,6 @@ extern "C" int rf_debug_attn_mix_plan(int32_t S, int32_t heads, int32_t num_cus,
 // mixed-size launch of the bounded / lagged-max kernel (7 = v6, experiments)
 extern "C" int rf_debug_last_attn_path(void) { return rf::g_last_attn_path; }
 
-#ifdef RF_EXPERIMENTS
-extern "C" int rf_debug_attn_v2(int on) { rf::g_at.v2 = on < 0 ? -1 : (on ? 1 : 0); return RF_OK; }
-extern "C" int rf_debug_attn_v5(int mode) { rf::g_at.v5 = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
-extern "C" int rf_debug_attn_v4(int on) { rf::g_at.v4 = on ? 1 : 0; return RF_OK; }
-extern "C" int rf_debug_attn_v6(int on) { rf::g_at.v6 = on ? 1 : 0; return RF_OK; }
-extern "C" int rf_debug_attn_knock(int k) { rf::g_at.knock = k; return RF_OK; }
-extern "C" int rf_debug_attn_sk(int mode) { rf::g_at.sk = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
-extern "C" int rf_debug_attn_lag(int mode) { rf::g_at.lag = mode < 0 ? -1 : (mode ? 1 : 0); return RF_OK; }
-extern "C" int rf_debug_attn_mix(int mode) { rf::g_at.mix = mode < 0 ? -1 : 0; return RF_OK; }
-extern "C" int rf_debug_attn_v7(int on) { rf::g_at.v7 = on ? 1 : 0; return RF_OK; }
-extern "C" int rf_debug_attn_stamps7(unsigned long long* out128) {   // [8 waves][16]
-  return hipMemcpyFromSymbol(out128, HIP_SYMBOL(rf::g_attn_stamps7), 128 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
-}
-extern "C" int rf_debug_attn_stamps(unsigned long long* out64) {   // [8 waves][8]
-  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(rf::g_attn_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? RF_OK : RF_ERR_HIP;
-}
-#endif
 
 extern "C" int64_t rf_attention_ws_bytes(void) {
   int dev = 0, cus = 0;
@@ -1615,45 +1566,6 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-#ifdef RF_EXPERIMENTS
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5mix<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7mix<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7mix<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-#endif
-#ifdef RF_EXPERIMENTS
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v6, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7k<48>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v7k<80>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<8>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<80>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<256>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<384>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<640>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<768>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<144>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<272>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<400>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2320>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<2304>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<832>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<320>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<1040>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<512>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel_v5k<528>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT4_LDS));
-#endif
     attr_set = true;
   }
   AttnParams p;
@@ -1663,6 +1575,7 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
   p.cross_bias_l2 = d->cross_bias * 1.4426950408889634f;
   p.sl2 = d->scale * 1.4426950408889634f;
   p.lag_thresh = d->lag_thresh > 0.f ? d->lag_thresh : 1073741824.0f;   // 2^30
+  p.probe = prof_open() ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const bool pre = d->q_prescaled != 0;
   ProfScope prof(RF_KC_ATTN, 4.0 * (double)S * (double)S * 128.0 * heads, st);
@@ -1752,10 +1665,6 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       g_last_attn_path = 9;
       break;
     case RF_ATTN_LAGGED16:
-#ifdef RF_EXPERIMENTS
-      if (g_at.v7) hipLaunchKernelGGL(attn_fwd_kernel_v7<true>, grid2, blk, ATT4_LDS, st, p);
-      else
-#endif
       hipLaunchKernelGGL(attn_fwd_kernel_v5<true>, grid2, blk, ATT4_LDS, st, p);
       g_last_attn_path = 8;
       break;
@@ -1769,69 +1678,12 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
       mx.n_big = a * heads;
       mx.big_per_head = a;
       const dim3 gridm((a + b) * heads);
-#ifdef RF_EXPERIMENTS
-      if (g_at.v7) {
-        if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v7mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
-        else hipLaunchKernelGGL(attn_fwd_kernel_v7mix<false>, gridm, blk, ATT4_LDS, st, p, mx);
-      } else
-#endif
-#ifdef RF_EXPERIMENTS
-      if (g_at.knock == 2048 && kern == RF_ATTN_BOUNDED16_MIX) hipLaunchKernelGGL((attn_fwd_kernel_v5mix<false, 2>), gridm, blk, ATT4_LDS, st, p, mx);
-      else
-#endif
       if (kern == RF_ATTN_LAGGED16_MIX) hipLaunchKernelGGL(attn_fwd_kernel_v5mix<true>, gridm, blk, ATT4_LDS, st, p, mx);
       else hipLaunchKernelGGL(attn_fwd_kernel_v5mix<false>, gridm, blk, ATT4_LDS, st, p, mx);
       g_last_attn_path = kern == RF_ATTN_LAGGED16_MIX ? 11 : 10;
       break;
     }
     case RF_ATTN_BOUNDED16:
-#ifdef RF_EXPERIMENTS
-      if (g_at.v6 && !g_at.knock) {
-        hipLaunchKernelGGL(attn_fwd_kernel_v6, grid2, dim3(256), ATT4_LDS, st, p);
-        g_last_attn_path = 7;
-        break;
-      }
-      if (g_at.v7 && (g_at.knock == 16 || g_at.knock == 48 || g_at.knock == 80)) {
-        if (g_at.knock == 16) hipLaunchKernelGGL(attn_fwd_kernel_v7k<16>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 48) hipLaunchKernelGGL(attn_fwd_kernel_v7k<48>, grid2, blk, ATT4_LDS, st, p);
-        else hipLaunchKernelGGL(attn_fwd_kernel_v7k<80>, grid2, blk, ATT4_LDS, st, p);
-        g_last_attn_path = 5;
-        break;
-      }
-      if (g_at.knock) {
-        if (g_at.knock == 1) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 2) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 4) hipLaunchKernelGGL(attn_fwd_kernel_v5k<4>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 8) hipLaunchKernelGGL(attn_fwd_kernel_v5k<8>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 16) hipLaunchKernelGGL(attn_fwd_kernel_v5k<16>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 32) hipLaunchKernelGGL(attn_fwd_kernel_v5k<32>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 64) hipLaunchKernelGGL(attn_fwd_kernel_v5k<64>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 80) hipLaunchKernelGGL(attn_fwd_kernel_v5k<80>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 128) hipLaunchKernelGGL(attn_fwd_kernel_v5k<128>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 256) hipLaunchKernelGGL(attn_fwd_kernel_v5k<256>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 384) hipLaunchKernelGGL(attn_fwd_kernel_v5k<384>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 1024) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1024>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 640) hipLaunchKernelGGL(attn_fwd_kernel_v5k<640>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 768) hipLaunchKernelGGL(attn_fwd_kernel_v5k<768>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 144) hipLaunchKernelGGL(attn_fwd_kernel_v5k<144>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 272) hipLaunchKernelGGL(attn_fwd_kernel_v5k<272>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 400) hipLaunchKernelGGL(attn_fwd_kernel_v5k<400>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 1024) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1024>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 1040) hipLaunchKernelGGL(attn_fwd_kernel_v5k<1040>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 528) hipLaunchKernelGGL(attn_fwd_kernel_v5k<528>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 320) hipLaunchKernelGGL(attn_fwd_kernel_v5k<320>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 832) hipLaunchKernelGGL(attn_fwd_kernel_v5k<832>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 2304) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2304>, grid2, blk, ATT4_LDS, st, p);
-        else if (g_at.knock == 2320) hipLaunchKernelGGL(attn_fwd_kernel_v5k<2320>, grid2, blk, ATT4_LDS, st, p);
-        else hipLaunchKernelGGL(attn_fwd_kernel_v5k<3>, grid2, blk, ATT4_LDS, st, p);
-        g_last_attn_path = 5;
-        break;
-      }
-#endif
-#ifdef RF_EXPERIMENTS
-      if (g_at.v7) hipLaunchKernelGGL(attn_fwd_kernel_v7<false>, grid2, blk, ATT4_LDS, st, p);
-      else
-#endif
       hipLaunchKernelGGL(attn_fwd_kernel_v5<false>, grid2, blk, ATT4_LDS, st, p);
       g_last_attn_path = 5;
       break;

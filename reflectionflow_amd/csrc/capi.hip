@@ -46,6 +46,7 @@ ProfScope::ProfScope(int cls, double work, hipStream_t s) : idx_(-1), s_(s) {
   (void)hipEventRecord(g_prof.ev[idx_], s_);
 }
 ProfScope::~ProfScope() {}
+bool prof_open() { return g_prof.on; }
 
 static void prof_free() {
   for (int i = 0; i <= g_prof.cap; ++i)

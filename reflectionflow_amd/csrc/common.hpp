@@ -67,6 +67,8 @@ struct ProfScope {
   hipStream_t s_;
 };
 
+bool prof_open();   // capi.hip: a kernel-class profile (rf_profile_begin) is open -> kernels also store their clock probes
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

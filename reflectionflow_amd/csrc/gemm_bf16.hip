@@ -25,9 +25,8 @@
 // persistent schedules) and gemm_mainloop_pp2_m16 (fp8 / mixed launches: gemm_w8_pp16_kernel and the W8 stream-K kernel),
 // splitk_reduce_kernel, dispatch() and the C entry points.  The schedule of a launch is picked by dispatch() from the shape or
 // by the CALLER per launch (rf_gemm_desc.schedule) -- there is no process-global kernel switch in this library.
-// The loops kept for the A/B studies of profiles/r02_gemm_power.md (round-1 phases, 32x32x16 MFMA shapes, one wave per SIMD,
-// skinny-N, knock-outs, the s_memtime timeline) live in experiments/*.inc and are compiled only with -DRF_EXPERIMENTS
-// (make EXPERIMENTS=1 -> librf_flux_exp.so, which tools/kb_*.py load; its rf_debug_* setters do not exist in librf_flux.so).
+// The loops of the A/B studies in profiles/r01..r03 (round-1 phases, 32x32x16 MFMA shapes, skinny-N, knock-outs, the s_memtime
+// timeline) are not in this tree any more: they are retired sources under csrc/experiments/retired/ that built against git 6cfca97.
 #include "common.hpp"
 #include <type_traits>
 #include <stdlib.h>
@@ -59,7 +58,6 @@ struct GemmParams {
   int w8;      // 1: at least one token group has fp8 e4m3 operands (1 byte / element; a K-tile is 128 elements = the same
                //    128 bytes): the launch uses the mixed-precision kernels, which pick the multiply per group
   int vec_ok;  // every output/residual/bias/gate pointer is 16-byte aligned and N % 8 == 0: LDS-staged epilogue
-  int nt_store;  // LDS-staged epilogue: write the output rows with non-temporal stores (rf_debug_gemm_nt_store)
   bf16_t* q; bf16_t* k; bf16_t* vt;
   const float* rope_cos; const float* rope_sin; float norm_eps; float q_scale;
   // deterministic split-K (few-tile GEMMs, e.g. the LoRA down-projections): blockIdx.y = K-slice of kchunk
@@ -67,32 +65,14 @@ struct GemmParams {
   int ksplit, kchunk; float* ws; int64_t ws_slice; int ws_ld;
   float* scratch; int64_t scratch_bytes;  // host side: the caller's scratch as passed (flags + partials)
   int sched, _pad_s;                      // host side: rf_gemm_desc.schedule (rf_gemm_schedule)
-  unsigned long long* timeline;           // debug build of the kernel only (rf_debug_gemm_timeline)
+  int probe, _pad_p;                      // block 0 stores its shader-clock probe (rf_gemm_desc.clock_probe, or while a profile is open)
   GemmGroupDev g[4];
 };
 
 __device__ unsigned long long g_clk_probe[4];   // see ClkProbe (common.hpp)
 __device__ unsigned long long g_clk_probe_epi[2];   // {s_memtime, s_memrealtime} when block 0 / wave 0 has drained its epilogue stores
 
-// Kernel-selection knobs.  In librf_flux.so they are compile-time constants (the shipped choice); the experiments build
-// (-DRF_EXPERIMENTS) makes them mutable through rf_debug_* setters for the A/B tools.
-#define RF_GEMM_PP4_DEFAULT 0
-struct Tuning {
-  int nt_store;            // LDS-staged epilogue writes output rows with non-temporal stores
-  int mi16;                // bf16 launches of the 256x256 kernels use 16x16x32 MFMAs
-  int even;                // ... in evenly loaded phases (gemm_mainloop_pp3_m16)
-  int force_tile;          // 0 = rf_gemm_desc.schedule / heuristic; 128 / 256 / 257 / 258 / 259 forced
-  int force_sk;            // -1 = schedule / heuristic, 0 = never, 1 = stream-K whenever feasible, 2 = persistent whole tiles
-  int persistent_rounds;   // > 0: bf16 launches with >= this many rounds run as ONE persistent launch (measured neutral: off)
-  int skinny;              // LoRA down-projections on the single-launch skinny-N kernel (measured slower: off)
-  int w4_knock;            // variant selector of the experimental kernels
-  int pp4;                 // bf16 tile-per-block launches on gemm_mainloop_pp4_m16 (two 32-MFMA phases per K-tile)
-};
-#ifdef RF_EXPERIMENTS
-static Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0, RF_GEMM_PP4_DEFAULT};
-#else
-static constexpr Tuning g_tune = {0, 1, 1, 0, -1, 0, 0, 0, RF_GEMM_PP4_DEFAULT};
-#endif
+constexpr int PERSISTENT_ROUNDS = 0;   // > 0: bf16 launches with >= this many rounds run as ONE persistent launch (measured neutral: off)
 constexpr int EPI_PARTIAL = 100;  // internal epilogue id: raw fp32 accumulators -> split-K scratch
 
 
@@ -424,8 +404,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_v(const GemmParams& p, const G
           } else {
             dst = G.out + (int64_t)m * G.ldo + (n - ncol_base);
           }
-          if (p.nt_store) __builtin_nontemporal_store(pack8(v), (u32x4*)dst);   // a round's 32 x 128 KiB per XCD would fill its 4 MiB L2
-          else *(u32x4*)dst = pack8(v);
+          *(u32x4*)dst = pack8(v);   // (non-temporal stores here were measured neutral to -1 %: profiles/r02, tools/kb_nt_store.py)
         }
       }
     }
@@ -447,10 +426,10 @@ __device__ __forceinline__ void gemm_epilogue_lds16(const GemmParams& p, const G
 
 // ---- main loop ----------------------------------------------------------------------------------------
 // acc += A[m0.., K-tiles kt_begin .. kt_begin+nk) . W[n0.., same)^T over the concatenation of G's K segments.
-template <int BM, int BN, int WM, int WN, bool TL = false>
+template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                               const int nk, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], char* smem, const int w,
-                                              const int lane, unsigned long long* tl = nullptr) {
+                                              const int lane) {
   constexpr int NW = WM * WN;
   constexpr int NT = NW * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -546,29 +525,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
   stage(kk, 0);
   advance();
 
-  // TL: s_memtime at three points per K-tile (before the drain, after it, after the barrier), summed per wave
-  unsigned long long t_a = 0, t_b = 0, t_c = 0, s_drain = 0, s_bar = 0, s_body = 0, t_start = 0;
-  if constexpr (TL) {
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
-    t_c = t_start;
-  }
   for (int kt = 0; kt < nk; ++kt) {
-    if constexpr (TL) {
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a)::"memory");
-      if (kt > 0) s_body += t_a - t_c;
-    }
     // explicit drain of this wave's LDS-DMA before the barrier: never rely on the compiler's own
     // vmcnt placement for LDS-DMA in a loop (see attention.hip)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (TL) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_b)::"memory");
     __syncthreads();  // tile kt has landed for every wave; every wave is done with tile kt-1
-    if constexpr (TL) {
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_c)::"memory");
-      s_drain += t_b - t_a;
-      s_bar += t_c - t_b;
-      __builtin_amdgcn_sched_barrier(0);
-    }
     // The next tile's 8 LDS-DMA pieces are issued BEHIND the fragment reads of the first three k-steps rather than all
     // at once after the barrier: the matrix pipe restarts ~300 cycles earlier per K-tile (+5-10 %, measured; profiles/r01_gemm_variants.md)
     const bool more = kt + 1 < nk;
@@ -598,15 +559,6 @@ __device__ __forceinline__ void gemm_mainloop(const GemmGroupDev& G, const int N
     }
     if (more) advance();
   }
-  if constexpr (TL) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_a)::"memory");
-    s_body += t_a - t_c;
-    if (tl != nullptr && lane == 0) {
-      tl[w * 8 + 0] = s_drain; tl[w * 8 + 1] = s_bar; tl[w * 8 + 2] = s_body; tl[w * 8 + 3] = t_a - t_start;
-      tl[w * 8 + 4] = (unsigned long long)nk;
-    }
-  }
 }
 
 // local tile id of a group -> (tm, tn).  Grouped raster: column bands of GW tiles; consecutive ids (= one XCD's
@@ -623,7 +575,7 @@ __device__ __forceinline__ void tile_coords(const int lt, const int tiles_m, con
 }
 
 // VEC: LDS-staged 16-byte epilogue (all pointers 16-byte aligned, N % 8 == 0) vs the per-element fallback
-template <int BM, int BN, int WM, int WN, bool VEC, bool TL = false>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
@@ -651,8 +603,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams
   const int nk = p.ksplit > 1 ? ((nk_all - kt_begin) < p.kchunk ? (nk_all - kt_begin) : p.kchunk) : nk_all;
 
   f32x16 acc[FM][FN];
-  gemm_mainloop<BM, BN, WM, WN, TL>(G, p.N, m0, n0, kt_begin, nk, acc, smem, w, lane,
-                                    TL ? p.timeline + (int64_t)(blockIdx.x % 16) * 64 : nullptr);
+  gemm_mainloop<BM, BN, WM, WN>(G, p.N, m0, n0, kt_begin, nk, acc, smem, w, lane);
 
   if constexpr (VEC) {
     static_assert(FN == 4, "LDS-staged epilogue expects 128-column wave strips");
@@ -703,16 +654,13 @@ __device__ __forceinline__ i32x8 cat_frag(const bf16x8& lo, const bf16x8& hi) {
 #define RF_MFMA_FP8_16(a, b, c) (c)
 #endif
 
-#ifdef RF_EXPERIMENTS
-#include "experiments/gemm_loops_exp.inc"
-#endif
 
 // The same balanced schedule on v_mfma_f32_16x16x32_bf16.  Under the 1.4 kW cap the matrix pipes sustain 1.82 PFLOP/s with
 // 32x32x16 MFMAs on random bf16 operands and 2.06 PFLOP/s with 16x16x32 (tools/ubench/mfma_power.py, no memory traffic at
 // all: the chip settles at 1.89 vs 2.13 GHz) -- the small shape reads and writes half the accumulator bytes per MAC.  Fragment
 // counts per phase, LDS image, staging and barriers are unchanged (a 32-row A half = 2 row tiles x 2 k-steps = 4 fragments,
 // a 64-column W half = 4 x 2 = 8); only the lane -> (row, chunk) map of a fragment read and the accumulator layout differ.
-template <bool W8 = false, int KNOCK = 0>   // KNOCK (timing diagnostics, wrong results): 1 = no DMA in the loop, 2 = no fragment reads
+template <bool W8 = false>
 __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                   const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
   constexpr int ESZ = W8 ? 1 : 2;  // bytes per element
@@ -779,14 +727,12 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
   auto frag_coff = [&](int ks) { return ((ks * 4 + (lane >> 4)) ^ swz) << 4; };
   // A half: fragments [rt*2 + ks] (2 row tiles x 2 k-steps); W half: [ct*2 + ks] (4 column tiles x 2 k-steps)
   auto rdA = [&](bf16x8 (&dst)[4], const char* half) {
-    if (KNOCK & 2) return;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) dst[rt * 2 + ks] = *(const bf16x8*)(half + a_off + rt * 2048 + frag_coff(ks));
   };
   auto rdB = [&](bf16x8 (&dst)[8], const char* half) {
-    if (KNOCK & 2) return;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)      // k-step 0 of all four column tiles first: the phase's first MFMAs need those
 #pragma unroll
@@ -856,7 +802,7 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
   auto tile = [&](const int t, bf16x8 (&P)[4], bf16x8 (&Q)[4]) {
     const char* base = smem + (t & 1) * BUF;
     const char* nbase = smem + ((t + 1) & 1) * BUF;
-    const bool more1 = !(KNOCK & 1) && t + 1 < nk, more2 = !(KNOCK & 1) && t + 2 < nk;
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
     // ---- p0: 8 reads ---------------------------------------------------------------------
     rdB(bq, base);
     RF_PP2_BAR();
@@ -910,13 +856,12 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
 }
 
 
-// Experiment (rf_debug_force_gemm_tile(259), variant 11): the evenly loaded 6/6/6/6 + 2/2/2/2 schedule of gemm_mainloop_pp3 on
-// 16x16x32 MFMAs: the k-step-0 fragments of column tiles 0, 1 of each W half are read one phase early (e0 / e1), the other six
+// THE SHIPPED bf16 LOOP (gemm_bf16_pp16e_kernel; the stream-K kernel's EVEN form): the evenly loaded 6/6/6/6 + 2/2/2/2 ping-pong
+// schedule on 16x16x32 MFMAs: the k-step-0 fragments of column tiles 0, 1 of each W half are read one phase early (e0 / e1), the other six
 // share one register set m; a phase starts with the four MFMAs that need only the early pair.
 __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                   const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
   constexpr int ESZ = 2;  // bytes per element
-  constexpr bool W8 = false; constexpr int KNOCK = 0;
   constexpr int HT = 128 * 128;  // half-tile bytes
   constexpr int BUF = 4 * HT;    // {A0, A1, B0, B1} of one K-tile
   const int wm = w >> 1, wn = w & 1, grp = w >> 2;
@@ -980,7 +925,6 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
   auto frag_coff = [&](int ks) { return ((ks * 4 + (lane >> 4)) ^ swz) << 4; };
   // A half: fragments [rt*2 + ks] (2 row tiles x 2 k-steps); W half: [ct*2 + ks] (4 column tiles x 2 k-steps)
   auto rdA = [&](bf16x8 (&dst)[4], const char* half) {
-    if (KNOCK & 2) return;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1105,7 +1049,7 @@ template <bool W8>
 __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
-  clk.begin();
+  if (p.probe) clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1122,16 +1066,16 @@ __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
   f32x4 acc[4][8];
   if (W8 && G.w8) {
     gemm_mainloop_pp2_m16<W8>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-    clk.end(g_clk_probe);
+    if (p.probe) clk.end(g_clk_probe);
     __syncthreads();
     gemm_epilogue_lds16<2, W8>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
   } else {
     gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-    clk.end(g_clk_probe);
+    if (p.probe) clk.end(g_clk_probe);
     __syncthreads();  // every wave is done reading the staged operands: the LDS is free
     gemm_epilogue_lds16<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
   }
-  if (blockIdx.x == 0 && w == 0) {   // probe only: when has this wave's part of the tile left the CU?
+  if (p.probe && blockIdx.x == 0 && w == 0) {   // probe only: when has this wave's part of the tile left the CU?
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
       unsigned long long c, r;
@@ -1144,7 +1088,7 @@ __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
 __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
-  clk.begin();
+  if (p.probe) clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1160,7 +1104,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x4 acc[4][8];
   gemm_mainloop_pp3_m16(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
-  clk.end(g_clk_probe);
+  if (p.probe) clk.end(g_clk_probe);
   __syncthreads();  // every wave is done reading the staged operands: the LDS is free
   gemm_epilogue_lds16<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
 }
@@ -1168,10 +1112,6 @@ __global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) {
 
 #include "gemm_w4.hpp"
 
-#ifdef RF_EXPERIMENTS
-#include "experiments/gemm_kernels_exp.inc"
-#include "experiments/gemm_pp4_exp.inc"
-#endif
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
 // One persistent block per CU.  The launch's MAC work is measured in K-tile iterations (tile-major) and cut into
@@ -1286,12 +1226,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
       else if constexpr (EVEN && !W8) gemm_mainloop_pp3_m16(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
       else gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     }
-#ifdef RF_EXPERIMENTS
-    else if (g8) gemm_mainloop_pp2<true>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
-    else gemm_mainloop_pp2<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);  // same ping-pong loop as the tile-per-block kernel
-#else
     static_assert(MI16, "librf_flux.so ships the 16x16 MFMA shapes only");
-#endif
 
     if (!is_tail) {
       // head or middle piece: raw accumulators -> this block's slot, [quad k][thread] x 16 B, as agent-coherent
@@ -1352,10 +1287,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
         if (g8) gemm_epilogue_lds16<FM, W8>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
         else gemm_epilogue_lds16<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
       }
-#ifdef RF_EXPERIMENTS
-      else if (g8) gemm_epilogue_lds<FM, true>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
-      else gemm_epilogue_lds<FM, false>(p, G, acc, m0, n0, wm * TM, wn * TN, lane_i, smem + w * EPI_REGION);
-#endif
     }
   }
 }
@@ -1372,16 +1303,13 @@ static void layout_tiles(GemmParams& p) {
   p.total_tiles = start;
 }
 
-#ifdef RF_EXPERIMENTS
-#include "experiments/gemm_launch_exp.inc"
-#endif
 
-template <int BM, int BN, int WM, int WN, bool VEC, bool TL = false>
+template <int BM, int BN, int WM, int WN, bool VEC>
 static int launch_gemm(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * (BM + BN) * 128, LDS_EPI = WM * WN * EPI_REGION;
   constexpr int LDS = (VEC && LDS_EPI > LDS_MAIN) ? LDS_EPI : LDS_MAIN;
   static bool attr_set = false;
-  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, VEC, TL>;
+  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, VEC>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
@@ -1415,31 +1343,11 @@ static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-#ifdef RF_EXPERIMENTS
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16f_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-#endif
-#ifdef RF_EXPERIMENTS
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-#endif
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
-#ifdef RF_EXPERIMENTS
-  if (!g_tune.mi16 || (!p.w8 && !g_tune.even)) {
-    if (p.w8) hipLaunchKernelGGL(gemm_w8_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-    else if (g_tune.mi16) hipLaunchKernelGGL(gemm_bf16_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-    else hipLaunchKernelGGL(gemm_bf16_pp_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-    RF_LAUNCH_CHECK();
-    return RF_OK;
-  }
-#endif
   if (p.w8) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-#ifdef RF_EXPERIMENTS
-  else if (g_tune.pp4) hipLaunchKernelGGL(gemm_bf16_pp16f_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-#endif
   else hipLaunchKernelGGL(gemm_bf16_pp16e_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
@@ -1454,7 +1362,6 @@ static int g_last_path = 0;  // 0 = one tile per block, 1 = split-K, 2 = stream-
 
 // stream-K mode of a launch: -1 = heuristic, 0 = never, 1 = whenever feasible, 2 = persistent whole tiles only
 static int sk_mode(const GemmParams& p) {
-  if (g_tune.force_sk >= 0) return g_tune.force_sk;   // experiments build only (constant -1 in librf_flux.so)
   switch (p.sched) {
     case RF_SCHED_STREAMK: return 1;
     case RF_SCHED_PERSISTENT: return 2;
@@ -1552,7 +1459,7 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   // under this kernel), so a last round that leaves CUs idle costs less than its tile count suggests, while the
   // stream-K region loses the lock-step L2 sharing of A/W panels.  Stream-K wins below ~83 % round utilisation
   // (S=5632: 264 tiles +40..58 %, 792 tiles +9 %, 1056 tiles +5 %) and loses above it (S=4608: 0.84 -> -2..-10 %).
-  const bool persistent_only = force_sk == 2 || (force_sk < 0 && !W8 && g_tune.persistent_rounds > 0 && rounds >= g_tune.persistent_rounds &&
+  const bool persistent_only = force_sk == 2 || (force_sk < 0 && !W8 && PERSISTENT_ROUNDS > 0 && rounds >= PERSISTENT_ROUNDS &&
                                                  (double)T / ((double)rounds * P) >= 0.83);
   if (force_sk < 0 && !persistent_only && (double)T / ((double)rounds * P) >= 0.83) return 0;
   SkParams sk;
@@ -1569,17 +1476,8 @@ static int try_launch_gemm_sk(GemmParams& p, float* ws, int64_t ws_bytes, hipStr
   auto kern16 = gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, !W8>;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)kern16, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-#ifdef RF_EXPERIMENTS
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-#endif
     attr_set = true;
   }
-#ifdef RF_EXPERIMENTS
-  if (!g_tune.mi16) hipLaunchKernelGGL((gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, false>), dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
-  else if (!g_tune.even) hipLaunchKernelGGL((gemm_bf16_sk_kernel<BM, BN, WM, WN, W8, true, false>), dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
-  else
-#endif
   hipLaunchKernelGGL(kern16, dim3(P), dim3(WM * WN * 64), LDS, stream, p, sk);
   RF_LAUNCH_CHECK();
   g_last_path = 2;
@@ -1688,7 +1586,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
           (t.residual == nullptr || (aligned16(t.residual) && t.ldr % 8 == 0));
   }
   p.vec_ok = vec ? 1 : 0;
-  p.nt_store = g_tune.nt_store;
+  p.probe = (d->clock_probe != 0 || prof_open()) ? 1 : 0;
   if (w8) {
     RF_REQUIRE(vec, RF_ERR_ALIGN, "rf_gemm_w8a8: needs N %% 8 == 0 and 16-byte aligned outputs / bias / gate / residual");
     bool any8 = false;
@@ -1715,7 +1613,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   for (int g = 0; g < p.ngroups; ++g) rows += p.g[g].M;
   // tile: 128 / 256 = the shipped kernels, 257 = plain 256x256 loop (bit-exact reference of the ping-pong loops);
   // 258 / 259 = experiments build only
-  int tile = g_tune.force_tile;
+  int tile = 0;
   if (tile == 0) {
     switch (p.sched) {
       case RF_SCHED_TILE128: tile = 128; break;
@@ -1741,12 +1639,6 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
-#ifdef RF_EXPERIMENTS
-  if (g_tune.skinny && g_tune.force_tile == 0 && p.sched == RF_SCHED_AUTO && skinny_ok(p)) {
-    g_last_path = 3;
-    return launch_gemm_skinny(p, stream);
-  }
-#endif
   if (tile == 260)
     RF_REQUIRE(p.vec_ok && !p.w8, RF_ERR_UNSUPPORTED, "rf_gemm: RF_SCHED_W4 needs bf16 operands and the 16-byte aligned epilogue path");
   if (tile >= 257 && (!p.vec_ok || p.w8)) tile = 256;
@@ -1782,10 +1674,6 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
   if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (bit-exact reference)
   if (tile == 260) return launch_gemm_w4m16(p, stream);                   // one wave per SIMD, 128 x 128 wave tiles
-#ifdef RF_EXPERIMENTS
-  if (tile == 258) return launch_gemm_w4(p, stream);                       // one wave per SIMD (experimental A/B)
-  if (tile == 259) return launch_gemm_ppx(p, stream);                      // ping-pong loop experiments
-#endif
   if (tile == 256) return p.vec_ok ? launch_gemm_pp(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }
@@ -1858,37 +1746,6 @@ extern "C" int rf_debug_clock_probe(int which, double* mhz, double* us) {
   return RF_OK;
 }
 
-#ifdef RF_EXPERIMENTS
-// ---- experiments build only (librf_flux_exp.so): kernel-selecting switches for tools/kb_*.py ------------------------------
-extern "C" int rf_debug_force_gemm_tile(int tile) {
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 257 && tile != 258 && tile != 259) return RF_ERR_SHAPE;
-  rf::g_tune.force_tile = tile;
-  return RF_OK;
-}
-// run the 256x256 tile-per-block kernel with s_memtime instrumentation; out = device u64[16 blocks][8 waves][8]
-// (per wave: cycles in the DMA drain, in the barrier, in the K-tile bodies, total, K-tiles) of blocks 0..15 (mod 16)
-extern "C" int rf_debug_gemm_timeline(const rf_gemm_desc* d, unsigned long long* out, void* stream) {
-  rf::GemmParams p;
-  int rc = rf::build_params(d, p);
-  if (rc != RF_OK) return rc;
-  RF_REQUIRE(p.vec_ok && out != nullptr, RF_ERR_ALIGN, "rf_debug_gemm_timeline: needs the aligned path and an output buffer");
-  p.timeline = out;
-  p.ksplit = 1;
-  return rf::launch_gemm<256, 256, 4, 2, true, true>(p, (hipStream_t)stream);
-}
-extern "C" int rf_debug_gemm_nt_store(int on) { rf::g_tune.nt_store = on ? 1 : 0; return RF_OK; }
-extern "C" int rf_debug_gemm_skinny(int on) { rf::g_tune.skinny = on ? 1 : 0; return RF_OK; }   // skinny-N kernel vs split-K
-extern "C" int rf_debug_gemm_pp4(int on) { rf::g_tune.pp4 = on ? 1 : 0; return RF_OK; }
-extern "C" int rf_debug_gemm_even(int on) { rf::g_tune.even = on ? 1 : 0; return RF_OK; }       // 6/6/6/6 vs 8/4/8/4 phases
-extern "C" int rf_debug_gemm_mi16(int on) { rf::g_tune.mi16 = on ? 1 : 0; return RF_OK; }       // MFMA shape of the bf16 256x256 kernel
-extern "C" int rf_debug_gemm_w4_knock(int k) { rf::g_tune.w4_knock = k; return RF_OK; }
-extern "C" int rf_debug_gemm_persistent_rounds(int rounds) { rf::g_tune.persistent_rounds = rounds < 0 ? 0 : rounds; return RF_OK; }
-extern "C" int rf_debug_force_gemm_sk(int mode) {
-  if (mode < -1 || mode > 2) return RF_ERR_SHAPE;
-  rf::g_tune.force_sk = mode;
-  return RF_OK;
-}
-#endif
 
 static int time_gemm_impl(const rf_gemm_desc* d, int32_t iters, float* us, void* stream, bool w8);
 extern "C" int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream) { return time_gemm_impl(d, iters, us, stream, false); }
@@ -1897,6 +1754,7 @@ static int time_gemm_impl(const rf_gemm_desc* d, int32_t iters, float* us, void*
   rf::GemmParams p;
   int rc = rf::build_params(d, p, w8);
   if (rc != RF_OK) return rc;
+  p.probe = 1;   // the timing hook is bench instrumentation: it wants the in-kernel clock of what it times
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   RF_CHECK_HIP(hipEventCreate(&e0));

@@ -158,7 +158,7 @@ __device__ __forceinline__ void gemm_mainloop_w4m16(const GemmGroupDev& G, const
 __global__ __launch_bounds__(256) void gemm_bf16_w4m16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
-  clk.begin();
+  if (p.probe) clk.begin();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_w4m16_kernel(const GemmParams p
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x4 acc[8][8];
   gemm_mainloop_w4m16(G, p.N, m0, n0, nk, acc, smem, w, lane);
-  clk.end(g_clk_probe);
+  if (p.probe) clk.end(g_clk_probe);
   __syncthreads();  // every wave is done reading the staged operands: the LDS is free
   gemm_epilogue_lds16<4, false>(p, G, acc, m0, n0, (w >> 1) * 128, (w & 1) * 128, lane, smem + w * EPI_REGION);
 }

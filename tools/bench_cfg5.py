@@ -9,7 +9,6 @@ Prints one JSON line: s/latent for T steps, TFLOP/s, fraction of the bf16 MFMA p
 (GEMM vs attention vs row kernels) from the library's in-sequence timing hook over 2 profiled forwards."""
 import argparse, json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from reflectionflow_amd import _lib as _rf_lib; _rf_lib.load_experiments()   # A/B switches live in librf_flux_exp.so (make -C reflectionflow_amd/csrc EXPERIMENTS=1)
 import bench
 from reflectionflow_amd import ops
 from reflectionflow_amd.flux.condition import Condition
@@ -22,8 +21,6 @@ ap.add_argument("--steps", type=int, default=10, help="Euler steps per timed lat
 ap.add_argument("--res", type=int, default=2048)
 ap.add_argument("--w8", action="store_true")
 ap.add_argument("--no-cond", action="store_true", help="no condition image (with --res 1024 this is cfg2's S = 4608)")
-ap.add_argument("--ab-attn", action="store_true", help="instead: interleaved in-sequence A/B of the attention kernels (v4 / v5) over profiled forwards")
-ap.add_argument("--ab-mix", action="store_true", help="instead: interleaved in-sequence A/B of the mixed-size attention launch (on / off): wall time of a --steps denoise + per-class times")
 args = ap.parse_args()
 dev = torch.device("cuda:0"); bf = torch.bfloat16
 pipe = bench.build_model(dev, {}, seed=0)
@@ -47,37 +44,6 @@ def one(seed, T):
 
 T = args.steps
 one(1, 2); torch.cuda.synchronize()
-if args.ab_attn:
-    from reflectionflow_amd import _lib
-    lib = _lib.load()
-    for rep in range(3):
-        for v5 in (0, 1):
-            lib.rf_debug_attn_v5(v5)
-            with ops.profile(4096) as pr:
-                one(1, 2); torch.cuda.synchronize()
-            a, gm = pr.classes["attention"], pr.classes.get("gemm_main", pr.classes.get("gemm_w8"))
-            print(f"rep {rep} attention {'v5 (16x16x32)' if v5 else 'v4 (32x32x16)'}: {a['us']/2e3:7.2f} ms/forward = {a['work']/(a['us']*1e-6)/1e12:7.1f} TF   "
-                  f"(GEMM class next to it: {gm['us']/2e3:7.2f} ms/forward)", flush=True)
-    lib.rf_debug_attn_v5(-1)
-    sys.exit(0)
-if args.ab_mix:
-    from reflectionflow_amd import _lib
-    lib = _lib.load()
-    import os
-    os.environ["RF_DENOISE_GRAPH"] = "0"
-    for rep in range(4):
-        for mix in (0, -1, -2):                      # -2: mixed-size launch whose 192-query workgroups let waves 0-3 issue the DMA (experiment)
-            lib.rf_debug_attn_mix(-1 if mix else 0)
-            lib.rf_debug_attn_knock(2048 if mix == -2 else 0)
-            one(2, 2); torch.cuda.synchronize()
-            t0 = time.perf_counter(); one(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-            with ops.profile(4096) as pr:
-                one(1, 2); torch.cuda.synchronize()
-            a, gm = pr.classes["attention"], pr.classes.get("gemm_main", pr.classes.get("gemm_w8"))
-            print(f"rep {rep} mixed-size launch {'off ' if mix == 0 else ('auto' if mix == -1 else 'A-dma')}: {dt / T * 1e3:8.2f} ms/step wall   attention {a['us']/2e3:7.2f} ms/forward = "
-                  f"{a['work']/(a['us']*1e-6)/1e12:7.1f} TF   GEMM class {gm['us']/2e3:7.2f} ms/forward   (last attention path {lib.rf_debug_last_attn_path()})", flush=True)
-    lib.rf_debug_attn_mix(-1); lib.rf_debug_attn_knock(0)
-    sys.exit(0)
 t0 = time.perf_counter(); o = one(2, T); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 assert torch.isfinite(o.float()).all()
 with ops.profile(4096) as pr:
