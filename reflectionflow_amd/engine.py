@@ -231,7 +231,9 @@ def get_workspace(device, d: L.rf_flux_dims) -> L.rf_workspace:
 
 class FluxEngine:
     def __init__(self, transformer: M.FluxTransformer2DModel):
-        self._graphs = {}      # hipGraphs of whole denoise loops, see denoise(use_graph=True)
+        self._graphs = {}      # hipGraphs of whole denoise loops, see denoise(use_graph=True); LRU order
+        self._graph_captures = {}
+        self._graph_cache_max = 3
         self._eager_done = False
         self.lib = L.load()
         self.tr = transformer
@@ -300,15 +302,25 @@ class FluxEngine:
 
     def rope_tables(self, txt_ids, img_ids, cond_ids=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """FluxPosEmbed over [txt | img | cond] ids (transformer.py:129-134) -> fp32 [S,128] x2."""
-        ids = [txt_ids, img_ids] + ([cond_ids] if cond_ids is not None else [])
-        ids = torch.cat([i.to(self.device).float() for i in ids], 0)
-        key = (ids.shape[0], float(ids.sum()), float((ids * ids).sum()), float(ids[-1].sum()))
-        hit = self._rope_cache.get(key)
-        if hit is not None and torch.equal(hit[2], ids):
+        parts = [txt_ids, img_ids] + ([cond_ids] if cond_ids is not None else [])
+        # first level: the SAME id tensors as last time (a denoise loop passes the same objects every step) -- no device read at all.
+        # (tensor identity + version counter: an in-place edit of an id tensor bumps _version and misses)
+        fast = tuple((id(t), t._version, tuple(t.shape)) for t in parts)
+        hit = self._rope_cache.get(("obj", fast))
+        if hit is not None and all(a is b for a, b in zip(hit[2], parts)):
             return hit[0], hit[1]
+        ids = torch.cat([i.to(self.device).float() for i in parts], 0)
+        # second level: equal VALUES in different tensors; the comparison stays on the device except for its one-bit result
+        for k, v in self._rope_cache.items():
+            if k[0] == "val" and k[1] == ids.shape[0] and bool(torch.equal(v[2], ids)):
+                self._rope_cache[("obj", fast)] = (v[0], v[1], list(parts))
+                return v[0], v[1]
         cos, sin = self.tr.pos_embed(ids)
         cos, sin = cos.contiguous(), sin.contiguous()
-        self._rope_cache[key] = (cos, sin, ids)
+        if len(self._rope_cache) > 16:
+            self._rope_cache.clear()
+        self._rope_cache[("val", ids.shape[0], len(self._rope_cache))] = (cos, sin, ids)
+        self._rope_cache[("obj", fast)] = (cos, sin, list(parts))
         return cos, sin
 
     def temb(self, timestep, guidance, pooled) -> torch.Tensor:
@@ -392,9 +404,16 @@ class FluxEngine:
             self._eager_done = True
             return latents
         key = (bytes(d), T, tuple(float(x) for x in dts), ws.base, tuple(cos.shape))
-        ent = self._graphs.get(key)
+        ent = self._graphs.pop(key, None)                    # LRU: a hit moves to the most-recently-used end (re-inserted below)
         if ent is None:
-            if len(self._graphs) >= 2:                       # a captured 50-step loop holds ~110 MB of static tables
+            # a workload that cycles through more keys than the cache holds would re-capture T x ~300 nodes per call (a capture also
+            # syncs the device): count captures per key and fall back to eager launches for a key that keeps being evicted
+            n_cap = self._graph_captures.get(key, 0)
+            if n_cap >= 2:
+                launch(latents, ctx, mod_steps, cos, sin, cond_latents, mod_cond, torch.empty_like(latents))
+                return latents
+            self._graph_captures[key] = n_cap + 1
+            if len(self._graphs) >= self._graph_cache_max:   # a captured 50-step loop holds ~110 MB of static tables
                 self._graphs.pop(next(iter(self._graphs)))
             st = dict(lat=torch.empty_like(latents), ctx=torch.empty_like(ctx), mod=torch.empty_like(mod_steps), cos=torch.empty_like(cos),
                       sin=torch.empty_like(sin), vel=torch.empty_like(latents),
@@ -406,7 +425,8 @@ class FluxEngine:
             with torch.cuda.graph(graph, stream=side):
                 launch(st["lat"], st["ctx"], st["mod"], st["cos"], st["sin"], st["cond"], st["mc"], st["vel"])
             torch.cuda.current_stream().wait_stream(side)
-            ent = self._graphs[key] = (graph, st)
+            ent = (graph, st)
+        self._graphs[key] = ent
         graph, st = ent
         for k_, src in (("lat", latents), ("ctx", ctx), ("mod", mod_steps), ("cos", cos), ("sin", sin), ("cond", cond_latents), ("mc", mod_cond)):
             if src is not None:

@@ -94,6 +94,13 @@ def generate(pipeline, conditions: List[Condition] = None, config_path: str = No
     # 4.1 conditions (reference :177-190; `conditions is not None or []` quirk kept)
     condition_latents, condition_ids, condition_type_ids = ([] for _ in range(3))
     use_condition = conditions is not None or []
+    # geometry the HIP VAE cannot take is refused BEFORE the denoise loop, not after it
+    if hasattr(self.vae, "check_geometry"):
+        if output_type != "latent":
+            self.vae.check_geometry(height, width, "output image")
+        for c in (conditions or []) if use_condition else []:
+            if getattr(c, "condition", None) is not None and hasattr(c.condition, "size"):
+                self.vae.check_geometry(c.condition.size[1], c.condition.size[0], "condition image")
     condition = None
     if use_condition:
         assert len(conditions) <= 1, "Only one condition is supported for now."

@@ -171,11 +171,22 @@ class FluxPipeline:
             clip_state_dict, c1 = load_dir(os.path.join(root, "text_encoder"))
             t5_heads, clip_heads = c2.get("num_heads", t5_heads), c1.get("num_attention_heads", clip_heads)
             clip_eos_token_id = c1.get("eos_token_id", clip_eos_token_id)
+            # everything else the kernels assume is READ from the configs and refused when it differs (no silent defaults)
+            act = c2.get("feed_forward_proj", "gated-gelu")
+            if act != "gated-gelu" or c2.get("d_kv", 64) != 64 or not c2.get("is_gated_act", True):
+                raise ValueError(f"enable_hip_text_encoders(): the HIP T5 path is T5 v1.1 (gated-gelu, d_kv 64); config has feed_forward_proj={act!r}, d_kv={c2.get('d_kv')}")
+            if c1.get("hidden_act", "quick_gelu") != "quick_gelu":
+                raise ValueError(f"enable_hip_text_encoders(): the HIP CLIP path uses quick_gelu; config has hidden_act={c1.get('hidden_act')!r}")
+            t5_kw = dict(eps=float(c2.get("layer_norm_epsilon", 1e-6)), num_buckets=int(c2.get("relative_attention_num_buckets", 32)),
+                         max_distance=int(c2.get("relative_attention_max_distance", 128)))
+            clip_kw = dict(eps=float(c1.get("layer_norm_eps", 1e-5)))
+        else:
+            t5_kw, clip_kw = {}, {}
         if t5_state_dict is None or clip_state_dict is None:
             raise ValueError("enable_hip_text_encoders(): state dicts or a checkpoint root are required")
         dev = self.device
-        self.text_encoder = HipTextEncoders(HipT5Encoder(t5_state_dict, t5_heads, dev), HipClipTextEncoder(clip_state_dict, clip_heads, dev,
-                                                                                                          eos_token_id=clip_eos_token_id), tokenize)
+        self.text_encoder = HipTextEncoders(HipT5Encoder(t5_state_dict, t5_heads, dev, **t5_kw),
+                                            HipClipTextEncoder(clip_state_dict, clip_heads, dev, eos_token_id=clip_eos_token_id, **clip_kw), tokenize)
         return self
 
     def set_progress_bar_config(self, **kw):

@@ -231,7 +231,19 @@ class HipTextEncoders:
     SentencePiece model and CLIP's BPE vocabulary are files this repo does not ship)."""
 
     def __init__(self, t5: HipT5Encoder, clip: HipClipTextEncoder, tokenize: Callable):
-        self.t5, self.clip, self.tokenize = t5, clip, tokenize
+        self.t5, self.clip, self._tokenize = t5, clip, tokenize
+        self._memo = None          # (prompts, L) -> ids of the last tokenize() call
+
+    def tokenize(self, prompts, max_sequence_length: int):
+        """The caller's tokenizer runs BOTH towers' vocabularies per call; encode_prompt asks for the T5 ids (L = max_sequence_length)
+        and the CLIP ids (L = 77) of the same prompts one after the other -- the T5 pass is memoised per prompt list so that one
+        encode_prompt costs one SentencePiece pass at the T5 length, not two passes of each tokenizer."""
+        key = (tuple(prompts), int(max_sequence_length))
+        if self._memo is not None and self._memo[0] == key:
+            return self._memo[1]
+        out = self._tokenize(list(prompts), max_sequence_length)
+        self._memo = (key, out)
+        return out
 
     def encode_t5(self, prompt, max_sequence_length: int, dtype, device):
         single = isinstance(prompt, str)
@@ -241,7 +253,12 @@ class HipTextEncoders:
 
     def encode_clip(self, prompt, dtype, device):
         single = isinstance(prompt, str)
-        _, clip_ids = self.tokenize([prompt] if single else list(prompt), 77)
+        prompts = [prompt] if single else list(prompt)
+        # CLIP ids do not depend on the T5 length: reuse the ids of the T5 call on the same prompts when there was one
+        if self._memo is not None and self._memo[0][0] == tuple(prompts):
+            clip_ids = self._memo[1][1]
+        else:
+            clip_ids = self.tokenize(prompts, 77)[1]
         pooled = self.clip.encode(clip_ids.to(device))[1].to(dtype)
         return pooled[0] if single else pooled
 

@@ -149,6 +149,18 @@ class HipVAE:
     dtype = property(lambda self: BF)
     device = property(lambda self: self.module.device)
 
+    def check_geometry(self, height: int, width: int, what: str = "image") -> None:
+        """Raise NOW (before a search has spent minutes denoising) if an image of height x width pixels cannot go through this VAE:
+        sides must be multiples of the down-scaling factor, and the mid-block attention kernel needs (h / scale)(w / scale) % 64 == 0
+        latent pixels.  The torch AutoencoderKL it replaces takes any size; callers with odd sizes keep the torch module
+        (do not call pipe.enable_hip_vae())."""
+        s = self.scale
+        if height % s or width % s:
+            raise RFError(f"HipVAE: {what} {height}x{width}: sides must be multiples of {s}")
+        if (self._dec.has_attn or self._enc.has_attn) and ((height // s) * (width // s)) % 64:
+            raise RFError(f"HipVAE: {what} {height}x{width} has {(height // s) * (width // s)} latent pixels; the mid-block attention "
+                          "kernel needs a multiple of 64 (e.g. sides that are multiples of 64 pixels)")
+
     def to(self, *a, **k):                                  # pipeline.to(device) walks its parts
         return self
 

@@ -217,6 +217,9 @@ def run_reflection_search(config: dict, prompts: Optional[List[str]], output_dir
     kind = config.get("verifier_args", {}).get("name", "nvila")
     kind = kind if kind in search.SORT_KEYS else "nvila"
     H, W, csize = pa["height"], pa["width"], pa["condition_size"]
+    if hasattr(pipe.vae, "check_geometry"):          # HIP VAE: refuse unsupported sizes before any candidate is generated
+        pipe.vae.check_geometry(H, W, "candidate image")
+        pipe.vae.check_geometry(csize, csize, "condition image")
     use_reflection = reflect is not None
     use_refine = refine is not None
     if use_reflection and not use_refine:
