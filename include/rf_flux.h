@@ -35,7 +35,7 @@ typedef enum rf_status {
 } rf_status;
 
 const char* rf_last_error(void);
-/* ABI version: bump on any struct/signature change. */
+/* ABI version: bump on any struct/signature change (v11: rf_lora_seg.merged, rf_gemm_desc.clock_probe, RF_SCHED_W4). */
 int rf_abi_version(void);
 /* Returns 950 when the library was compiled for gfx950. */
 int rf_target_arch(void);
@@ -254,11 +254,13 @@ int rf_add_inplace(void* out, const void* x, int64_t n, void* stream);
 /* ------------------------------------------------------------------------------------
  * Whole blocks / whole forward / whole denoise loop
  * ---------------------------------------------------------------------------------- */
-typedef struct rf_lora_seg {          /* second K-segment for one fused linear (NULL W2 = no LoRA) */
+typedef struct rf_lora_seg {          /* LoRA of one fused linear (B == NULL: none) */
   const void* A;  /* [r_pad x K]   stacked lora_A rows, zero padded to r_pad % 64 == 0            */
   const void* B;  /* [N x r_pad]   block-diagonal scaling*lora_B                                   */
   int32_t r_pad;
-  int32_t _pad;
+  int32_t merged; /* != 0: B is instead the MERGED weight bf16(W + scaling * lora_B lora_A), [N x K] in the layout of the base
+                     weight; the token groups LoRA acts on multiply by it and no low-rank launches are made (A, r_pad unused).
+                     Static LoRA only (inference); costs one more copy of the LoRA'd weights and one bf16 rounding of the sum. */
 } rf_lora_seg;
 
 typedef struct rf_w8 {                 /* fp8 copy of one (fused) nn.Linear weight for rf_gemm_w8a8; w == NULL: none */

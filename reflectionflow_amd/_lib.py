@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -65,7 +65,7 @@ class rf_w8(C.Structure):
 
 
 class rf_lora_seg(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("r_pad", C.c_int32), ("_pad", C.c_int32)]
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("r_pad", C.c_int32), ("merged", C.c_int32)]
 
 
 _P = C.c_void_p

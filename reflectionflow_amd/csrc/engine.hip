@@ -223,8 +223,9 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         g.a_scale = sXN + s.off; g.w_scale = q8.scale;
         return RF_OK;
       }
-      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, txt ? w->w_add_qkv : w->w_qkv, D, D);
-      if (!txt && s.lora && w->lora_qkv.B) {
+      const bool mrg_lora_qkv = !txt && s.lora && w->lora_qkv.B && w->lora_qkv.merged;   // LoRA folded into a per-group weight copy (W + s B A)
+      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, mrg_lora_qkv ? (const bf16_t*)w->lora_qkv.B : (const bf16_t*)(txt ? w->w_add_qkv : w->w_qkv), D, D);
+      if (!txt && s.lora && w->lora_qkv.B && !w->lora_qkv.merged) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_qkv, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_qkv.B, w->lora_qkv.r_pad, w->lora_qkv.r_pad);
@@ -260,8 +261,9 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         g.a_scale = sA + s.off; g.w_scale = q8.scale;
         return RF_OK;
       }
-      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, txt ? w->w_add_out : w->w_out, D, D);
-      if (!txt && s.lora && w->lora_out.B) {
+      const bool mrg_lora_out = !txt && s.lora && w->lora_out.B && w->lora_out.merged;   // LoRA folded into a per-group weight copy (W + s B A)
+      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, mrg_lora_out ? (const bf16_t*)w->lora_out.B : (const bf16_t*)(txt ? w->w_add_out : w->w_out), D, D);
+      if (!txt && s.lora && w->lora_out.B && !w->lora_out.merged) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
@@ -322,8 +324,9 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         g.a_scale = sA + s.off; g.w_scale = q8.scale;
         return RF_OK;
       }
-      set_seg(g.seg[0], HID + (int64_t)s.off * MLP, MLP, txt ? w->w_ffc2 : w->w_ff2, MLP, MLP);
-      if (!txt && s.lora && w->lora_ff2.B) {
+      const bool mrg_lora_ff2 = !txt && s.lora && w->lora_ff2.B && w->lora_ff2.merged;   // LoRA folded into a per-group weight copy (W + s B A)
+      set_seg(g.seg[0], HID + (int64_t)s.off * MLP, MLP, mrg_lora_ff2 ? (const bf16_t*)w->lora_ff2.B : (const bf16_t*)(txt ? w->w_ffc2 : w->w_ff2), MLP, MLP);
+      if (!txt && s.lora && w->lora_ff2.B && !w->lora_ff2.merged) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_ff2, HID + (int64_t)s.off * MLP, MLP, MLP, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_ff2.B, w->lora_ff2.r_pad, w->lora_ff2.r_pad);
@@ -406,8 +409,9 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
         g.a_scale = sXN + s.off; g.w_scale = w->q_qkv_mlp.scale;
         return RF_OK;
       }
-      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, w->w_qkv_mlp, D, D);
-      if (s.lora && w->lora_qkv_mlp.B) {
+      const bool mrg_lora_qkv_mlp = s.lora && w->lora_qkv_mlp.B && w->lora_qkv_mlp.merged;   // LoRA folded into a per-group weight copy (W + s B A)
+      set_seg(g.seg[0], XN + (int64_t)s.off * D, D, mrg_lora_qkv_mlp ? (const bf16_t*)w->lora_qkv_mlp.B : (const bf16_t*)(w->w_qkv_mlp), D, D);
+      if (s.lora && w->lora_qkv_mlp.B && !w->lora_qkv_mlp.merged) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_qkv_mlp, XN + (int64_t)s.off * D, D, D, nullptr, 0, 0, s.rows, T, ws, L, st));
         set_seg(g.seg[1], T, 256, w->lora_qkv_mlp.B, w->lora_qkv_mlp.r_pad, w->lora_qkv_mlp.r_pad);
@@ -442,9 +446,11 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
         g.a_scale = sA + s.off; g.w_scale = w->q_out.scale;
         return RF_OK;
       }
-      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, w->w_out, ldw, D);
-      set_seg(g.seg[1], HID + (int64_t)s.off * MLP, MLP, (const bf16_t*)w->w_out + D, ldw, MLP);
-      if (s.lora && w->lora_out.B) {
+      const bool mrg_out = s.lora && w->lora_out.B && w->lora_out.merged;   // LoRA folded into a per-group copy of proj_out
+      const bf16_t* w_out = mrg_out ? (const bf16_t*)w->lora_out.B : (const bf16_t*)w->w_out;
+      set_seg(g.seg[0], ATT + (int64_t)s.off * D, D, w_out, ldw, D);
+      set_seg(g.seg[1], HID + (int64_t)s.off * MLP, MLP, w_out + D, ldw, MLP);
+      if (s.lora && w->lora_out.B && !w->lora_out.merged) {
         bf16_t* T = LT + (int64_t)s.off * 256;
         RF_TRY(lora_down(w->lora_out, ATT + (int64_t)s.off * D, D, D, HID + (int64_t)s.off * MLP, MLP, MLP, s.rows, T, ws, L, st));
         set_seg(g.seg[2], T, 256, w->lora_out.B, w->lora_out.r_pad, w->lora_out.r_pad);
@@ -499,9 +505,10 @@ extern "C" int rf_flux_forward(const rf_flux_dims* dims, const rf_flux_model* m,
       rf_gemm_group& g = d.g[i];
       g.M = rows[i];
       if (rows[i] <= 0) continue;
-      set_seg(g.seg[0], src[i], m->in_ch, m->w_x_embed, m->in_ch, m->in_ch);
+      const bool mrg = lora[i] && m->lora_x_embed.B && m->lora_x_embed.merged;
+      set_seg(g.seg[0], src[i], m->in_ch, mrg ? m->lora_x_embed.B : m->w_x_embed, m->in_ch, m->in_ch);
       g.bias = m->b_x_embed; g.out = dst[i]; g.ldo = D;
-      if (lora[i] && m->lora_x_embed.B) {
+      if (lora[i] && m->lora_x_embed.B && !m->lora_x_embed.merged) {
         bf16_t* T = LT + (int64_t)(i == 0 ? St : St + Si) * 256;
         RF_TRY(lora_down(m->lora_x_embed, (const bf16_t*)src[i], m->in_ch, m->in_ch, nullptr, 0, 0, rows[i], T, ws, L, st));
         set_seg(g.seg[1], T, 256, m->lora_x_embed.B, m->lora_x_embed.r_pad, m->lora_x_embed.r_pad);

@@ -108,17 +108,27 @@ class _Packed:
         q, sc = ops.quantize_weight_fp8(weight)
         dst.w, dst.scale = self.k(q), self.k(sc)
 
-    def lora(self, seg: L.rf_lora_seg, linears):
+    def lora(self, seg: L.rf_lora_seg, linears, merge_into: Optional[torch.Tensor] = None):
+        """LoRA of the fused `linears`: the low-rank K-segment (A, s B), or -- merge_into = the fused base weight -- the MERGED
+        weight bf16(W + s B A) for the token groups LoRA acts on (rf_lora_seg.merged; no low-rank launches at run time)."""
         f = _fused_lora(linears)
         if f is not None:
             A, B, r_pad = f
-            seg.A, seg.B, seg.r_pad = self.k(A), self.k(B), r_pad
+            if merge_into is not None:
+                Wm = torch.addmm(merge_into.float(), B.float(), A.float()).to(merge_into.dtype)     # one rounding of the sum
+                seg.A, seg.B, seg.r_pad, seg.merged = None, self.k(Wm), 0, 1
+            else:
+                seg.A, seg.B, seg.r_pad, seg.merged = self.k(A), self.k(B), r_pad, 0
 
 
 def _require_device_bf16(p: torch.Tensor, what: str):
     if not p.is_cuda or p.dtype != torch.bfloat16:
         raise ops.RFError(f"{what}: weights must be bf16 on a HIP device (got {p.dtype} on {p.device}); "
                           "the HIP path has no CPU fallback")
+
+
+def _merged_lora(module) -> bool:
+    return bool(getattr(module, "_rf_merged_lora", False))
 
 
 def pack_double_block(b, refresh: bool = False, fp8: bool = False) -> _Packed:
@@ -145,9 +155,10 @@ def pack_double_block(b, refresh: bool = False, fp8: bool = False) -> _Packed:
     w.w_ff2, w.b_ff2 = pk.k(_base(b.ff.net[2]).weight), pk.k(_base(b.ff.net[2]).bias)
     w.w_ffc1, w.b_ffc1 = pk.k(b.ff_context.net[0].proj.weight), pk.k(b.ff_context.net[0].proj.bias)
     w.w_ffc2, w.b_ffc2 = pk.k(b.ff_context.net[2].weight), pk.k(b.ff_context.net[2].bias)
-    pk.lora(w.lora_qkv, qkv)
-    pk.lora(w.lora_out, [a.to_out[0]])
-    pk.lora(w.lora_ff2, [b.ff.net[2]])
+    mrg = _merged_lora(b)
+    pk.lora(w.lora_qkv, qkv, pk.by_ptr[w.w_qkv] if mrg else None)
+    pk.lora(w.lora_out, [a.to_out[0]], pk.by_ptr[w.w_out] if mrg else None)
+    pk.lora(w.lora_ff2, [b.ff.net[2]], pk.by_ptr[w.w_ff2] if mrg else None)
     # |score| bound from the norm weights alone: lets attention skip the online softmax (rf_attention_fwd score_bound)
     w.qk_bound = ops.qk_score_bound((a.norm_q.weight, a.norm_added_q.weight), (a.norm_k.weight, a.norm_added_k.weight))
     pk.fp8 = fp8
@@ -174,8 +185,9 @@ def pack_single_block(b, refresh: bool = False, fp8: bool = False) -> _Packed:
     w.b_qkv_mlp = pk.k(cat([_base(l).bias for l in fused], 0))
     w.norm_q, w.norm_k = pk.k(a.norm_q.weight), pk.k(a.norm_k.weight)
     w.w_out, w.b_out = pk.k(_base(b.proj_out).weight), pk.k(_base(b.proj_out).bias)
-    pk.lora(w.lora_qkv_mlp, fused)
-    pk.lora(w.lora_out, [b.proj_out])
+    mrg = _merged_lora(b)
+    pk.lora(w.lora_qkv_mlp, fused, pk.by_ptr[w.w_qkv_mlp] if mrg else None)
+    pk.lora(w.lora_out, [b.proj_out], pk.by_ptr[w.w_out] if mrg else None)
     w.qk_bound = ops.qk_score_bound((a.norm_q.weight,), (a.norm_k.weight,))
     pk.fp8 = fp8
     if fp8:
@@ -273,7 +285,7 @@ class FluxEngine:
         m.dbl = C.cast(self._dbl, C.POINTER(L.rf_double_block_weights))
         m.sgl = C.cast(self._sgl, C.POINTER(L.rf_single_block_weights))
         m.w_x_embed, m.b_x_embed = top.k(_base(tr.x_embedder).weight), top.k(_base(tr.x_embedder).bias)
-        top.lora(m.lora_x_embed, [tr.x_embedder])
+        top.lora(m.lora_x_embed, [tr.x_embedder], top.by_ptr[m.w_x_embed] if _merged_lora(tr) else None)
         m.w_ctx_embed, m.b_ctx_embed = top.k(tr.context_embedder.weight), top.k(tr.context_embedder.bias)
         m.w_proj_out, m.b_proj_out = top.k(tr.proj_out.weight), top.k(tr.proj_out.bias)
         m.in_ch, m.joint_dim = self.in_ch, tr.context_embedder.in_features
@@ -444,6 +456,17 @@ def engine_for(transformer) -> FluxEngine:
         eng = FluxEngine(transformer)
         object.__setattr__(transformer, "_rf_engine", eng)
     return eng
+
+
+def set_merged_lora(transformer, on: bool = True):
+    """Inference-time option (cfg4 / cfg5): fold every gated LoRA into a second copy of its weight, bf16(W + s B A), used by the token
+    groups LoRA acts on (condition rows; image rows too under latent_lora) -- the per-group K-segment form without its 2 launches per
+    LoRA'd linear (5.5 ms of an 83 ms cfg4 forward).  +11 GB for FLUX.1-dev; the sum is rounded to bf16 once (diffusers' fuse_lora
+    rounds the same way, but for ALL tokens, which would break the reference's enable_lora gating).  Call after load_lora_weights."""
+    object.__setattr__(transformer, "_rf_merged_lora", bool(on))
+    for b in list(transformer.transformer_blocks) + list(transformer.single_transformer_blocks):
+        object.__setattr__(b, "_rf_merged_lora", bool(on))
+    invalidate(transformer)
 
 
 def invalidate(transformer):

@@ -189,6 +189,11 @@ class FluxPipeline:
                                             HipClipTextEncoder(clip_state_dict, clip_heads, dev, eos_token_id=clip_eos_token_id, **clip_kw), tokenize)
         return self
 
+    def enable_merged_lora(self, on: bool = True):
+        """See engine.set_merged_lora: static LoRA folded into per-token-group weight copies (no low-rank launches per step)."""
+        E.set_merged_lora(self.transformer, on)
+        return self
+
     def set_progress_bar_config(self, **kw):
         self._progress = kw
 

@@ -49,6 +49,8 @@ class FluxTrainer:
         if self.cfg.get("add_cond_attn", False) or not self.cfg.get("union_cond_attn", True):
             raise ops.RFError("the training path covers the shipped training config (union_cond_attn: true, add_cond_attn: false)")
         E.check_lora_placement(transformer)
+        if getattr(transformer, "_rf_merged_lora", False):
+            raise ops.RFError("training needs the LoRA factors as factors: call pipe.enable_merged_lora(False) first")
         bad = [n for n, m in transformer.named_modules() if isinstance(m, LoraLinear) and
                (n.endswith("norm1_context.linear") or n.endswith("norm_out.linear"))]
         if bad:

@@ -91,3 +91,42 @@ def test_w4_token_groups_and_qkv_epilogue(dev):
     a, c = _both(run)
     assert torch.isfinite(c.float()).all() and float(c.float().abs().max()) > 0
     assert torch.equal(a, c)
+
+
+@torch.no_grad()
+def test_merged_lora_equals_k_segment_lora_within_bf16(dev):
+    """pipe.enable_merged_lora(): the condition rows multiply by bf16(W + s B A) instead of carrying the low-rank K-segment.  On the
+    fixture model (reference outputs in tests/golden/transformer_hd128.npz) both forms must meet the same bound against the
+    reference's fp32 output, the merged form may differ from the K-segment form only at bf16 level, and LoRA gating must survive
+    (without a condition and latent_lora = False the output is exactly the base model's)."""
+    from tests.golden_util import T, build, load
+    from tests.test_model_gpu import check, g, to_product, bf16_oracle
+    from oracle import flux_oracle as O
+    from reflectionflow_amd.flux.transformer import tranformer_forward
+    z = load("transformer_hd128")
+    om = build("hd128", lora=True)
+    pipe = to_product(om, dev)
+    kw = dict(hidden_states=g(T(z["lat"]), dev), encoder_hidden_states=g(T(z["pe"]), dev), pooled_projections=g(T(z["pooled"]), dev),
+              timestep=T(z["t"]).to(dev), guidance=T(z["g"]).to(dev), img_ids=T(z["img_ids"]).to(dev), txt_ids=T(z["txt_ids"]).to(dev),
+              joint_attention_kwargs=None, return_dict=False)
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    cond = dict(condition_latents=g(T(z["cond"]), dev), condition_ids=T(z["cond_ids"]).to(dev), condition_type_ids=None)
+    nocond = dict(condition_latents=None, condition_ids=None, condition_type_ids=None)
+    seg = tranformer_forward(pipe.transformer, model_config=cfg, **cond, **kw)[0]
+    base_nocond = tranformer_forward(pipe.transformer, model_config=cfg, **nocond, **kw)[0]
+    pipe.enable_merged_lora()
+    mrg = tranformer_forward(pipe.transformer, model_config=cfg, **cond, **kw)[0]
+    mrg_nocond = tranformer_forward(pipe.transformer, model_config=cfg, **nocond, **kw)[0]
+    ref = T(z["out_lora_cond_nolatlora"])
+    ob = bf16_oracle(om)
+    tb = O.tranformer_forward(ob, condition_latents=T(z["cond"]).to(BF), condition_ids=T(z["cond_ids"]), model_config=cfg,
+                              hidden_states=T(z["lat"]).to(BF), encoder_hidden_states=T(z["pe"]).to(BF), pooled_projections=T(z["pooled"]).to(BF),
+                              timestep=T(z["t"]), guidance=T(z["g"]), img_ids=T(z["img_ids"]), txt_ids=T(z["txt_ids"]))[0]
+    e_seg = check(seg, ref, tb, "K-segment LoRA")
+    e_mrg = check(mrg, ref, tb, "merged LoRA")
+    print(f"  rel-L2 vs the reference fp32 output: K-segment {e_seg[0]:.3e}, merged {e_mrg[0]:.3e}, torch-bf16 {e_seg[1]:.3e}")
+    assert float((mrg.float() - seg.float()).norm() / seg.float().norm()) < 1.5e-2
+    assert torch.equal(mrg_nocond, base_nocond), "without a condition the merged copies must not be touched"
+    assert not torch.equal(mrg, base_nocond)
+    pipe.enable_merged_lora(False)
+    assert torch.equal(tranformer_forward(pipe.transformer, model_config=cfg, **cond, **kw)[0], seg)

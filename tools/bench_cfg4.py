@@ -12,6 +12,9 @@ from reflectionflow_amd.tts.utils import get_noises
 dev = torch.device("cuda:0"); bf = torch.bfloat16
 pipe = bench.build_model(dev, {}, seed=0)
 pipe.load_lora_weights({k: v.to(dev) for k, v in synthetic_lora_state_dict(pipe.transformer, r=32, seed=1).items()}, adapter_name="reflection")
+MERGED = "--merged-lora" in sys.argv
+if MERGED:
+    pipe.enable_merged_lora()     # W + s B A copies for the condition rows: no low-rank launches per step
 g = torch.Generator().manual_seed(1)
 pe = torch.randn(1, 512, 4096, generator=g).to(dev).to(bf); pooled = torch.randn(1, 768, generator=g).to(dev).to(bf)
 cond_tokens = torch.randn(1, 1024, 64, generator=g).to(dev).to(bf)
@@ -23,7 +26,7 @@ def one(seed, T):
     return generate(pipe, conditions=[cond], model_config=mc, default_lora=True, height=1024, width=1024, num_inference_steps=T,
                     guidance_scale=3.5, latents=noises[seed], prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent").images
 res = {}
-for T in (50, 28):
+for T in ((20,) if "--quick" in sys.argv else (50, 28)):
     o = one(1, T); torch.cuda.synchronize()
     t0 = time.perf_counter(); outs = [one(s, T) for s in (2, 3)]; torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
     assert all(torch.isfinite(x.float()).all() for x in outs)
@@ -38,4 +41,5 @@ for k, v in pr.classes.items():
     if k not in ("rowop", "quant"):
         cl[k]["tflops"] = round(v["work"] / (v["us"] * 1e-6) / 1e12, 1)
 res["classes_T4_profile"] = cl
-print(json.dumps({"workload": "cfg4-shaped: 1024^2 + 512^2 condition, LoRA r=32 on condition rows, S=5632, 94.95 TFLOP/forward (SURVEY 8d)", **res}))
+print(json.dumps({"workload": "cfg4-shaped: 1024^2 + 512^2 condition, LoRA r=32 on condition rows, S=5632, 94.95 TFLOP/forward (SURVEY 8d)",
+                  "lora": "merged per-group weight copies (pipe.enable_merged_lora())" if MERGED else "K-segments (x A^T as its own launches)", **res}))

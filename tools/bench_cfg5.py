@@ -20,11 +20,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=10, help="Euler steps per timed latent (per-step cost is step-invariant)")
 ap.add_argument("--res", type=int, default=2048)
 ap.add_argument("--w8", action="store_true")
+ap.add_argument("--merged-lora", action="store_true", help="pipe.enable_merged_lora(): LoRA folded into per-group weight copies")
 ap.add_argument("--no-cond", action="store_true", help="no condition image (with --res 1024 this is cfg2's S = 4608)")
 args = ap.parse_args()
 dev = torch.device("cuda:0"); bf = torch.bfloat16
 pipe = bench.build_model(dev, {}, seed=0)
 pipe.load_lora_weights({k: v.to(dev) for k, v in synthetic_lora_state_dict(pipe.transformer, r=32, seed=1).items()}, adapter_name="reflection")
+if args.merged_lora:
+    pipe.enable_merged_lora()
 if args.w8:
     pipe.enable_fp8_weights()
 g = torch.Generator().manual_seed(1)
