@@ -9,6 +9,8 @@
 // Deterministic, no atomics: two kernels, each accumulating its outputs in registers over a loop --
 //   attn_bwd_dq_kernel   one workgroup per 64 queries (a wave owns 16): pass 1 streams the keys once for the row statistics
 //                        lse2 (online max / sum; the forward kernels do not emit them), pass 2 streams them again for dq~;
+//   (both loops double-buffer their LDS stage: the global loads of step s+1 are issued before step s multiplies and committed to
+//   the other buffer after it -- one barrier per step)
 //   attn_bwd_dkv_kernel  one workgroup per 64 * KT keys (a wave owns KT tiles of 16), streams the queries for dK, dV.
 // All five products run on v_mfma_f32_16x16x32_bf16.  A 16x16 score tile leaves a lane with 4 rows of ONE column, so two
 // tiles give the 8 contraction slots of the next MFMA's operand without any data movement, provided the other operand is
@@ -27,23 +29,35 @@ constexpr float LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int slot32(int n) { return 8 * ((n & 15) >> 2) + 4 * (n >> 4) + (n & 3); }
 
-// 256 threads copy a [32][128] bf16 row tile (global row pitch ld elements, rows >= rows_valid read as zero) into the swizzled image
-__device__ __forceinline__ void stage_rows(char* dst, const bf16_t* src, int64_t ld, int rows_valid, int tid) {
+// NT threads move a [32][128] bf16 row tile (global row pitch ld elements, rows >= rows_valid read as zero) or a transposed tile
+// (8 KiB contiguous) in two halves, so that the global loads of step s+1 are in flight while step s multiplies: FETCH into
+// registers (512 / NT chunks of 16 bytes per thread) ... and COMMIT them to the LDS image afterwards (row tiles swizzled).
+template <int NT>
+__device__ __forceinline__ void fetch_rows(u32x4 (&r)[512 / NT], const bf16_t* src, int64_t ld, int rows_valid, int tid) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int idx = tid + 256 * p, r = idx >> 4, c = idx & 15;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (r < rows_valid) v = *(const u32x4*)(src + (int64_t)r * ld + c * 8);
-    *(u32x4*)(dst + r * 256 + ((c ^ (r & 15)) << 4)) = v;
+  for (int p = 0; p < 512 / NT; ++p) {
+    const int idx = tid + NT * p, row = idx >> 4, c = idx & 15;
+    r[p] = u32x4{0u, 0u, 0u, 0u};
+    if (row < rows_valid) r[p] = *(const u32x4*)(src + (int64_t)row * ld + c * 8);
   }
 }
-// ... and a transposed tile (8 KiB contiguous)
-__device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int tid) {
+template <int NT>
+__device__ __forceinline__ void fetch_tile(u32x4 (&r)[512 / NT], const bf16_t* src, int tid) {
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int idx = tid + 256 * p;
-    *(u32x4*)(dst + idx * 16) = *(const u32x4*)(src + idx * 8);
+  for (int p = 0; p < 512 / NT; ++p) r[p] = *(const u32x4*)(src + (tid + NT * p) * 8);
+}
+template <int NT>
+__device__ __forceinline__ void commit_rows(char* dst, const u32x4 (&r)[512 / NT], int tid) {
+#pragma unroll
+  for (int p = 0; p < 512 / NT; ++p) {
+    const int idx = tid + NT * p, row = idx >> 4, c = idx & 15;
+    *(u32x4*)(dst + row * 256 + ((c ^ (row & 15)) << 4)) = r[p];
   }
+}
+template <int NT>
+__device__ __forceinline__ void commit_tile(char* dst, const u32x4 (&r)[512 / NT], int tid) {
+#pragma unroll
+  for (int p = 0; p < 512 / NT; ++p) *(u32x4*)(dst + (tid + NT * p) * 16) = r[p];
 }
 // A/B fragment of a swizzled row tile: lane (g, i) <- row 16 t + i, elements 32 ks + 8 g .. + 7
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int t, int ks, int l15, int g) {
@@ -104,110 +118,173 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 }
 
 // ---- dq~ (and the row statistics) -------------------------------------------------------------------------------------------
-// grid (s_pad / 64, heads), 256 threads.  LDS: K rows | V rows | K^T tile of the current 32 keys.
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+// grid (ceil(s_pad / (128 QT)), heads), 512 threads: 8 waves, a wave owns QT tiles of 16 queries, so a workgroup multiplies every
+// staged key step (K rows | V rows | K^T tile, 24 KiB) against 128 QT queries -- the loop is L2 -> LDS bandwidth bound (each
+// workgroup streams the head's whole K, V, K^T), and FLOPs per staged byte scale with the queries per workgroup.
+template <int QT>
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt,
                                                           const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ dsum,
                                                           float* __restrict__ lse, bf16_t* __restrict__ dq, int S, int s_pad) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * AB_ROWS];
-  char* const kl = smem;
-  char* const vl = smem + AB_ROWS;
-  char* const ktl = smem + 2 * AB_ROWS;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * AB_ROWS];     // two buffers of {K rows | V rows | K^T tile}
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int head = blockIdx.y;
-  const int qrow = blockIdx.x * 64 + w * 16 + l15;            // this lane's query (as a COLUMN of the S^T tiles)
   const int64_t hb = (int64_t)head * s_pad;
-  bf16x8 qf[4], dof[4];
+  int qrow[QT];                                               // this lane's queries (COLUMNS of the S^T tiles)
+  bf16x8 qf[QT][4], dof[QT][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    qf[ks] = *(const bf16x8*)(q + (hb + qrow) * 128 + 32 * ks + 8 * g);
-    u32x4 z = {0u, 0u, 0u, 0u};
-    if (qrow < S) z = *(const u32x4*)(dout + (int64_t)qrow * lddo + head * 128 + 32 * ks + 8 * g);
-    dof[ks] = __builtin_bit_cast(bf16x8, z);
+  for (int t = 0; t < QT; ++t) {
+    qrow[t] = blockIdx.x * (128 * QT) + w * (16 * QT) + 16 * t + l15;
+    const int qr = qrow[t] < s_pad ? qrow[t] : s_pad - 1;     // (a partial last workgroup: those lanes are not written)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[t][ks] = *(const bf16x8*)(q + (hb + qr) * 128 + 32 * ks + 8 * g);
+      u32x4 z = {0u, 0u, 0u, 0u};
+      if (qrow[t] < S) z = *(const u32x4*)(dout + (int64_t)qrow[t] * lddo + head * 128 + 32 * ks + 8 * g);
+      dof[t][ks] = __builtin_bit_cast(bf16x8, z);
+    }
   }
   const int nsteps = (S + 31) >> 5;
   const float NEG = -__builtin_huge_valf();
 
-  // pass 1: lse2 of this lane's query over all keys (each lane sees keys 4 g + r (+16) of every step; merged over g at the end)
-  float m = NEG, l = 0.f;
+  // pass 1: lse2 of this lane's queries over all keys (each lane sees keys 4 g + r (+16) of every step; merged over g at the end)
+  float m[QT], l[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) m[t] = NEG, l[t] = 0.f;
+  u32x4 rk[1], rv[1], rt[1];
+  fetch_rows<512>(rk, k + hb * 128, 128, 32, tid);
+  commit_rows<512>(smem, rk, tid);
+  __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    __syncthreads();
-    stage_rows(kl, k + (hb + st * 32) * 128, 128, 32, tid);
-    __syncthreads();
-    f32x4 s[2];
+    const char* kl = smem + (st & 1) * 3 * AB_ROWS;
+    const bool more = st + 1 < nsteps;
+    if (more) fetch_rows<512>(rk, k + (hb + (st + 1) * 32) * 128, 128, 32, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 kfr[2][4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[t] = mfma16(frag_rows(kl, t, ks, l15, g), qf[ks], s[t]);
-    }
-    float mx = m;
+      for (int ks = 0; ks < 4; ++ks) kfr[t2][ks] = frag_rows(kl, t2, ks, l15, g);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < QT; ++t) {
+      f32x4 s[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (st * 32 + 16 * t + 4 * g + r >= S) s[t][r] = NEG;
-        mx = fmaxf(mx, s[t][r]);
+      for (int t2 = 0; t2 < 2; ++t2) {
+        s[t2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s[t2] = mfma16(kfr[t2][ks], qf[t][ks], s[t2]);
       }
-    if (mx > NEG) {
-      float add = 0.f;
+      float mx = m[t];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) add += __builtin_amdgcn_exp2f(s[t][r] - mx);
-      l = l * __builtin_amdgcn_exp2f(m - mx) + add;     // m = -inf, l = 0 on the first contribution: exp2(-inf) = 0
-      m = mx;
+        for (int r = 0; r < 4; ++r) {
+          if (st * 32 + 16 * t2 + 4 * g + r >= S) s[t2][r] = NEG;
+          mx = fmaxf(mx, s[t2][r]);
+        }
+      if (mx > NEG) {
+        float add = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) add += __builtin_amdgcn_exp2f(s[t2][r] - mx);
+        l[t] = l[t] * __builtin_amdgcn_exp2f(m[t] - mx) + add;     // m = -inf, l = 0 on the first contribution: exp2(-inf) = 0
+        m[t] = mx;
+      }
     }
+    if (more) commit_rows<512>(smem + ((st + 1) & 1) * 3 * AB_ROWS, rk, tid);
+    __syncthreads();
   }
+  float my_lse[QT], my_d[QT];
 #pragma unroll
-  for (int o = 16; o <= 32; o <<= 1) {
-    const float m2 = __shfl_xor(m, o), l2 = __shfl_xor(l, o);
-    const float mn = fmaxf(m, m2);
-    if (mn > NEG) l = l * __builtin_amdgcn_exp2f(m - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
-    m = mn;
+  for (int t = 0; t < QT; ++t) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float m2 = __shfl_xor(m[t], o), l2 = __shfl_xor(l[t], o);
+      const float mn = fmaxf(m[t], m2);
+      if (mn > NEG) l[t] = l[t] * __builtin_amdgcn_exp2f(m[t] - mn) + l2 * __builtin_amdgcn_exp2f(m2 - mn);
+      m[t] = mn;
+    }
+    // padded queries: lse = +huge makes every P of that row exactly 0 in the dK / dV kernel
+    my_lse[t] = (qrow[t] < S && l[t] > 0.f) ? m[t] + __builtin_amdgcn_logf(l[t]) : 1e30f;
+    if (g == 0 && qrow[t] < s_pad) lse[hb + qrow[t]] = my_lse[t];
+    my_d[t] = qrow[t] < s_pad ? dsum[hb + qrow[t]] : 0.f;
   }
-  // padded queries: lse = +huge makes every P of that row exactly 0 in the dK / dV kernel
-  const float my_lse = (qrow < S && l > 0.f) ? m + __builtin_amdgcn_logf(l) : 1e30f;
-  if (g == 0) lse[hb + qrow] = my_lse;
-  const float my_d = dsum[hb + qrow];
 
   // pass 2: dq~^T[d][q] += K^T[d][key slots] g^T[key slots][q]
-  f32x4 acc[8];
+  f32x4 acc[QT][8];
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch2 = [&](const int st) {
+    fetch_rows<512>(rk, k + (hb + st * 32) * 128, 128, 32, tid);
+    fetch_rows<512>(rv, v + (hb + st * 32) * 128, 128, 32, tid);
+    fetch_tile<512>(rt, kt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+  };
+  auto commit2 = [&](char* buf) {
+    commit_rows<512>(buf, rk, tid);
+    commit_rows<512>(buf + AB_ROWS, rv, tid);
+    commit_tile<512>(buf + 2 * AB_ROWS, rt, tid);
+  };
+  fetch2(0);
+  commit2(smem);
+  __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    __syncthreads();
-    stage_rows(kl, k + (hb + st * 32) * 128, 128, 32, tid);
-    stage_rows(vl, v + (hb + st * 32) * 128, 128, 32, tid);
-    stage_tile(ktl, kt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
-    __syncthreads();
-    float gv[8];
+    const char* kl = smem + (st & 1) * 3 * AB_ROWS;
+    const char* vl = kl + AB_ROWS;
+    const char* ktl = kl + 2 * AB_ROWS;
+    const bool more = st + 1 < nsteps;
+    if (more) fetch2(st + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t gw[QT][4];                                  // the 8-slot g operand of each query tile, as packed bf16 pairs
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+    for (int t2 = 0; t2 < 2; ++t2) {
+      bf16x8 kfr[4], vfr[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = mfma16(frag_rows(kl, t, ks, l15, g), qf[ks], s);
-        dp = mfma16(frag_rows(vl, t, ks, l15, g), dof[ks], dp);
-      }
+      for (int ks = 0; ks < 4; ++ks) kfr[ks] = frag_rows(kl, t2, ks, l15, g), vfr[ks] = frag_rows(vl, t2, ks, l15, g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool ok = st * 32 + 16 * t + 4 * g + r < S;
-        const float p = ok ? __builtin_amdgcn_exp2f(s[r] - my_lse) : 0.f;
-        gv[4 * t + r] = LN2 * p * (dp[r] - my_d);
+      for (int t = 0; t < QT; ++t) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma16(kfr[ks], qf[t][ks], s);
+          dp = mfma16(vfr[ks], dof[t][ks], dp);
+        }
+        float gv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = st * 32 + 16 * t2 + 4 * g + r < S;
+          const float p = ok ? __builtin_amdgcn_exp2f(s[r] - my_lse[t]) : 0.f;
+          gv[r] = LN2 * p * (dp[r] - my_d[t]);
+        }
+        gw[t][2 * t2] = pack2(gv[0], gv[1]);            // slots 4 t2 .. 4 t2 + 3 of this lane group
+        gw[t][2 * t2 + 1] = pack2(gv[2], gv[3]);
       }
     }
-    const bf16x8 gf = __builtin_bit_cast(bf16x8, pack8(gv));
+    bf16x8 gf[QT];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) acc[dt] = mfma16(frag_tile(ktl, dt, l15, g), gf, acc[dt]);
+    for (int t = 0; t < QT; ++t) gf[t] = __builtin_bit_cast(bf16x8, u32x4{gw[t][0], gw[t][1], gw[t][2], gw[t][3]});
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const bf16x8 a_k = frag_tile(ktl, dt, l15, g);
+#pragma unroll
+      for (int t = 0; t < QT; ++t) acc[t][dt] = mfma16(a_k, gf[t], acc[t][dt]);
+    }
+    if (more) commit2(smem + ((st + 1) & 1) * 3 * AB_ROWS);
+    __syncthreads();
   }
-  bf16_t* drow = dq + (hb + qrow) * 128 + 4 * g;      // padded rows are written too (zeros: their dO and D are zero)
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) {
-    u32x2 o;
-    o[0] = pack2(acc[dt][0], acc[dt][1]);
-    o[1] = pack2(acc[dt][2], acc[dt][3]);
-    *(u32x2*)(drow + 16 * dt) = o;
+  for (int t = 0; t < QT; ++t) {
+    if (qrow[t] >= s_pad) continue;
+    bf16_t* drow = dq + (hb + qrow[t]) * 128 + 4 * g;      // padded rows are written too (zeros: their dO and D are zero)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      u32x2 o;
+      o[0] = pack2(acc[t][dt][0], acc[t][dt][1]);
+      o[1] = pack2(acc[t][dt][2], acc[t][dt][3]);
+      *(u32x2*)(drow + 16 * dt) = o;
+    }
   }
 }
 
@@ -220,12 +297,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ dout, int64_t lddo, const bf16_t* __restrict__ dot,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int s_pad) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * AB_ROWS + 256];
-  char* const ql = smem;
-  char* const dol = smem + AB_ROWS;
-  char* const qtl = smem + 2 * AB_ROWS;
-  char* const dotl = smem + 3 * AB_ROWS;
-  float* const stat = (float*)(smem + 4 * AB_ROWS);     // lse[32] | D[32]
+  constexpr int BUF = 4 * AB_ROWS + 256;                 // q~ rows | dO rows | q~^T tile | dO^T tile | lse[32] | D[32]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF = 66 048 bytes: dynamic (beyond the 64 KiB static limit)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int head = blockIdx.y;
   const int64_t hb = (int64_t)head * s_pad;
@@ -247,15 +320,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) akv[kt_][dt] = f32x4{0.f, 0.f, 0.f, 0.f}, avv[kt_][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nsteps = (S + 31) >> 5;
-  for (int st = 0; st < nsteps; ++st) {
+  u32x4 r0[2], r1[2], r2[2], r3[2];
+  float rs = 0.f;
+  auto fetch = [&](const int st) {
     const int q0 = st * 32;
-    __syncthreads();
-    stage_rows(ql, q + (hb + q0) * 128, 128, 32, tid);
-    stage_rows(dol, dout + (int64_t)q0 * lddo + head * 128, lddo, S - q0, tid);
-    stage_tile(qtl, qt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
-    stage_tile(dotl, dot + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
-    if (tid < 64) stat[tid] = tid < 32 ? lse[hb + q0 + tid] : dsum[hb + q0 + tid - 32];
-    __syncthreads();
+    fetch_rows<256>(r0, q + (hb + q0) * 128, 128, 32, tid);
+    fetch_rows<256>(r1, dout + (int64_t)q0 * lddo + head * 128, lddo, S - q0, tid);
+    fetch_tile<256>(r2, qt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+    fetch_tile<256>(r3, dot + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+    if (tid < 64) rs = tid < 32 ? lse[hb + q0 + tid] : dsum[hb + q0 + tid - 32];
+  };
+  auto commit = [&](char* buf) {
+    commit_rows<256>(buf, r0, tid);
+    commit_rows<256>(buf + AB_ROWS, r1, tid);
+    commit_tile<256>(buf + 2 * AB_ROWS, r2, tid);
+    commit_tile<256>(buf + 3 * AB_ROWS, r3, tid);
+    if (tid < 64) ((float*)(buf + 4 * AB_ROWS))[tid] = rs;
+  };
+  fetch(0);
+  commit(smem);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const char* ql = smem + (st & 1) * BUF;
+    const char* dol = ql + AB_ROWS;
+    const char* qtl = ql + 2 * AB_ROWS;
+    const char* dotl = ql + 3 * AB_ROWS;
+    const float* stat = (const float*)(ql + 4 * AB_ROWS);
+    const bool more = st + 1 < nsteps;
+    if (more) fetch(st + 1);                              // in flight while this step multiplies
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 lv[2], dvv[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -293,6 +386,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         akv[kt_][dt] = mfma16(a_q, gf[kt_], akv[kt_][dt]);                   // dK^T[d][key] += q~^T[d][q slots] g[q slots][key]
       }
     }
+    if (more) commit(smem + ((st + 1) & 1) * BUF);
+    __syncthreads();
   }
 #pragma unroll
   for (int kt_ = 0; kt_ < KT; ++kt_) {
@@ -337,12 +432,19 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(sp / 32, H), dim3(256), 0, st, (const bf16_t*)d->o, d->ldo, (const bf16_t*)d->dout,
                      d->lddo, (bf16_t*)d->dot, d->dsum, S, sp);
   RF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(sp / 64, H), dim3(256), 0, st, (const bf16_t*)d->q, (const bf16_t*)d->k,
+  constexpr int QT = 2;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<QT>, dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), 0, st, (const bf16_t*)d->q, (const bf16_t*)d->k,
                      (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo, (const float*)d->dsum, d->lse,
                      (bf16_t*)d->dq, S, sp);
   RF_LAUNCH_CHECK();
-  constexpr int KT = 2;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<KT>, dim3((sp + 64 * KT - 1) / (64 * KT), H), dim3(256), 0, st, (const bf16_t*)d->q,
+  constexpr int KT = 3;
+  constexpr int DKV_LDS = 2 * (4 * AB_ROWS + 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<KT>, dim3((sp + 64 * KT - 1) / (64 * KT), H), dim3(256), DKV_LDS, st, (const bf16_t*)d->q,
                      (const bf16_t*)d->qt, (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->dout, d->lddo,
                      (const bf16_t*)d->dot, (const float*)d->lse, (const float*)d->dsum, (bf16_t*)d->dk, (bf16_t*)d->dv, S, sp);
   RF_LAUNCH_CHECK();

@@ -260,15 +260,33 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restric
   }
 }
 
-// out[c] = sum_w partials[w][c], w in index order; `cols` columns (2 D for the LayerNorm kernel, D for the gate kernel)
+// out[c] = sum_w partials[w][c] in a FIXED order: a block owns 64 columns; thread (c, j) adds the partial rows j, j + 4, j + 8, ... with
+// four independent accumulators (the loads of a column are independent: the loop is latency-, not dependency-bound), then the four
+// j-sums are combined as ((j0 + j1) + (j2 + j3)).  `cols` columns (2 D for the LayerNorm kernel, D for the gate kernel).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partials, int nw, int cols, float* __restrict__ out0,
                                                             float* __restrict__ out1, int split) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int w = 0; w < nw; ++w) s += partials[(int64_t)w * cols + c];
-  if (c < split) out0[c] = s;
-  else out1[c - split] = s;
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), j = threadIdx.x >> 6;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    const float* p = partials + c;
+    int w = j;
+    for (; w + 12 < nw; w += 16) {
+      a0 += p[(int64_t)w * cols];
+      a1 += p[(int64_t)(w + 4) * cols];
+      a2 += p[(int64_t)(w + 8) * cols];
+      a3 += p[(int64_t)(w + 12) * cols];
+    }
+    for (; w < nw; w += 4) a0 += p[(int64_t)w * cols];
+  }
+  part[j][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (j == 0 && c < cols) {
+    const int t = threadIdx.x;
+    const float s = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+    if (c < split) out0[c] = s;
+    else out1[c - split] = s;
+  }
 }
 
 // ---- gated residual, backward ------------------------------------------------------------------------------------------------------
@@ -453,7 +471,7 @@ extern "C" int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void*
   else RF_LNB(6);
 #undef RF_LNB
   RF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(2 * D, 256)), dim3(256), 0, st, (const float*)partials, nw, 2 * D, d_shift, d_scale, D);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, st, (const float*)partials, nw, 2 * D, d_shift, d_scale, D);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
@@ -478,7 +496,7 @@ extern "C" int rf_gate_bwd(const void* dy, int64_t lddy, const void* f, int64_t 
   else RF_GB(6);
 #undef RF_GB
   RF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 256)), dim3(256), 0, st, (const float*)partials, nw, D, d_gate, d_gate, D);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, (const float*)partials, nw, D, d_gate, d_gate, D);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
