@@ -66,11 +66,14 @@ def test_w4_k_segments_and_epilogues(dev, Ks):
     assert torch.equal(a, c)
 
 
-def test_w4_token_groups_and_qkv_epilogue(dev):
-    """Three token groups (text / image / condition) with a LoRA K-segment on the last, through the fused QKV + RMSNorm + RoPE epilogue."""
+@pytest.mark.parametrize("H", [2, 1, 3])
+def test_w4_token_groups_and_qkv_epilogue(dev, H):
+    """Three token groups (text / image / condition) with a LoRA K-segment on the last, through the fused QKV + RMSNorm + RoPE epilogue.
+    H = 1, 3: q|k and v|out-of-range strips share a 256-column block, so the 8-wave kernel runs its swapped (register-direct epilogue)
+    and natural (V^T) wave orientations side by side in one workgroup."""
     from oracle import flux_oracle as O
     from reflectionflow_amd import ops
-    H, D = 2, 256
+    D = 128 * H
     St, Si, Sc = 40, 300, 70
     S = St + Si + Sc
     xs = [rnd(m, D, dev=dev, seed=10 + i) for i, m in enumerate((St, Si, Sc))]
