@@ -18,6 +18,9 @@ ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--cond", type=int, default=512)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--rank", type=int, default=32)
+ap.add_argument("--layers", type=int, default=1, help="DoubleStream blocks (FLUX.1-dev: 19)")
+ap.add_argument("--single-layers", type=int, default=1, help="SingleStream blocks (FLUX.1-dev: 38)")
+ap.add_argument("--optimizer", action="store_true", help="time an AdamW update of the LoRA factors inside the step (train/model.py:105-139)")
 args = ap.parse_args()
 
 from reflectionflow_amd import ops                                   # noqa: E402
@@ -30,7 +33,7 @@ BF = torch.bfloat16
 old = torch.get_default_dtype()
 torch.set_default_dtype(BF)
 with torch.device(dev):
-    tr = M.FluxTransformer2DModel(num_layers=1, num_single_layers=1)
+    tr = M.FluxTransformer2DModel(num_layers=args.layers, num_single_layers=args.single_layers)
 torch.set_default_dtype(old)
 M.init_synthetic_(tr, seed=0)
 pipe = FluxPipeline(tr)
@@ -53,6 +56,7 @@ batch = dict(x_0=r(1, Si, 64), img_ids=ids(gh), prompt_embeds=r(1, St, 4096), po
              condition_latents=r(1, Sc, 64), condition_ids=cond_ids, t=torch.tensor([0.5], device=dev), x_1=r(1, Si, 64))
 trainer = FluxTrainer(tr, {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False})
 params = lora_parameters(tr)
+opt = torch.optim.AdamW(params, lr=1e-4, fused=True) if args.optimizer else None
 
 
 def step():
@@ -60,6 +64,8 @@ def step():
         p.grad = None
     loss = trainer.step(batch)
     loss.backward()
+    if opt is not None:
+        opt.step()
     return loss
 
 
@@ -73,15 +79,17 @@ for _ in range(args.iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / args.iters
-with ops.profile(max_launches=4000) as pr:
+with ops.profile(max_launches=min(24000, 2000 * (args.layers + args.single_layers))) as pr:
     step()
     torch.cuda.synchronize()
-gemm_f = S * (2 * D * 3 * D + 2 * D * D + 2 * 2 * D * mlp) + S * (2 * D * (3 * D + mlp) + 2 * (D + mlp) * D)
-att_f = 2 * 4 * S * S * D
+nd, ns = args.layers, args.single_layers
+gemm_f = nd * S * (2 * D * 3 * D + 2 * D * D + 2 * 2 * D * mlp) + ns * S * (2 * D * (3 * D + mlp) + 2 * (D + mlp) * D)
+att_f = (nd + ns) * 4 * S * S * D
 F_, B_ = gemm_f + att_f, gemm_f + 2.5 * att_f
 cl = pr.classes
-res = {"workload": f"1 DoubleStream + 1 SingleStream block, D=3072, S = {St} text + {Si} image + {Sc} condition = {S}, LoRA r = {args.rank} on the condition rows",
-       "ms_per_step_fwd_bwd": round(ms, 3), "loss": float(loss),
+res = {"workload": f"{nd} DoubleStream + {ns} SingleStream blocks, D=3072, S = {St} text + {Si} image + {Sc} condition = {S}, LoRA r = {args.rank} on the condition rows",
+       "ms_per_step_fwd_bwd": round(ms, 3), "optimizer_in_step": "AdamW (fused) on the LoRA factors" if opt is not None else None,
+       "lora_parameters": sum(p.numel() for p in params), "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2), "loss": float(loss),
        "tflop": {"forward": round(F_ / 1e12, 3), "backward": round(B_ / 1e12, 3), "executed_with_recompute": round((2 * F_ + B_) / 1e12, 3)},
        "tflops_executed": round((2 * F_ + B_) / ms / 1e9, 1), "tflops_model": round((F_ + B_) / ms / 1e9, 1),
        "frac_of_bf16_mfma_peak_executed": round((2 * F_ + B_) / ms / 1e9 / 2500.0, 4),
