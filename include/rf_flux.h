@@ -35,7 +35,7 @@ typedef enum rf_status {
 } rf_status;
 
 const char* rf_last_error(void);
-/* ABI version: bump on any struct/signature change (v11: rf_lora_seg.merged, rf_gemm_desc.clock_probe, RF_SCHED_W4). */
+/* ABI version: bump on any struct/signature change (v12: rf_attn_desc.lse, rf_attn_bwd_desc.lse_given). */
 int rf_abi_version(void);
 /* Returns 950 when the library was compiled for gfx950. */
 int rf_target_arch(void);
@@ -220,6 +220,9 @@ typedef struct rf_attn_desc {
                                          other S / 256 - 3 b / 4 workgroups of a head take 256 queries); 0 = sized by the
                                          library for the device's CU count (S = 4608 x 24 heads on 256 CUs: 12) */
   void* ws; int64_t ws_bytes;         /* optional scratch, see rf_attention_fwd_ws */
+  float* lse;                         /* optional OUT [heads][s_pad] fp32 (rows < S written): log2 sum_k exp2(s2[q][k]) of every query
+                                         row, s2 = the scaled (and biased) scores in the exp2 domain -- the row statistic of the
+                                         backward (rf_attn_bwd_desc.lse with lse_given = 1).  NULL: not produced. */
 } rf_attn_desc;
 int rf_attention(const rf_attn_desc* d, void* stream);
 
@@ -516,6 +519,9 @@ typedef struct rf_attn_bwd_desc {
   void *dq, *dk, *dv;
   void* dot; float* lse; float* dsum;
   int32_t heads, S, s_pad, mode;
+  int32_t lse_given;   /* 1: lse[heads][s_pad] holds the forward's row statistics for rows < S (rf_attn_desc.lse of the SAME q, k): the
+                          dq kernel skips its own statistics pass over the keys (a quarter of its work).  0: lse is scratch. */
+  int32_t _pad;
 } rf_attn_bwd_desc;
 int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream);
 

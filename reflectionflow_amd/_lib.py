@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -51,13 +51,13 @@ class rf_attn_desc(C.Structure):
                 ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("n_main", C.c_int32),
                 ("ldo", C.c_int64), ("mode", C.c_int32), ("q_prescaled", C.c_int32),
                 ("cross_bias", C.c_float), ("scale", C.c_float), ("score_bound", C.c_float), ("lag_thresh", C.c_float),
-                ("kernel", C.c_int32), ("mix_small", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("kernel", C.c_int32), ("mix_small", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("lse", C.c_void_p)]
 
 
 class rf_attn_bwd_desc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "qt", "kt", "o", "dout")] + [("ldo", C.c_int64), ("lddo", C.c_int64)] + [
         (n, C.c_void_p) for n in ("dq", "dk", "dv", "dot", "lse", "dsum")] + [
-        ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("mode", C.c_int32)]
+        ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("mode", C.c_int32), ("lse_given", C.c_int32), ("_pad", C.c_int32)]
 
 
 class rf_w8(C.Structure):

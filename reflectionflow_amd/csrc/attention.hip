@@ -46,6 +46,8 @@ struct AttnParams {
   float sl2;            // softmax scale * log2(e)
   float lag_thresh;     // lagged-max kernels: a lane's 16-key row sum above this re-centres the row (default 2^30)
   int probe;            // block 0 stores its shader-clock probe (only while rf_profile_begin is open)
+  float* lse;           // optional [heads][s_pad] fp32: log2-sum-exp2 of each query's (scaled, biased) score row -- the row statistic
+                        // rf_attention_bwd needs (rf_attn_desc.lse); rows >= S are not written
 };
 
 constexpr int ATT_QBLK = 128;        // query rows per workgroup (4 waves x 32)
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   // ---- normalise and store: lane owns query q_row, d = db*32 + 8*rg + 4*h + (0..3) ----------
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
+  if (p.lse != nullptr && h == 0 && q_row < S) p.lse[(int64_t)head * p.s_pad + q_row] = m_run + __builtin_amdgcn_logf(l_tot);
   if (q_row < S) {
     bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * h;
 #pragma unroll
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v2(const AttnParams p) {
     l_tot = l_run + __uint_as_float(h ? sw[0] : sw[1]);
   }
   const float inv = 1.0f / l_tot;
+  if (p.lse != nullptr && h == 0 && q_row < S) p.lse[(int64_t)head * p.s_pad + q_row] = m_run + __builtin_amdgcn_logf(l_tot);
   if (q_row < S) {
     bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * h;
 #pragma unroll
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
     l_tot = l_run + __uint_as_float(h ? sw[0] : sw[1]);
   }
   const float inv = 1.0f / l_tot;
+  if (p.lse != nullptr && h == 0 && q_row < S) p.lse[(int64_t)head * p.s_pad + q_row] = __builtin_amdgcn_logf(l_tot);   // bounded form: m == 0
   if (q_row < S) {
     bf16_t* orow = p.out + (int64_t)q_row * p.ldo + head * 128 + 4 * h;
 #pragma unroll
@@ -752,7 +757,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel_v4(const AttnParams p) {
 // wave's first query row
 template <int NQT, bool NARROW = false>
 __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[8][NQT], float (&l_run)[NQT], const int lane, const int head,
-                                             const int q0w) {
+                                             const int q0w, const float (&m_row)[NQT]) {
   const int l15 = lane & 15, g = lane >> 4;
   const int S = p.S;
   const bool wide = !NARROW && (p.ldo & 7) == 0;   // 16-byte stores need 16-byte aligned rows
@@ -764,6 +769,8 @@ __device__ __forceinline__ void attn5_finish(const AttnParams& p, f32x4 (&oacc)[
     l_tot += __shfl_xor(l_tot, 32);
     const float inv = 1.0f / l_tot;
     const int q_row = q0w + qt * 16 + l15;
+    // the row statistic of the backward: P = exp2(s - m) summed to l  =>  log2-sum-exp2 = m + log2 l  (m = the lagged maximum, 0 in the bounded form)
+    if (p.lse != nullptr && g == 0 && q_row < S) p.lse[(int64_t)head * p.s_pad + q_row] = m_row[qt] + __builtin_amdgcn_logf(l_tot);
     if (wide) {
       // The store tail is store-ISSUE-bound (cdna_hip_programming.md T21): 4 x 16 bytes per lane and q-tile instead of 8 x 8.  A lane
       // holds d = 4g .. 4g+3 of every d tile; lane groups g and g ^ 1 trade so that the even group owns d = 8 (g >> 1) .. +7 of
@@ -1267,7 +1274,10 @@ __device__ __forceinline__ void attn5_body(const AttnParams& p, char* smem, cons
     partial[16 * 2048 + 1536 + tid] = -negm[1][0];
     return;
   }
-  attn5_finish<NQT, (VAR & 8) != 0>(p, oacc, l_run, lane, head, q0w);
+  float m_row[NQT];
+#pragma unroll
+  for (int qt = 0; qt < NQT; ++qt) m_row[qt] = -negm[qt][0];
+  attn5_finish<NQT, (VAR & 8) != 0>(p, oacc, l_run, lane, head, q0w, m_row);
 }
 
 // The variant the product kernels run (the VAR bits of attn5_body): 256 = wave priority scheme 2 -- s_setprio 2 in G (scores + packing),
@@ -1464,7 +1474,7 @@ __global__ __launch_bounds__(512) void attn5_combine_kernel(const AttnParams p, 
     l_run[0] += src[16 * 2048 + tid] * f[0];
     l_run[1] += src[16 * 2048 + 512 + tid] * f[1];
   }
-  attn5_finish<2>(p, oacc, l_run, lane, head, qb * 256 + w * 32);
+  attn5_finish<2>(p, oacc, l_run, lane, head, qb * 256 + w * 32, mmax);
 }
 
 int read_clk_probe_attn(unsigned long long* h) {
@@ -1576,6 +1586,7 @@ extern "C" int rf_attention(const rf_attn_desc* d, void* stream) {
   p.sl2 = d->scale * 1.4426950408889634f;
   p.lag_thresh = d->lag_thresh > 0.f ? d->lag_thresh : 1073741824.0f;   // 2^30
   p.probe = prof_open() ? 1 : 0;
+  p.lse = d->lse;
   hipStream_t st = (hipStream_t)stream;
   const bool pre = d->q_prescaled != 0;
   ProfScope prof(RF_KC_ATTN, 4.0 * (double)S * (double)S * 128.0 * heads, st);

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 // grid (ceil(s_pad / (128 QT)), heads), 512 threads: 8 waves, a wave owns QT tiles of 16 queries, so a workgroup multiplies every
 // staged key step (K rows | V rows | K^T tile, 24 KiB) against 128 QT queries -- the loop is L2 -> LDS bandwidth bound (each
 // workgroup streams the head's whole K, V, K^T), and FLOPs per staged byte scale with the queries per workgroup.
-template <int QT>
+// HAVE_LSE: the forward launch already wrote the row statistics (rf_attn_desc.lse): pass 1 is skipped.
+template <int QT, bool HAVE_LSE>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt,
                                                           const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ dsum,
@@ -147,11 +148,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int nsteps = (S + 31) >> 5;
   const float NEG = -__builtin_huge_valf();
 
+  u32x4 rk[1], rv[1], rt[1];
+  float my_lse[QT], my_d[QT];
+  if constexpr (HAVE_LSE) {
+    // padded queries: lse = +huge makes every P of that row exactly 0 here and in the dK / dV kernel (which reads all s_pad rows)
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      my_lse[t] = qrow[t] < S ? lse[hb + qrow[t]] : 1e30f;
+      if (g == 0 && qrow[t] >= S && qrow[t] < s_pad) lse[hb + qrow[t]] = 1e30f;
+      my_d[t] = qrow[t] < s_pad ? dsum[hb + qrow[t]] : 0.f;
+    }
+  } else {
   // pass 1: lse2 of this lane's queries over all keys (each lane sees keys 4 g + r (+16) of every step; merged over g at the end)
   float m[QT], l[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) m[t] = NEG, l[t] = 0.f;
-  u32x4 rk[1], rv[1], rt[1];
   fetch_rows<512>(rk, k + hb * 128, 128, 32, tid);
   commit_rows<512>(smem, rk, tid);
   __syncthreads();
@@ -195,7 +206,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
     if (more) commit_rows<512>(smem + ((st + 1) & 1) * 3 * AB_ROWS, rk, tid);
     __syncthreads();
   }
-  float my_lse[QT], my_d[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
 #pragma unroll
@@ -210,6 +220,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
     if (g == 0 && qrow[t] < s_pad) lse[hb + qrow[t]] = my_lse[t];
     my_d[t] = qrow[t] < s_pad ? dsum[hb + qrow[t]] : 0.f;
   }
+  }   // !HAVE_LSE
 
   // pass 2: dq~^T[d][q] += K^T[d][key slots] g^T[key slots][q]
   f32x4 acc[QT][8];
@@ -427,15 +438,21 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int S = d->S, sp = d->s_pad, H = d->heads;
   // algorithmic work = the 5 products of a flash backward (S, dP, dV, dK, dq~) x 2 S^2 128 per head = 2.5 x the forward's;
-  // this two-kernel, atomics-free form EXECUTES 8 (S three times: statistics, dq~ pass, dK / dV pass; dP twice)
+  // this two-kernel, atomics-free form EXECUTES 8 (S three times: statistics, dq~ pass, dK / dV pass; dP twice), 7 when the
+  // forward supplied the row statistics (lse_given)
   ProfScope ps(RF_KC_ATTN_BWD, 5.0 * 2.0 * (double)S * (double)S * 128.0 * (double)H, st);
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(sp / 32, H), dim3(256), 0, st, (const bf16_t*)d->o, d->ldo, (const bf16_t*)d->dout,
                      d->lddo, (bf16_t*)d->dot, d->dsum, S, sp);
   RF_LAUNCH_CHECK();
   constexpr int QT = 2;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<QT>, dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), 0, st, (const bf16_t*)d->q, (const bf16_t*)d->k,
-                     (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo, (const float*)d->dsum, d->lse,
-                     (bf16_t*)d->dq, S, sp);
+  if (d->lse_given)
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, true>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), 0, st, (const bf16_t*)d->q,
+                       (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,
+                       (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);
+  else
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, false>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), 0, st, (const bf16_t*)d->q,
+                       (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,
+                       (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);
   RF_LAUNCH_CHECK();
   constexpr int KT = 3;
   constexpr int DKV_LDS = 2 * (4 * AB_ROWS + 256);

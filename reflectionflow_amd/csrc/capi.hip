@@ -105,5 +105,5 @@ extern "C" int rf_profile_end(double* us_sum, int64_t* launches, double* work_su
 }
 
 extern "C" const char* rf_last_error(void) { return rf::g_err; }
-extern "C" int rf_abi_version(void) { return 11; }
+extern "C" int rf_abi_version(void) { return 12; }
 extern "C" int rf_target_arch(void) { return 950; }

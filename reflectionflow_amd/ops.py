@@ -336,8 +336,9 @@ def qk_score_bound(*norm_weights_qk) -> float:
 def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Optional[int] = None, mode: int = 0,
               cross_bias: float = 0.0, scale: Optional[float] = None, q_prescaled: bool = False,
               score_bound: float = 0.0, scratch: bool = True, kernel: Optional[int] = None, mix_small: int = 0,
-              lag_thresh: float = 0.0) -> torch.Tensor:
-    """scratch=True attaches the per-(device, stream) scratch that lets the library split a poorly filling grid
+              lag_thresh: float = 0.0, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """lse: optional fp32 [heads, s_pad] output -- log2-sum-exp2 of every query's score row (rows < S), the row statistic of
+    train.kernels.attention_bwd.  scratch=True attaches the per-(device, stream) scratch that lets the library split a poorly filling grid
     (rf_attention_fwd_ws); scratch=False is rf_attention_fwd.  kernel: rf_attn_kernel for THIS launch (an unrunnable
     request raises); lag_thresh: re-centring threshold of the lagged-max kernels (0 = 2^30)."""
     lib = L.load()
@@ -358,6 +359,11 @@ def attention(q, k, vt, S: int, out: Optional[torch.Tensor] = None, n_main: Opti
     d.score_bound, d.lag_thresh, d.kernel = float(score_bound), float(lag_thresh), _ATTN_KERNEL.get() if kernel is None else kernel
     d.mix_small = int(mix_small)
     d.ws, d.ws_bytes = ptr(ws), ws.numel() * 4 if ws is not None else 0
+    if lse is not None:
+        _chk(lse, "lse", torch.float32)
+        if lse.shape != (heads, s_pad) or not lse.is_contiguous():
+            raise RFError(f"attention: lse must be contiguous fp32 [{heads}, {s_pad}]")
+    d.lse = ptr(lse)
     L.check(lib.rf_attention(C.byref(d), stream_ptr()), "rf_attention")
     return out
 

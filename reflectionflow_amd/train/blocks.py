@@ -179,7 +179,9 @@ def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_im
     _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D, RAW, lora.get("qkv"), keep, "qkv")
     norms = (tw.w("norm_q"), tw.w("norm_k"), tw.w("norm_added_q"), tw.w("norm_added_k"))
     a = K.qkv_train_fwd(RAW, H, st[0].rows, norms, cos, sin)
-    ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0)
+    # (recompute inside the backward: the forward kernel also emits the row statistics its backward needs)
+    LSE = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev) if keep is not None else None
+    ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0, lse=LSE)
     AOUT = new(S, D)
     _grouped(st, ATT, [(tw,) + s.out for s in st], D, AOUT, lora.get("out"), keep, "out")
     X1, XN2 = new(S, D), new(S, D)
@@ -195,7 +197,7 @@ def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_im
     for s in st:
         K.gate_residual(FF[s.sl], s.mod[5], X1[s.sl], out=Y[s.sl])
     if keep is not None:
-        keep.update(st=st, XN=XN, RAW=RAW, a=a, ATT=ATT, AOUT=AOUT, X1=X1, XN2=XN2, Z1=Z1, HH=HH, FF=FF, norms=norms)
+        keep.update(st=st, XN=XN, RAW=RAW, a=a, ATT=ATT, LSE=LSE, AOUT=AOUT, X1=X1, XN2=XN2, Z1=Z1, HH=HH, FF=FF, norms=norms)
     return [Y[s.sl] for s in st]
 
 
@@ -243,7 +245,7 @@ def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     dTs, A = lora_of("out", kp["ATT"], DAO)
     DATT = new(S, D)
     _dx_grouped(st, DAO, [(tw, s.out[0], None) for s in st], D, DATT, dTs, A)
-    dq, dk, dv = K.attention_bwd(kp["a"], kp["ATT"], DATT)
+    dq, dk, dv = K.attention_bwd(kp["a"], kp["ATT"], DATT, lse=kp.get("LSE"))
     DRAW = new(S, 3 * D)
     K.qkv_train_bwd(kp["RAW"], H, st[0].rows, kp["norms"], cos, sin, dq, dk, dv, DRAW)
     dTs, A = lora_of("qkv", kp["XN"], DRAW)
@@ -303,7 +305,9 @@ def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, c
     _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D + mlp, Z, lora.get("qkv_mlp"), keep, "qkv_mlp")
     norms = (tw.w("norm_q"), tw.w("norm_k"), None, None)
     a = K.qkv_train_fwd(Z, H, 0, norms, cos, sin)
-    ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0)
+    # (recompute inside the backward: the forward kernel also emits the row statistics its backward needs)
+    LSE = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev) if keep is not None else None
+    ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0, lse=LSE)
     HM = K.gelu(Z[:, 3 * D:])
     FF = new(S, D)
     A_o, B_o = lora.get("out", (None, None))
@@ -323,7 +327,7 @@ def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, c
     for s in st:
         K.gate_residual(FF[s.sl], s.mod[2], s.x, out=Y[s.sl])
     if keep is not None:
-        keep.update(st=st, XN=XN, Z=Z, a=a, ATT=ATT, HM=HM, FF=FF, norms=norms)
+        keep.update(st=st, XN=XN, Z=Z, a=a, ATT=ATT, LSE=LSE, HM=HM, FF=FF, norms=norms)
     return [Y[s.sl] for s in st]
 
 
@@ -351,7 +355,7 @@ def single_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     _dx_grouped(st, DF, [(tw, "w_out", None) for _ in st], D + mlp, DCAT, dTs, A_o)
     DZ = new(S, 3 * D + mlp)
     K.gelu_bwd(kp["Z"][:, 3 * D:], DCAT[:, D:], out=DZ[:, 3 * D:])
-    dq, dk, dv = K.attention_bwd(kp["a"], kp["ATT"], DCAT[:, :D])
+    dq, dk, dv = K.attention_bwd(kp["a"], kp["ATT"], DCAT[:, :D], lse=kp.get("LSE"))
     K.qkv_train_bwd(kp["Z"], H, 0, kp["norms"], cos, sin, dq, dk, dv, DZ)
     A_q, B_q = lora.get("qkv_mlp", (None, None))
     dTs = {}

@@ -75,19 +75,27 @@ def qkv_train_bwd(raw: torch.Tensor, heads: int, n_added: int, norms, cos, sin, 
     return d_raw
 
 
-def attention_bwd(a: AttnOperands, o: torch.Tensor, dout: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(dq (w.r.t. the scaled q), dk, dv), each [heads, s_pad, 128] bf16."""
+def attention_bwd(a: AttnOperands, o: torch.Tensor, dout: torch.Tensor,
+                  lse: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dq (w.r.t. the scaled q), dk, dv), each [heads, s_pad, 128] bf16.  lse: the row statistics ops.attention(..., lse=) wrote for
+    the SAME operands ([heads, s_pad] fp32; rows >= S are filled in here) -- without it the dq kernel makes its own pass for them."""
     o, dout = _rows2d(o, "o"), _rows2d(dout, "dout")
     H, dev = a.q.shape[0], a.q.device
     dq, dk, dv = torch.empty_like(a.q), torch.empty_like(a.q), torch.empty_like(a.q)
     dot = torch.empty_like(a.qt)
-    lse = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev)
+    given = lse is not None
+    if given:
+        _chk(lse, "lse", torch.float32)
+        if lse.shape != (H, a.s_pad) or not lse.is_contiguous():
+            raise RFError(f"attention_bwd: lse must be contiguous fp32 [{H}, {a.s_pad}]")
+    else:
+        lse = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev)
     dsum = torch.empty_like(lse)
     d = L.rf_attn_bwd_desc()
     d.q, d.k, d.v, d.qt, d.kt = a.q.data_ptr(), a.k.data_ptr(), a.v.data_ptr(), a.qt.data_ptr(), a.kt.data_ptr()
     d.o, d.dout, d.ldo, d.lddo = o.data_ptr(), dout.data_ptr(), o.stride(0), dout.stride(0)
     d.dq, d.dk, d.dv, d.dot, d.lse, d.dsum = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dot.data_ptr(), lse.data_ptr(), dsum.data_ptr()
-    d.heads, d.S, d.s_pad, d.mode = H, a.S, a.s_pad, 0
+    d.heads, d.S, d.s_pad, d.mode, d.lse_given = H, a.S, a.s_pad, 0, 1 if given else 0
     L.check(L.load().rf_attention_bwd(C.byref(d), stream_ptr()), "rf_attention_bwd")
     return dq, dk, dv
 

@@ -155,6 +155,34 @@ def test_attention_bwd_vs_fp32_autograd(dev, H, S):
         assert float(dq[:, S:].abs().max()) == 0.0 and float(dk[:, S:].abs().max()) == 0.0 and float(dv[:, S:].abs().max()) == 0.0
     again = K.attention_bwd(a, out, dout)
     assert all(torch.equal(x, y) for x, y in zip((dq, dk, dv), again)), "the backward must be bit-reproducible (no atomics)"
+    # the forward's own row statistics (rf_attn_desc.lse) replace the dq kernel's statistics pass: every forward kernel the library
+    # may pick must write log2-sum-exp2 of the scaled score rows, and the gradients must meet the same bound
+    s2 = qf.detach().double() @ kf.detach().double().transpose(1, 2)
+    lse_ref = torch.logsumexp(s2 * LN2, -1) / LN2                                  # log2 sum_k 2^s2
+    from reflectionflow_amd import _lib as L
+    # (|s2| <= 128 * 0.128 here: the bounded kernels may run with score_bound = 100)
+    kernels = [(None, 0.0), (L.RF_ATTN_ONLINE128, 0.0), (L.RF_ATTN_ONLINE256, 0.0), (L.RF_ATTN_BOUNDED32, 100.0), (L.RF_ATTN_BOUNDED16, 100.0),
+               (L.RF_ATTN_BOUNDED16_SPLIT, 100.0), (L.RF_ATTN_LAGGED16, 0.0), (L.RF_ATTN_LAGGED16_SPLIT, 0.0), (L.RF_ATTN_BOUNDED16_MIX, 100.0),
+               (L.RF_ATTN_LAGGED16_MIX, 0.0)]
+    ran = 0
+    for kern, bound in kernels:
+        lse = torch.full((H, a.s_pad), float("nan"), dtype=torch.float32, device=dev)
+        try:
+            out2 = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, lse=lse, kernel=kern, score_bound=bound)
+        except ops.RFError:
+            continue                                                                # this kernel cannot run this shape
+        ran += 1
+        assert torch.equal(out2, out) or rel_l2(out2, out) < 2e-2
+        err = float((lse[:, :S].double() - lse_ref).abs().max())
+        print(f"  forward lse (kernel {kern}) H={H} S={S}: max |lse - ref| = {err:.2e} (log2 units)")
+        assert err < 2e-2
+        g2 = K.attention_bwd(a, out2, dout, lse=lse)
+        e2 = [rel_l2(g2[0][:, :S], qf.grad), rel_l2(g2[1][:, :S], kf.grad), rel_l2(g2[2][:, :S], vf.grad)]
+        assert max(e2) < 1.2e-2, e2
+        if a.s_pad > S:
+            assert all(float(t[:, S:].abs().max()) == 0.0 for t in g2)
+            assert bool((lse[:, S:] == 1e30).all()), "padded rows must be closed by the backward"
+    assert ran >= 2
 
 
 # ------------------------------------------------------------------------------------------------- the whole step
