@@ -76,6 +76,48 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 #endif
 }
 
+// ---- LDS-DMA staging (buffer_load_dwordx4 ... lds) ---------------------------------------------------------------------------------
+// A step of either loop multiplies for ~1 us against a staged tile set that takes longer than that to arrive from the L2, so one
+// step of lookahead through registers left every step waiting for its loads (2 us per step measured, both kernels).  The stages
+// are therefore a RING of AB_RING slots filled by LDS-DMA AB_RING - 1 steps ahead: no staging registers, and the only wait is
+// `vmcnt` down to the pieces of the NEWER stages.  A DMA instruction of a wave writes 1 KiB of LDS linearly (lane x 16 bytes), so
+// the XOR swizzle of the row tiles is applied on the global side: position (row, pc) receives chunk pc ^ (row & 15).
+constexpr int AB_RING = 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_MAKE_RSRC_N(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, (int)(bytes), 0x00020000)
+#define RF_BUF_LOAD_LDS4(r, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 4, voff, soff, 0, 0)
+#else
+#define RF_MAKE_RSRC_N(p, bytes) 0
+#define RF_BUF_LOAD_LDS4(r, lds, voff, soff) ((void)0)
+#endif
+// per-lane byte offsets of a wave's pieces of a row tile (row pitch in bytes) / of a transposed tile; piece i of wave w = 1 KiB
+// number i NW + w of the 8 KiB image
+template <int NW>
+__device__ __forceinline__ void dma_row_offsets(uint32_t (&off)[8 / NW], const uint32_t pitch, const int w, const int lane) {
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) {
+    const int row = 4 * (i * NW + w) + (lane >> 4);
+    off[i] = (uint32_t)row * pitch + (uint32_t)(((lane & 15) ^ (row & 15)) << 4);
+  }
+}
+template <int NW>
+__device__ __forceinline__ void dma_rows(const rsrc_t r, char* tile, const uint32_t (&off)[8 / NW], const uint32_t base, const int w) {
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) RF_BUF_LOAD_LDS(r, (lds_void*)(tile + (i * NW + w) * 1024), off[i], base);
+}
+template <int NW>
+__device__ __forceinline__ void dma_tile(const rsrc_t r, char* tile, const uint32_t base, const int w, const int lane) {
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) RF_BUF_LOAD_LDS(r, (lds_void*)(tile + (i * NW + w) * 1024), (uint32_t)((i * NW + w) * 1024 + lane * 16), base);
+}
+// wait until at most `later` NEWER stages of PER pieces each are still in flight (later <= AB_RING - 2)
+template <int PER>
+__device__ __forceinline__ void dma_wait(const int later) {
+  if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+  else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- prep: D = rowsum(dO o O), dO^T tiles -----------------------------------------------------------------------------------
 // grid (s_pad / 32, heads), 256 threads: 32 tokens x the head's 128 channels.
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ o, int64_t ldo, const bf16_t* __restrict__ dout,
@@ -127,7 +169,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt,
                                                           const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ dsum,
                                                           float* __restrict__ lse, bf16_t* __restrict__ dq, int S, int s_pad) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 3 * AB_ROWS];     // two buffers of {K rows | V rows | K^T tile}
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // AB_RING stages of {K rows | V rows | K^T tile} (98 304 bytes)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int head = blockIdx.y;
   const int64_t hb = (int64_t)head * s_pad;
@@ -148,7 +190,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int nsteps = (S + 31) >> 5;
   const float NEG = -__builtin_huge_valf();
 
-  u32x4 rk[1], rv[1], rt[1];
+  u32x4 rk[1];
   float my_lse[QT], my_d[QT];
   if constexpr (HAVE_LSE) {
     // padded queries: lse = +huge makes every P of that row exactly 0 here and in the dK / dV kernel (which reads all s_pad rows)
@@ -228,25 +270,34 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) acc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto fetch2 = [&](const int st) {
-    fetch_rows<512>(rk, k + (hb + st * 32) * 128, 128, 32, tid);
-    fetch_rows<512>(rv, v + (hb + st * 32) * 128, 128, 32, tid);
-    fetch_tile<512>(rt, kt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
+  // -lse2 and -D ride into the score / dP MFMA chains as their C operand (a lane's four accumulators are four KEYS of one query, so
+  // both are lane constants): P = exp2(chain), g / ln2 = P o chain' -- one exp2 and one multiply per element; ln 2 is applied once to
+  // the finished dq~.  Keys >= S exist only in the last step (zero K / V rows: they add nothing to dq~, but exp2(-lse2) of a row
+  // whose scores are all far below zero must not meet them as inf * 0): that step alone masks.
+  f32x4 negl[QT], negd[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) negl[t][r] = -my_lse[t], negd[t][r] = -my_d[t];
+  const rsrc_t r_k = RF_MAKE_RSRC_N(k, (int64_t)gridDim.y * s_pad * 256), r_v = RF_MAKE_RSRC_N(v, (int64_t)gridDim.y * s_pad * 256);
+  const rsrc_t r_kt = RF_MAKE_RSRC_N(kt, (int64_t)gridDim.y * s_pad * 256);
+  uint32_t off_r[1];
+  dma_row_offsets<8>(off_r, 256u, w, lane);
+  constexpr int PER = 3;                                    // DMA instructions per stage and wave
+  auto issue = [&](const int st) {
+    char* buf = smem + (st % AB_RING) * 3 * AB_ROWS;
+    dma_rows<8>(r_k, buf, off_r, (uint32_t)((hb + st * 32) * 256), w);
+    dma_rows<8>(r_v, buf + AB_ROWS, off_r, (uint32_t)((hb + st * 32) * 256), w);
+    dma_tile<8>(r_kt, buf + 2 * AB_ROWS, (uint32_t)(((int64_t)head * (s_pad >> 5) + st) * (128 * 32 * 2)), w, lane);
   };
-  auto commit2 = [&](char* buf) {
-    commit_rows<512>(buf, rk, tid);
-    commit_rows<512>(buf + AB_ROWS, rv, tid);
-    commit_tile<512>(buf + 2 * AB_ROWS, rt, tid);
-  };
-  fetch2(0);
-  commit2(smem);
-  __syncthreads();
-  for (int st = 0; st < nsteps; ++st) {
-    const char* kl = smem + (st & 1) * 3 * AB_ROWS;
+  auto step = [&](const int st, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    dma_wait<PER>(min(AB_RING - 2, nsteps - 1 - st));     // stage st has landed (this wave's pieces) ...
+    __syncthreads();                                      // ... and everybody's; every wave is done with step st - 1
+    if (st + AB_RING - 1 < nsteps) issue(st + AB_RING - 1);   // into the slot step st - 1 used
+    const char* kl = smem + (st % AB_RING) * 3 * AB_ROWS;
     const char* vl = kl + AB_ROWS;
     const char* ktl = kl + 2 * AB_ROWS;
-    const bool more = st + 1 < nsteps;
-    if (more) fetch2(st + 1);
     __builtin_amdgcn_sched_barrier(0);
     uint32_t gw[QT][4];                                  // the 8-slot g operand of each query tile, as packed bf16 pairs
 #pragma unroll
@@ -256,7 +307,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
       for (int ks = 0; ks < 4; ++ks) kfr[ks] = frag_rows(kl, t2, ks, l15, g), vfr[ks] = frag_rows(vl, t2, ks, l15, g);
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s = negl[t], dp = negd[t];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           s = mfma16(kfr[ks], qf[t][ks], s);
@@ -265,9 +316,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
         float gv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool ok = st * 32 + 16 * t2 + 4 * g + r < S;
-          const float p = ok ? __builtin_amdgcn_exp2f(s[r] - my_lse[t]) : 0.f;
-          gv[r] = LN2 * p * (dp[r] - my_d[t]);
+          float p = __builtin_amdgcn_exp2f(s[r]);
+          if (LAST && st * 32 + 16 * t2 + 4 * g + r >= S) p = 0.f;
+          gv[r] = p * dp[r];
         }
         gw[t][2 * t2] = pack2(gv[0], gv[1]);            // slots 4 t2 .. 4 t2 + 3 of this lane group
         gw[t][2 * t2 + 1] = pack2(gv[2], gv[3]);
@@ -282,9 +333,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
       for (int t = 0; t < QT; ++t) acc[t][dt] = mfma16(a_k, gf[t], acc[t][dt]);
     }
-    if (more) commit2(smem + ((st + 1) & 1) * 3 * AB_ROWS);
-    __syncthreads();
-  }
+  };
+  __syncthreads();                                        // (the statistics pass, if it ran, is done with the LDS)
+#pragma unroll
+  for (int st = 0; st < AB_RING - 1; ++st)
+    if (st < nsteps) issue(st);
+  for (int st = 0; st + 1 < nsteps; ++st) step(st, std::false_type{});
+  step(nsteps - 1, std::true_type{});
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (qrow[t] >= s_pad) continue;
@@ -292,12 +347,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
       u32x2 o;
-      o[0] = pack2(acc[t][dt][0], acc[t][dt][1]);
-      o[1] = pack2(acc[t][dt][2], acc[t][dt][3]);
+      o[0] = pack2(acc[t][dt][0] * LN2, acc[t][dt][1] * LN2);
+      o[1] = pack2(acc[t][dt][2] * LN2, acc[t][dt][3] * LN2);
       *(u32x2*)(drow + 16 * dt) = o;
     }
   }
 }
+
+// The 2 x KT x 8 accumulator quads of the dK / dV kernel live in AGPRs and are accumulated IN PLACE (inline asm pins them there:
+// left to the register allocator the loop carried ~100 v_accvgpr_read per step for the k / v fragments it had parked in AGPRs
+// instead).  MFMA -> MFMA on one accumulator is interlocked by the hardware; the first read after the loop is fenced by s_nops.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_ACC_MFMA(C, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(A_), "v"(B_))
+#else
+#define RF_ACC_MFMA(C, A_, B_) ((void)0)
+#endif
 
 // ---- dK, dV -----------------------------------------------------------------------------------------------------------------
 // grid (s_pad / (64 KT), heads), 256 threads; a wave owns KT tiles of 16 keys (their k, v fragments stay in registers).
@@ -308,8 +372,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ dout, int64_t lddo, const bf16_t* __restrict__ dot,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int s_pad) {
-  constexpr int BUF = 4 * AB_ROWS + 256;                 // q~ rows | dO rows | q~^T tile | dO^T tile | lse[32] | D[32]
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * BUF = 66 048 bytes: dynamic (beyond the 64 KiB static limit)
+  constexpr int BUF = 4 * AB_ROWS + 512;                 // q~ rows | dO rows | q~^T tile | dO^T tile | lse2[64] | D[64]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // AB_RING * BUF = 133 120 bytes (dynamic)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int head = blockIdx.y;
   const int64_t hb = (int64_t)head * s_pad;
@@ -331,75 +395,87 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) akv[kt_][dt] = f32x4{0.f, 0.f, 0.f, 0.f}, avv[kt_][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nsteps = (S + 31) >> 5;
-  u32x4 r0[2], r1[2], r2[2], r3[2];
-  float rs = 0.f;
-  auto fetch = [&](const int st) {
+  // stage = q~ rows | dO rows | q~^T tile | dO^T tile | lse2[64] | D[64] (the kernel uses the first 32 of each)
+  const rsrc_t r_q = RF_MAKE_RSRC_N(q, (int64_t)gridDim.y * s_pad * 256), r_qt = RF_MAKE_RSRC_N(qt, (int64_t)gridDim.y * s_pad * 256);
+  const rsrc_t r_dot = RF_MAKE_RSRC_N(dot, (int64_t)gridDim.y * s_pad * 256);
+  const rsrc_t r_do = RF_MAKE_RSRC_N(dout, (int64_t)S * lddo * 2);                 // rows >= S read as zero (range check)
+  const rsrc_t r_lse = RF_MAKE_RSRC_N(lse, (int64_t)gridDim.y * s_pad * 4), r_d = RF_MAKE_RSRC_N(dsum, (int64_t)gridDim.y * s_pad * 4);
+  uint32_t off_q[2], off_do[2];
+  dma_row_offsets<4>(off_q, 256u, w, lane);
+  dma_row_offsets<4>(off_do, (uint32_t)(lddo * 2), w, lane);
+  constexpr int PER = 10;                                   // DMA instructions per stage and wave
+  auto issue = [&](const int st) {
+    char* buf = smem + (st % AB_RING) * BUF;
     const int q0 = st * 32;
-    fetch_rows<256>(r0, q + (hb + q0) * 128, 128, 32, tid);
-    fetch_rows<256>(r1, dout + (int64_t)q0 * lddo + head * 128, lddo, S - q0, tid);
-    fetch_tile<256>(r2, qt + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
-    fetch_tile<256>(r3, dot + ((int64_t)head * (s_pad >> 5) + st) * (128 * 32), tid);
-    if (tid < 64) rs = tid < 32 ? lse[hb + q0 + tid] : dsum[hb + q0 + tid - 32];
+    dma_rows<4>(r_q, buf, off_q, (uint32_t)((hb + q0) * 256), w);
+    dma_rows<4>(r_do, buf + AB_ROWS, off_do, (uint32_t)(((int64_t)q0 * lddo + head * 128) * 2), w);
+    dma_tile<4>(r_qt, buf + 2 * AB_ROWS, (uint32_t)(((int64_t)head * (s_pad >> 5) + st) * (128 * 32 * 2)), w, lane);
+    dma_tile<4>(r_dot, buf + 3 * AB_ROWS, (uint32_t)(((int64_t)head * (s_pad >> 5) + st) * (128 * 32 * 2)), w, lane);
+    // (every wave issues the two statistics pieces: identical bytes, and it keeps the waves' vmcnt arithmetic the same)
+    RF_BUF_LOAD_LDS4(r_lse, (lds_void*)(buf + 4 * AB_ROWS), (uint32_t)(lane * 4), (uint32_t)((hb + q0) * 4));
+    RF_BUF_LOAD_LDS4(r_d, (lds_void*)(buf + 4 * AB_ROWS + 256), (uint32_t)(lane * 4), (uint32_t)((hb + q0) * 4));
   };
-  auto commit = [&](char* buf) {
-    commit_rows<256>(buf, r0, tid);
-    commit_rows<256>(buf + AB_ROWS, r1, tid);
-    commit_tile<256>(buf + 2 * AB_ROWS, r2, tid);
-    commit_tile<256>(buf + 3 * AB_ROWS, r3, tid);
-    if (tid < 64) ((float*)(buf + 4 * AB_ROWS))[tid] = rs;
-  };
-  fetch(0);
-  commit(smem);
-  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < AB_RING - 1; ++st)
+    if (st < nsteps) issue(st);
   for (int st = 0; st < nsteps; ++st) {
-    const char* ql = smem + (st & 1) * BUF;
+    dma_wait<PER>(min(AB_RING - 2, nsteps - 1 - st));     // stage st has landed (this wave's pieces) ...
+    __syncthreads();                                      // ... and everybody's; every wave is done with step st - 1
+    if (st + AB_RING - 1 < nsteps) issue(st + AB_RING - 1);   // into the slot step st - 1 used
+    __builtin_amdgcn_sched_barrier(0);
+    const char* ql = smem + (st % AB_RING) * BUF;
     const char* dol = ql + AB_ROWS;
     const char* qtl = ql + 2 * AB_ROWS;
     const char* dotl = ql + 3 * AB_ROWS;
     const float* stat = (const float*)(ql + 4 * AB_ROWS);
-    const bool more = st + 1 < nsteps;
-    if (more) fetch(st + 1);                              // in flight while this step multiplies
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 lv[2], dvv[2];
+    f32x4 lv[2], dvv[2];                                  // -lse2, -D of this lane's queries: the C operands of the chains below
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      lv[t] = *(const f32x4*)(stat + 16 * t + 4 * g);
-      dvv[t] = *(const f32x4*)(stat + 32 + 16 * t + 4 * g);
+      lv[t] = -*(const f32x4*)(stat + 16 * t + 4 * g);
+      dvv[t] = -*(const f32x4*)(stat + 64 + 16 * t + 4 * g);
+    }
+    // query tile t outermost: its q~ / dO fragments are read once and serve the KT key tiles (32 registers at a time, not 64)
+    uint32_t pw[KT][4], gw[KT][4];                          // P / g operands of the second pair of products, packed bf16 pairs
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bf16x8 qfr[4], dofr[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qfr[ks] = frag_rows(ql, t, ks, l15, g), dofr[ks] = frag_rows(dol, t, ks, l15, g);
+#pragma unroll
+      for (int kt_ = 0; kt_ < KT; ++kt_) {
+        f32x4 s = lv[t], dp = dvv[t];                                        // chains start from -lse2[q], -D[q] (row = query here)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma16(qfr[ks], kf[kt_][ks], s);                               // S[q = 16 t + 4 g + r][key = l15] - lse2[q]
+          dp = mfma16(dofr[ks], vf[kt_][ks], dp);
+        }
+        float pv[4], gv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pv[r] = __builtin_amdgcn_exp2f(s[r]);                              // padded queries: -lse = -1e30 -> 0
+          gv[r] = pv[r] * dp[r];                                             // g / ln 2 (ln 2 goes onto the finished dK)
+        }
+        pw[kt_][2 * t] = pack2(pv[0], pv[1]), pw[kt_][2 * t + 1] = pack2(pv[2], pv[3]);     // slots 4 t .. 4 t + 3 of this lane group
+        gw[kt_][2 * t] = pack2(gv[0], gv[1]), gw[kt_][2 * t + 1] = pack2(gv[2], gv[3]);
+      }
     }
     bf16x8 pf[KT], gf[KT];
 #pragma unroll
     for (int kt_ = 0; kt_ < KT; ++kt_) {
-      float pv[8], gv[8];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma16(frag_rows(ql, t, ks, l15, g), kf[kt_][ks], s);          // S[q = 16 t + 4 g + r][key = l15]
-          dp = mfma16(frag_rows(dol, t, ks, l15, g), vf[kt_][ks], dp);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[r] - lv[t][r]);          // padded queries: lse = 1e30 -> 0
-          pv[4 * t + r] = p;
-          gv[4 * t + r] = LN2 * p * (dp[r] - dvv[t][r]);
-        }
-      }
-      pf[kt_] = __builtin_bit_cast(bf16x8, pack8(pv));
-      gf[kt_] = __builtin_bit_cast(bf16x8, pack8(gv));
+      pf[kt_] = __builtin_bit_cast(bf16x8, u32x4{pw[kt_][0], pw[kt_][1], pw[kt_][2], pw[kt_][3]});
+      gf[kt_] = __builtin_bit_cast(bf16x8, u32x4{gw[kt_][0], gw[kt_][1], gw[kt_][2], gw[kt_][3]});
     }
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
       const bf16x8 a_do = frag_tile(dotl, dt, l15, g), a_q = frag_tile(qtl, dt, l15, g);
 #pragma unroll
       for (int kt_ = 0; kt_ < KT; ++kt_) {
-        avv[kt_][dt] = mfma16(a_do, pf[kt_], avv[kt_][dt]);                  // dV^T[d][key] += dO^T[d][q slots] P[q slots][key]
-        akv[kt_][dt] = mfma16(a_q, gf[kt_], akv[kt_][dt]);                   // dK^T[d][key] += q~^T[d][q slots] g[q slots][key]
+        RF_ACC_MFMA(avv[kt_][dt], a_do, pf[kt_]);                            // dV^T[d][key] += dO^T[d][q slots] P[q slots][key]
+        RF_ACC_MFMA(akv[kt_][dt], a_q, gf[kt_]);                             // dK^T[d][key] += q~^T[d][q slots] g[q slots][key]
       }
     }
-    if (more) commit(smem + ((st + 1) & 1) * BUF);
-    __syncthreads();
   }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have left the matrix pipe before the AGPRs are read
 #pragma unroll
   for (int kt_ = 0; kt_ < KT; ++kt_) {
     const int kr = kv0 + 16 * kt_ + l15;
@@ -410,8 +486,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         u32x2 a, b;
-        a[0] = live ? pack2(akv[kt_][dt][0], akv[kt_][dt][1]) : 0u;
-        a[1] = live ? pack2(akv[kt_][dt][2], akv[kt_][dt][3]) : 0u;
+        a[0] = live ? pack2(akv[kt_][dt][0] * LN2, akv[kt_][dt][1] * LN2) : 0u;
+        a[1] = live ? pack2(akv[kt_][dt][2] * LN2, akv[kt_][dt][3] * LN2) : 0u;
         b[0] = live ? pack2(avv[kt_][dt][0], avv[kt_][dt][1]) : 0u;
         b[1] = live ? pack2(avv[kt_][dt][2], avv[kt_][dt][3]) : 0u;
         *(u32x2*)(krow + 16 * dt) = a;
@@ -445,17 +521,24 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
                      d->lddo, (bf16_t*)d->dot, d->dsum, S, sp);
   RF_LAUNCH_CHECK();
   constexpr int QT = 2;
+  constexpr int DQ_LDS = AB_RING * 3 * AB_ROWS;
+  static bool dq_attr_set = false;
+  if (!dq_attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<QT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS));
+    dq_attr_set = true;
+  }
   if (d->lse_given)
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, true>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), 0, st, (const bf16_t*)d->q,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, true>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), DQ_LDS, st, (const bf16_t*)d->q,
                        (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,
                        (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);
   else
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, false>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), 0, st, (const bf16_t*)d->q,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, false>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), DQ_LDS, st, (const bf16_t*)d->q,
                        (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,
                        (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);
   RF_LAUNCH_CHECK();
   constexpr int KT = 3;
-  constexpr int DKV_LDS = 2 * (4 * AB_ROWS + 256);
+  constexpr int DKV_LDS = AB_RING * (4 * AB_ROWS + 512);
   static bool attr_set = false;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
