@@ -76,6 +76,15 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 #endif
 }
 
+// The output accumulators of both kernels (dq~: QT x 8 quads; dK, dV: 2 x KT x 8) live in AGPRs and are accumulated IN PLACE (inline asm pins them there:
+// left to the register allocator the loop carried ~100 v_accvgpr_read per step for the k / v fragments it had parked in AGPRs
+// instead).  MFMA -> MFMA on one accumulator is interlocked by the hardware; the first read after the loop is fenced by s_nops.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_ACC_MFMA(C, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(A_), "v"(B_))
+#else
+#define RF_ACC_MFMA(C, A_, B_) ((void)0)
+#endif
+
 // ---- LDS-DMA staging (buffer_load_dwordx4 ... lds) ---------------------------------------------------------------------------------
 // A step of either loop multiplies for ~1 us against a staged tile set that takes longer than that to arrive from the L2, so one
 // step of lookahead through registers left every step waiting for its loads (2 us per step measured, both kernels).  The stages
@@ -164,8 +173,10 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 // staged key step (K rows | V rows | K^T tile, 24 KiB) against 128 QT queries -- the loop is L2 -> LDS bandwidth bound (each
 // workgroup streams the head's whole K, V, K^T), and FLOPs per staged byte scale with the queries per workgroup.
 // HAVE_LSE: the forward launch already wrote the row statistics (rf_attn_desc.lse): pass 1 is skipped.
-template <int QT, bool HAVE_LSE>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+// NW waves (8 or 4) x QT query tiles: 16 NW QT queries per workgroup -- the host picks the pair whose grid wastes least of its last
+// round of CUs (S = 5632 x 24 heads: 256-query workgroups are 2.06 rounds run as 3, 192-query ones 2.81).
+template <int QT, bool HAVE_LSE, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                           const bf16_t* __restrict__ v, const bf16_t* __restrict__ kt,
                                                           const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ dsum,
                                                           float* __restrict__ lse, bf16_t* __restrict__ dq, int S, int s_pad) {
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   bf16x8 qf[QT][4], dof[QT][4];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    qrow[t] = blockIdx.x * (128 * QT) + w * (16 * QT) + 16 * t + l15;
+    qrow[t] = blockIdx.x * (16 * NW * QT) + w * (16 * QT) + 16 * t + l15;
     const int qr = qrow[t] < s_pad ? qrow[t] : s_pad - 1;     // (a partial last workgroup: those lanes are not written)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   const int nsteps = (S + 31) >> 5;
   const float NEG = -__builtin_huge_valf();
 
-  u32x4 rk[1];
+  u32x4 rk[8 / NW];
   float my_lse[QT], my_d[QT];
   if constexpr (HAVE_LSE) {
     // padded queries: lse = +huge makes every P of that row exactly 0 here and in the dK / dV kernel (which reads all s_pad rows)
@@ -205,13 +216,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
   float m[QT], l[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) m[t] = NEG, l[t] = 0.f;
-  fetch_rows<512>(rk, k + hb * 128, 128, 32, tid);
-  commit_rows<512>(smem, rk, tid);
+  fetch_rows<NW * 64>(rk, k + hb * 128, 128, 32, tid);
+  commit_rows<NW * 64>(smem, rk, tid);
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
     const char* kl = smem + (st & 1) * 3 * AB_ROWS;
     const bool more = st + 1 < nsteps;
-    if (more) fetch_rows<512>(rk, k + (hb + (st + 1) * 32) * 128, 128, 32, tid);
+    if (more) fetch_rows<NW * 64>(rk, k + (hb + (st + 1) * 32) * 128, 128, 32, tid);
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 kfr[2][4];
 #pragma unroll
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
         m[t] = mx;
       }
     }
-    if (more) commit_rows<512>(smem + ((st + 1) & 1) * 3 * AB_ROWS, rk, tid);
+    if (more) commit_rows<NW * 64>(smem + ((st + 1) & 1) * 3 * AB_ROWS, rk, tid);
     __syncthreads();
   }
 #pragma unroll
@@ -281,16 +292,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int r = 0; r < 4; ++r) negl[t][r] = -my_lse[t], negd[t][r] = -my_d[t];
   const rsrc_t r_k = RF_MAKE_RSRC_N(k, (int64_t)gridDim.y * s_pad * 256), r_v = RF_MAKE_RSRC_N(v, (int64_t)gridDim.y * s_pad * 256);
   const rsrc_t r_kt = RF_MAKE_RSRC_N(kt, (int64_t)gridDim.y * s_pad * 256);
-  uint32_t off_r[1];
-  dma_row_offsets<8>(off_r, 256u, w, lane);
-  constexpr int PER = 3;                                    // DMA instructions per stage and wave
+  uint32_t off_r[8 / NW];
+  dma_row_offsets<NW>(off_r, 256u, w, lane);
+  constexpr int PER = 3 * 8 / NW;                           // DMA instructions per stage and wave
   auto issue = [&](const int st) {
     char* buf = smem + (st % AB_RING) * 3 * AB_ROWS;
-    dma_rows<8>(r_k, buf, off_r, (uint32_t)((hb + st * 32) * 256), w);
-    dma_rows<8>(r_v, buf + AB_ROWS, off_r, (uint32_t)((hb + st * 32) * 256), w);
-    dma_tile<8>(r_kt, buf + 2 * AB_ROWS, (uint32_t)(((int64_t)head * (s_pad >> 5) + st) * (128 * 32 * 2)), w, lane);
+    dma_rows<NW>(r_k, buf, off_r, (uint32_t)((hb + st * 32) * 256), w);
+    dma_rows<NW>(r_v, buf + AB_ROWS, off_r, (uint32_t)((hb + st * 32) * 256), w);
+    dma_tile<NW>(r_kt, buf + 2 * AB_ROWS, (uint32_t)(((int64_t)head * (s_pad >> 5) + st) * (128 * 32 * 2)), w, lane);
   };
-  auto step = [&](const int st, auto last_tag) {
+  auto step = [&](const int st, auto last_tag, f32x4 (&accr)[QT][8]) {   // (accr = acc: an asm operand cannot name a capture of a generic lambda)
     constexpr bool LAST = decltype(last_tag)::value;
     dma_wait<PER>(min(AB_RING - 2, nsteps - 1 - st));     // stage st has landed (this wave's pieces) ...
     __syncthreads();                                      // ... and everybody's; every wave is done with step st - 1
@@ -331,15 +342,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int dt = 0; dt < 8; ++dt) {
       const bf16x8 a_k = frag_tile(ktl, dt, l15, g);
 #pragma unroll
-      for (int t = 0; t < QT; ++t) acc[t][dt] = mfma16(a_k, gf[t], acc[t][dt]);
+      for (int t = 0; t < QT; ++t) {
+        // one wave per SIMD: 512 registers, the accumulators pinned in the AGPR half; two waves per SIMD: 256 in all, and pinning
+        // splits them 128 + 128 with spills across -- there the allocator keeps everything in VGPRs
+        if constexpr (NW == 4) RF_ACC_MFMA(accr[t][dt], a_k, gf[t]);
+        else accr[t][dt] = mfma16(a_k, gf[t], accr[t][dt]);
+      }
     }
   };
   __syncthreads();                                        // (the statistics pass, if it ran, is done with the LDS)
 #pragma unroll
   for (int st = 0; st < AB_RING - 1; ++st)
     if (st < nsteps) issue(st);
-  for (int st = 0; st + 1 < nsteps; ++st) step(st, std::false_type{});
-  step(nsteps - 1, std::true_type{});
+  for (int st = 0; st + 1 < nsteps; ++st) step(st, std::false_type{}, acc);
+  step(nsteps - 1, std::true_type{}, acc);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs have left the matrix pipe before the AGPRs are read
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (qrow[t] >= s_pad) continue;
@@ -353,15 +370,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const bf16_t* __restri
     }
   }
 }
-
-// The 2 x KT x 8 accumulator quads of the dK / dV kernel live in AGPRs and are accumulated IN PLACE (inline asm pins them there:
-// left to the register allocator the loop carried ~100 v_accvgpr_read per step for the k / v fragments it had parked in AGPRs
-// instead).  MFMA -> MFMA on one accumulator is interlocked by the hardware; the first read after the loop is fenced by s_nops.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define RF_ACC_MFMA(C, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(A_), "v"(B_))
-#else
-#define RF_ACC_MFMA(C, A_, B_) ((void)0)
-#endif
 
 // ---- dK, dV -----------------------------------------------------------------------------------------------------------------
 // grid (s_pad / (64 KT), heads), 256 threads; a wave owns KT tiles of 16 keys (their k, v fragments stay in registers).
@@ -520,33 +528,57 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
   hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(sp / 32, H), dim3(256), 0, st, (const bf16_t*)d->o, d->ldo, (const bf16_t*)d->dout,
                      d->lddo, (bf16_t*)d->dot, d->dsum, S, sp);
   RF_LAUNCH_CHECK();
-  constexpr int QT = 2;
-  constexpr int DQ_LDS = AB_RING * 3 * AB_ROWS;
-  static bool dq_attr_set = false;
-  if (!dq_attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<QT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<QT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS));
-    dq_attr_set = true;
+  static int num_cus = 0;
+  if (num_cus == 0) {
+    int dev = 0;
+    RF_CHECK_HIP(hipGetDevice(&dev));
+    RF_CHECK_HIP(hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (num_cus <= 0) num_cus = 256;
   }
-  if (d->lse_given)
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, true>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), DQ_LDS, st, (const bf16_t*)d->q,
-                       (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,
-                       (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);
-  else
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<QT, false>), dim3((sp + 128 * QT - 1) / (128 * QT), H), dim3(512), DQ_LDS, st, (const bf16_t*)d->q,
-                       (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,
-                       (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);
-  RF_LAUNCH_CHECK();
-  constexpr int KT = 3;
-  constexpr int DKV_LDS = AB_RING * (4 * AB_ROWS + 512);
+  // one workgroup per CU at a time (LDS ring): time ~ rounds of CUs x rows per workgroup.  Pick the shape with the least.
+  auto cost = [&](const int rows) { return (int64_t)(((int64_t)((sp + rows - 1) / rows) * H + num_cus - 1) / num_cus) * rows; };
+  constexpr int DQ_LDS = AB_RING * 3 * AB_ROWS;
   static bool attr_set = false;
+  constexpr int DKV_LDS = AB_RING * (4 * AB_ROWS + 512);
+#define RF_DQ_ALL(F) F(2, 8) F(2, 4) F(3, 4)
   if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
+#define RF_DQ_ATTR(QT_, NW_)                                                                                                                 \
+  RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<QT_, true, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS)); \
+  RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<QT_, false, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS));
+    RF_DQ_ALL(RF_DQ_ATTR)
+#undef RF_DQ_ATTR
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<KT>, dim3((sp + 64 * KT - 1) / (64 * KT), H), dim3(256), DKV_LDS, st, (const bf16_t*)d->q,
-                     (const bf16_t*)d->qt, (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->dout, d->lddo,
-                     (const bf16_t*)d->dot, (const float*)d->lse, (const float*)d->dsum, (bf16_t*)d->dk, (bf16_t*)d->dv, S, sp);
+#define RF_DQ_LAUNCH(QT_, NW_)                                                                                                          \
+  {                                                                                                                                     \
+    const dim3 grid((sp + 16 * NW_ * QT_ - 1) / (16 * NW_ * QT_), H);                                                                   \
+    if (d->lse_given)                                                                                                                   \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<QT_, true, NW_>), grid, dim3(NW_ * 64), DQ_LDS, st, (const bf16_t*)d->q,                  \
+                         (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,               \
+                         (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);                                                        \
+    else                                                                                                                                \
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<QT_, false, NW_>), grid, dim3(NW_ * 64), DQ_LDS, st, (const bf16_t*)d->q,                 \
+                         (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,               \
+                         (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);                                                        \
+  }
+  {
+    const int64_t c256 = cost(256), c192 = cost(192), c128 = cost(128);
+    if (c192 < c256 && c192 <= c128) RF_DQ_LAUNCH(3, 4)
+    else if (c128 < c256) RF_DQ_LAUNCH(2, 4)
+    else RF_DQ_LAUNCH(2, 8)
+  }
+#undef RF_DQ_LAUNCH
+#undef RF_DQ_ALL
+  RF_LAUNCH_CHECK();
+#define RF_DKV_LAUNCH(KT_)                                                                                                              \
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<KT_>, dim3((sp + 64 * KT_ - 1) / (64 * KT_), H), dim3(256), DKV_LDS, st, (const bf16_t*)d->q,  \
+                     (const bf16_t*)d->qt, (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->dout, d->lddo,                   \
+                     (const bf16_t*)d->dot, (const float*)d->lse, (const float*)d->dsum, (bf16_t*)d->dk, (bf16_t*)d->dv, S, sp)
+  if (cost(128) < cost(192)) RF_DKV_LAUNCH(2);
+  else RF_DKV_LAUNCH(3);
+#undef RF_DKV_LAUNCH
   RF_LAUNCH_CHECK();
   return RF_OK;
 }

@@ -1614,6 +1614,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   // tile: 128 / 256 = the shipped kernels, 257 = plain 256x256 loop (bit-exact reference of the ping-pong loops);
   // 258 / 259 = experiments build only
   int tile = 0;
+  bool sk_or_128 = false;   // AUTO chose 256^2 tiles for their stream-K form only: without it (no scratch / not this device) use 128^2
   if (tile == 0) {
     switch (p.sched) {
       case RF_SCHED_TILE128: tile = 128; break;
@@ -1621,9 +1622,15 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
       case RF_SCHED_PLAIN256: tile = 257; break;
       case RF_SCHED_W4: tile = 260; break;
       default: {
-        // 256^2 tiles only pay when they still fill the 256 CUs; small problems get 128^2.
+        // 256^2 tiles pay from ~half a round of the 256 CUs (plain or stream-K: 144-192 tiles measured 15-30 % ahead of 128^2,
+        // tools/kb_gemm_midsize.py / profiles/r04_gemm_midsize.md); below that only as stream-K and only with a long K
+        // (>= 128 K-tiles: 48-120 tiles at K = 12288 / 15360 are 4-24 % ahead, at K = 3072 they lose 15-40 %).
         const int64_t t256 = (int64_t)cdiv((int)rows, 256) * cdiv(p.N, 256);
-        tile = (t256 >= 200) ? 256 : 128;
+        int nk_min = 1 << 30;
+        for (int g = 0; g < p.ngroups; ++g) nk_min = std::min(nk_min, p.g[g].seg[0].nk + p.g[g].seg[1].nk + p.g[g].seg[2].nk);
+        if (t256 >= 128) tile = 256;
+        else if (t256 >= 32 && nk_min >= 128 && !p.w8 && p.vec_ok) tile = 256, sk_or_128 = true;
+        else tile = 128;
       }
     }
   }
@@ -1648,6 +1655,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
                         : try_launch_gemm_sk<256, 256, 4, 2, false>(p, ws_base, ws_total, stream);
     if (rc != 0) return rc < 0 ? rc : RF_OK;
   }
+  if (sk_or_128) tile = 128;
   if (ws_bytes > 0 && tile == 128 && p.ngroups == 1 && p.epi == RF_EPI_STORE && p.vec_ok) {
     const GemmGroupDev& G = p.g[0];
     const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
