@@ -485,7 +485,7 @@ int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t B,
  * train_flux/train/model.py:164-238 (flow-matching MSE through tranformer_forward; per-block recompute = the
  * gradient-checkpoint branch train_flux/flux/transformer.py:139-157).  Base weights are frozen, so a block's backward is
  *   dX through every GEMM      = rf_gemm_bf16 on TRANSPOSED weight copies  (dX = dY W  ==  dY (W^T)^T)
- *   LoRA factor gradients      = rf_gemm_bf16 over the TOKEN axis on rf_transpose_bf16'd operands
+ *   LoRA factor gradients      = rf_gemm_tn_skinny (contraction over the TOKEN axis, operands as they lie)
  *   everything else            = the kernels below.
  * Gradients travel between kernels as bf16 (as torch's bf16 autograd does), sums are fp32, column reductions are
  * fixed-order two-stage sums: the whole backward is bit-reproducible (no atomics).
@@ -542,6 +542,14 @@ int rf_gate_residual(const void* f, int64_t ldf, const void* gate, const void* r
 int rf_gelu(const void* z, int64_t ldz, void* h, int64_t ldh, int32_t rows, int32_t cols, void* stream);
 int rf_gelu_bwd(const void* z, int64_t ldz, const void* dh, int64_t lddh, void* dz, int64_t lddz, int32_t rows, int32_t cols,
                 void* stream);
+/* Token-axis ("TN") skinny GEMM -- the LoRA factor gradients dB = dY^T T and dA = (x^T dT)^T (train/model.py's autograd through
+ * peft's lora_A / lora_B, lora_controller.py:5-42):
+ *   out[n][j] = sum_{s < S} big[s][n] * skinny[s][j]      n < N (N % 8 == 0), j < R (R % 16 == 0)
+ * big [S][ld_big], skinny [S][ld_sk] row-major bf16; out bf16 [N][ld_out], or [R][ld_out] when `transposed`.  fp32 partial sums per
+ * 128-token chunk in `ws` (rf_gemm_tn_skinny_ws_bytes), added in chunk order: bit-reproducible.  No operand is transposed in HBM. */
+int64_t rf_gemm_tn_skinny_ws_bytes(int32_t S, int32_t N, int32_t R);
+int rf_gemm_tn_skinny(const void* big, int64_t ld_big, const void* skinny, int64_t ld_sk, void* out, int64_t ld_out, int32_t S,
+                      int32_t N, int32_t R, int32_t transposed, float* ws, int64_t ws_bytes, void* stream);
 /* dst[c][r] = src[r][c], r < rows; zero for rows <= r < rows_pad (the K % 64 padding of a token-axis contraction) */
 int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, int32_t cols, void* dst, int64_t ld_dst,
                       int32_t rows_pad, void* stream);

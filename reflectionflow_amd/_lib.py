@@ -206,6 +206,8 @@ _SIGS = {
     "rf_gelu": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "rf_gelu_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "rf_transpose_bf16": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int64, C.c_int32, _P]),
+    "rf_gemm_tn_skinny_ws_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "rf_gemm_tn_skinny": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),
     "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int32)]),

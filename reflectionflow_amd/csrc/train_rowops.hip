@@ -404,6 +404,130 @@ static int row_blocks(int rows) {
   return b < 128 ? b : 128;      // <= 512 waves: 512 x 2 x D fp32 partials
 }
 
+
+// ---- token-axis ("TN") skinny GEMM: the LoRA factor gradients -----------------------------------------------------------------
+//   out[n][j] = sum_s big[s][n] * skinny[s][j]        big [S][ld_big] (N columns), skinny [S][ld_sk] (R <= 64 columns), both row-major bf16
+// dB = dY^T T  and  dA^T = x^T dT  contract over the TOKENS, the one axis along which neither operand is contiguous.  Going through
+// rf_gemm_bf16 meant writing dY^T and x^T out first (two full-size transposes per LoRA site and step: 6 % of a training step at the
+// reference's shape).  Here the transpose happens on the way INTO the LDS: a thread's 16-byte load (8 columns of one token) is
+// scattered as eight 2-byte writes into a [column][32 tokens] image, whose rows are then exactly the 16-byte MFMA fragments
+// (16x16x32: lane (g, i) <- row i, tokens 8 g .. 8 g + 7; chunk g of row n sits at g ^ ((n >> 2) & 3): conflict-free reads).
+// grid (ceil(N / 128), chunks of TN_CHUNK tokens): fp32 partial tiles [chunk][N][R] -> tn_reduce_kernel sums them in chunk order
+// (deterministic) and writes bf16, optionally transposed ([R][N]: dA).
+constexpr int TN_COLS = 128, TN_CHUNK = 128;
+__device__ __forceinline__ f32x4 mfma16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+  return c;
+#endif
+}
+template <int RT>   // RT = R / 16 (1, 2, 4 or 8) column tiles of the skinny operand
+__global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ big, int64_t ld_big, const bf16_t* __restrict__ sk,
+                                                        int64_t ld_sk, float* __restrict__ ws, int S, int N) {
+  constexpr int R = 16 * RT;
+  __shared__ __attribute__((aligned(16))) char bigT[2][TN_COLS * 64];   // [128 columns][32 tokens] bf16, chunk-swizzled
+  __shared__ __attribute__((aligned(16))) char skT[2][R * 64];          // [R columns][32 tokens]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * TN_COLS, s_begin = blockIdx.y * TN_CHUNK;
+  const int s_end = min(S, s_begin + TN_CHUNK);
+  const int nsteps = (s_end - s_begin + 31) >> 5;
+  // loader roles: big tile = 32 tokens x 16 column-octets = 512 pieces, two per thread; skinny tile = 32 tokens x (R / 8) octets
+  constexpr int SKP = (32 * (R / 8) + 255) / 256;   // skinny pieces per thread (2 at R = 128)
+  u32x4 rb[2], rs[SKP];
+  auto fetch = [&](const int st) {
+    const int s0 = s_begin + st * 32;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int idx = tid + 256 * p, row = idx >> 4, c = idx & 15;
+      const int n = n0 + c * 8;
+      rb[p] = u32x4{0u, 0u, 0u, 0u};
+      if (s0 + row < s_end && n < N) rb[p] = *(const u32x4*)(big + (int64_t)(s0 + row) * ld_big + n);   // N % 8 == 0
+    }
+#pragma unroll
+    for (int p = 0; p < SKP; ++p) {
+      const int idx = tid + 256 * p, row = idx / (R / 8), c = idx % (R / 8);
+      rs[p] = u32x4{0u, 0u, 0u, 0u};
+      if (idx < 32 * (R / 8) && s0 + row < s_end) rs[p] = *(const u32x4*)(sk + (int64_t)(s0 + row) * ld_sk + c * 8);
+    }
+  };
+  auto put8 = [&](char* img, const u32x4 v, const int col0, const int tok) {   // columns col0 .. col0 + 7 of token tok
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = col0 + e;
+      const uint32_t word = v[e >> 1];
+      const uint16_t h = (e & 1) ? (uint16_t)(word >> 16) : (uint16_t)(word & 0xffffu);
+      *(uint16_t*)(img + n * 64 + (((tok >> 3) ^ ((n >> 2) & 3)) << 4) + (tok & 7) * 2) = h;
+    }
+  };
+  auto commit = [&](const int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int idx = tid + 256 * p;
+      put8(bigT[buf], rb[p], (idx & 15) * 8, idx >> 4);
+    }
+#pragma unroll
+    for (int p = 0; p < SKP; ++p) {
+      const int idx = tid + 256 * p;
+      if (idx < 32 * (R / 8)) put8(skT[buf], rs[p], (idx % (R / 8)) * 8, idx / (R / 8));
+    }
+  };
+  f32x4 acc[2][RT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < RT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (nsteps > 0) {
+    fetch(0);
+    commit(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) fetch(st + 1);
+    bf16x8 bf[RT];
+#pragma unroll
+    for (int b = 0; b < RT; ++b) {
+      const int j = 16 * b + l15;
+      bf[b] = *(const bf16x8*)(skT[buf] + j * 64 + ((g ^ ((j >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int n = 16 * (2 * w + a) + l15;                    // this wave's column tiles 2 w, 2 w + 1
+      const bf16x8 af = *(const bf16x8*)(bigT[buf] + n * 64 + ((g ^ ((n >> 2) & 3)) << 4));
+#pragma unroll
+      for (int b = 0; b < RT; ++b) acc[a][b] = mfma16x16x32(af, bf[b], acc[a][b]);
+    }
+    if (st + 1 < nsteps) commit(buf ^ 1);
+    __syncthreads();
+  }
+  // partial tile: lane (g, j = l15) holds out[n = 16 (2 w + a) + 4 g + r][16 b + j]
+  float* dst = ws + ((int64_t)blockIdx.y * N + n0) * R;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 16 * (2 * w + a) + 4 * g + r;
+      if (n0 + n < N) {
+#pragma unroll
+        for (int b = 0; b < RT; ++b) dst[(int64_t)n * R + 16 * b + l15] = acc[a][b][r];
+      }
+    }
+}
+
+// out[n][j] (or out[j][n] when transposed) = bf16(sum over chunks, in chunk order)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int chunks, int N, int R, bf16_t* __restrict__ out,
+                                                        int64_t ld_out, int transposed) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)N * R) return;
+  // transposed output: consecutive threads walk n (the contiguous axis of out[j][:]); plain: consecutive threads walk j
+  const int n = transposed ? (int)(idx % N) : (int)(idx / R), j = transposed ? (int)(idx / N) : (int)(idx % R);
+  float v = 0.f;
+  for (int c = 0; c < chunks; ++c) v += ws[((int64_t)c * N + n) * R + j];
+  if (transposed) out[(int64_t)j * ld_out + n] = f2bf(v);
+  else out[(int64_t)n * ld_out + j] = f2bf(v);
+}
+
 }  // namespace rf
 
 using namespace rf;
@@ -443,6 +567,44 @@ extern "C" int rf_qkv_train_bwd(const void* raw, int64_t ld_raw, int32_t heads, 
                      (const bf16_t*)w_q, (const bf16_t*)w_k, (const bf16_t*)w_added_q, (const bf16_t*)w_added_k, cos_tab, sin_tab, eps,
                      q_scale == 0.f ? 1.0f : q_scale, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv, (bf16_t*)d_raw, ld_draw);
   RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int64_t rf_gemm_tn_skinny_ws_bytes(int32_t S, int32_t N, int32_t R) {
+  return (int64_t)((S + rf::TN_CHUNK - 1) / rf::TN_CHUNK) * N * R * 4;
+}
+
+extern "C" int rf_gemm_tn_skinny(const void* big, int64_t ld_big, const void* skinny, int64_t ld_sk, void* out, int64_t ld_out,
+                                 int32_t S, int32_t N, int32_t R, int32_t transposed, float* ws, int64_t ws_bytes, void* stream) {
+  using namespace rf;
+  RF_REQUIRE(big && skinny && out && ws, RF_ERR_NULL, "rf_gemm_tn_skinny: NULL operand");
+  RF_REQUIRE(S > 0 && N > 0 && N % 8 == 0 && R > 0 && R % 16 == 0 && ld_big % 8 == 0 && ld_sk % 8 == 0 && ld_big >= N && ld_sk >= R &&
+                 ld_out >= (transposed ? N : R),
+             RF_ERR_SHAPE, "rf_gemm_tn_skinny: S=%d N=%d R=%d (N %% 8 == 0, R %% 16 == 0)", S, N, R);
+  RF_REQUIRE(aligned16(big) && aligned16(skinny), RF_ERR_ALIGN, "rf_gemm_tn_skinny: 16-byte alignment");
+  RF_REQUIRE(ws_bytes >= rf_gemm_tn_skinny_ws_bytes(S, N, R), RF_ERR_WORKSPACE, "rf_gemm_tn_skinny: scratch needs %lld bytes",
+             (long long)rf_gemm_tn_skinny_ws_bytes(S, N, R));
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(RF_KC_GEMM_SMALL, 2.0 * S * (double)N * R, st);
+  const int chunks = cdiv(S, TN_CHUNK);
+  const dim3 grid(cdiv(N, TN_COLS), chunks);
+  // the skinny operand in slices of 128 / 64 / 32 / 16 columns (a fused q | k | v | mlp LoRA has R = 128); one launch pair per slice
+  for (int j0 = 0; j0 < R;) {
+    const int rem = R - j0, Rs = rem >= 128 ? 128 : rem >= 64 ? 64 : rem >= 32 ? 32 : 16;
+    const bf16_t* sks = (const bf16_t*)skinny + j0;
+#define RF_TN(RT_) hipLaunchKernelGGL(tn_skinny_kernel<RT_>, grid, dim3(256), 0, st, (const bf16_t*)big, ld_big, sks, ld_sk, ws, S, N)
+    if (Rs == 128) RF_TN(8);
+    else if (Rs == 64) RF_TN(4);
+    else if (Rs == 32) RF_TN(2);
+    else RF_TN(1);
+#undef RF_TN
+    RF_LAUNCH_CHECK();
+    bf16_t* outs = (bf16_t*)out + (transposed ? (int64_t)j0 * ld_out : (int64_t)j0);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv((int)((int64_t)N * Rs), 256)), dim3(256), 0, st, (const float*)ws, chunks, N, Rs, outs,
+                       ld_out, transposed);
+    RF_LAUNCH_CHECK();
+    j0 += Rs;
+  }
   return RF_OK;
 }
 

@@ -124,14 +124,12 @@ def _grouped(streams, A_buf, names, N, out_buf, loras=None, keep=None, tag=""):
 
 def _lora_bwd(x_segs: Sequence[torch.Tensor], T: torch.Tensor, dy: torch.Tensor, A: torch.Tensor, Bs: torch.Tensor):
     """y += (sum_s x_s A_s^T) Bs^T with A = [A_0 | A_1 ...] along K.  -> (dA [r_pad, K], dBs [N, r_pad], dT [M, r_pad])."""
-    dyT, TT = K.transpose(dy), K.transpose(T)
-    dBs = ops.linear(dyT, TT)                                   # [N, r_pad] = dy^T T   (contraction over the tokens)
+    dBs = K.gemm_tn(dy, T)                                      # [N, r_pad] = dy^T T   (contraction over the tokens, operands as they lie)
     dT = ops.linear(dy, K.transpose(Bs, rows_pad=Bs.shape[0]))  # [M, r_pad] = dy Bs
-    dTT = K.transpose(dT)
     dA = torch.empty_like(A)
     k0 = 0
     for x in x_segs:
-        ops.linear(dTT, K.transpose(x), out=dA[:, k0:k0 + x.shape[1]])   # [r_pad, K_s] = dT^T x_s
+        K.gemm_tn(x, dT, transposed=True, out=dA[:, k0:k0 + x.shape[1]])   # [r_pad, K_s] = dT^T x_s
         k0 += x.shape[1]
     return dA, dBs, dT
 

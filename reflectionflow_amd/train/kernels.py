@@ -153,6 +153,31 @@ def gelu_bwd(z, dh, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
+_TN_WS = {}
+
+
+def gemm_tn(big: torch.Tensor, skinny: torch.Tensor, transposed: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[n, j] = sum_s big[s, n] skinny[s, j] (the contraction runs over the ROWS of both operands: dB = dY^T T, dA = (x^T dT)^T
+    with transposed=True -> out [R, N]).  R = skinny.shape[1], a multiple of 16."""
+    big, skinny = _rows2d(big, "big"), _rows2d(skinny, "skinny")
+    S, N = big.shape
+    R = skinny.shape[1]
+    if skinny.shape[0] != S:
+        raise RFError(f"gemm_tn: {tuple(big.shape)} vs {tuple(skinny.shape)}")
+    if out is None:
+        out = torch.empty((R, N) if transposed else (N, R), dtype=BF, device=big.device)
+    out = _rows2d(out, "out")
+    lib = L.load()
+    need = int(lib.rf_gemm_tn_skinny_ws_bytes(S, N, R))
+    key = (big.device.index, stream_ptr())
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _TN_WS[key] = torch.empty(max(need // 4, 1 << 20), dtype=torch.float32, device=big.device)
+    L.check(lib.rf_gemm_tn_skinny(big.data_ptr(), big.stride(0), skinny.data_ptr(), skinny.stride(0), out.data_ptr(), out.stride(0),
+                                  S, N, R, 1 if transposed else 0, ws.data_ptr(), ws.numel() * 4, stream_ptr()), "rf_gemm_tn_skinny")
+    return out
+
+
 def transpose(x, rows_pad: Optional[int] = None) -> torch.Tensor:
     """[R, C] -> [C, R_pad] with zero columns R .. R_pad (R_pad defaults to R rounded up to 64: a GEMM K-segment)."""
     x = _rows2d(x, "x")

@@ -131,6 +131,24 @@ def test_qkv_train_fwd_bwd(dev, H, S, n_added, extra):
     assert float(d_raw[:, 3 * D:].abs().max() if extra else 0.0) == 0.0
 
 
+@pytest.mark.parametrize("S,N,R", [(1024, 3072, 32), (1000, 3080, 64), (70, 136, 16), (129, 128, 32), (31, 8, 64), (2560, 12288, 64), (1024, 21504, 128), (300, 512, 208)])
+def test_gemm_tn_skinny(dev, S, N, R):
+    """out[n, j] = sum_s big[s, n] skinny[s, j] (the LoRA factor gradients) against fp64, both output orientations, operands that
+    are column windows of wider buffers, and bit-reproducibility."""
+    from reflectionflow_amd.train import kernels as K
+    wide, sk_wide = rnd(dev, S, N + 24, seed=5), rnd(dev, S, R + 8, seed=6)
+    big, sk = wide[:, 8:8 + N], sk_wide[:, 8:8 + R]
+    ref = big.double().t() @ sk.double()
+    out = K.gemm_tn(big, sk)
+    assert out.shape == (N, R)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    assert err < 6e-3, err
+    outT = torch.zeros(R, N + 16, dtype=BF, device=dev)
+    K.gemm_tn(big, sk, transposed=True, out=outT[:, 16:])
+    assert torch.equal(outT[:, 16:].t().contiguous(), out) and float(outT[:, :16].abs().max()) == 0.0
+    assert torch.equal(K.gemm_tn(big, sk), out)
+
+
 @pytest.mark.parametrize("H,S", [(2, 112), (3, 256), (2, 1000), (24, 1024), (4, 4608)])
 def test_attention_bwd_vs_fp32_autograd(dev, H, S):
     from reflectionflow_amd import ops
