@@ -418,7 +418,10 @@ typedef struct rf_vae_weights {                 /* ONE direction: the Decoder or
 } rf_vae_weights;
 /* workspace (caller-owned, 256-byte aligned) for an input of h x w pixels (decode: latent size, encode: image size) */
 int64_t rf_vae_workspace_bytes(const rf_vae_weights* w, int32_t encode, int32_t h, int32_t w_in);
-/* z: zero-halo [(h+2)(w+2)][conv_in.cin]  ->  out: [(8h+2)(8w+2)][conv_out.cout]: only the INTERIOR of `out` is defined (its top /
+/* INPUT SLACK (both entry points): conv_in runs as a GEMM whose 64-element K-tiles reach past the last pixel's channels against zero
+ * weight columns, so the input buffer must be followed by >= 64 * max(conv_in.cin, 64) * 2 readable bytes holding FINITE values
+ * (zeros): a NaN / Inf there does not multiply away.  (reflectionflow_amd/flux/vae_hip.py::_padded_input allocates it that way.)
+ * z: zero-halo [(h+2)(w+2)][conv_in.cin]  ->  out: [(8h+2)(8w+2)][conv_out.cout]: only the INTERIOR of `out` is defined (its top /
  * bottom halo rows are never written, its halo columns receive garbage); the caller slices channels 0..2 of the interior */
 int rf_vae_decode(const rf_vae_weights* w, const void* z, int32_t h, int32_t w_in, void* out, const rf_workspace* ws, void* stream);
 /* img: zero-halo [(H+2)(W+2)][conv_in.cin] -> out: [(H/8+2)(W/8+2)][conv_out.cout] = (mean | logvar) moments, interior valid */

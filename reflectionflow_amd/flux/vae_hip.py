@@ -126,6 +126,16 @@ def _pack_direction(vae, encode: bool, device) -> Tuple["L.rf_vae_weights", _Pac
     return w, p
 
 
+def _padded_input(h: int, w: int, c: int, device) -> torch.Tensor:
+    """The zero-halo NHWC image [(h + 2), (w + 2), c] a convolution reads, as a view of a ZEROED allocation with 64 pixels of slack
+    behind it: conv_in runs as a GEMM whose K-tiles (64 elements) reach past the last pixel's 3 * c channels, against zero weight
+    columns -- finite garbage there multiplies away, a NaN / Inf left in a recycled block does not (it did: one image of a batch
+    came out all-NaN through the next GroupNorm when the allocator placed the input in front of such a block)."""
+    n = (h + 2) * (w + 2) * c
+    flat = torch.zeros(n + 64 * max(c, 64), dtype=BF, device=device)
+    return flat[:n].view(h + 2, w + 2, c)
+
+
 class HipVAE:
     """`AutoencoderKL`-shaped object whose encode / decode run on librf_flux.so.  `module` keeps the original torch modules
     (state_dict, dtype bookkeeping); nothing of it executes in encode() / decode()."""
@@ -188,7 +198,7 @@ class HipVAE:
         H, W = self.scale * h, self.scale * wd
         outs = []
         for b in range(B):
-            zp = torch.zeros(h + 2, wd + 2, w.conv_in.cin, dtype=BF, device=z.device)
+            zp = _padded_input(h, wd, w.conv_in.cin, z.device)
             zp[1:-1, 1:-1, :Cz] = z[b].to(BF).permute(1, 2, 0)
             out = torch.empty(H + 2, W + 2, w.conv_out.cout, dtype=BF, device=z.device)
             L.check(lib.rf_vae_decode(C.byref(w), zp.data_ptr(), h, wd, out.data_ptr(), C.byref(ws), stream_ptr()), "rf_vae_decode")
@@ -209,7 +219,7 @@ class HipVAE:
         h, wd = H // self.scale, W // self.scale
         outs = []
         for b in range(B):
-            xp = torch.zeros(H + 2, W + 2, w.conv_in.cin, dtype=BF, device=x.device)
+            xp = _padded_input(H, W, w.conv_in.cin, x.device)
             xp[1:-1, 1:-1, :Cx] = x[b].to(BF).permute(1, 2, 0)
             out = torch.empty(h + 2, wd + 2, w.conv_out.cout, dtype=BF, device=x.device)
             L.check(lib.rf_vae_encode(C.byref(w), xp.data_ptr(), H, W, out.data_ptr(), C.byref(ws), stream_ptr()), "rf_vae_encode")
