@@ -529,7 +529,7 @@ typedef struct rf_attn_bwd_desc {
 int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream);
 
 /* y = LayerNorm(x) (1 + scale) + shift  (rf_layernorm_modulate):  dx[m] = (dres ? dres[m] : 0) + LN-backward(dy[m]);
- * d_scale[c] = sum_m dy[m,c] xhat[m,c], d_shift[c] = sum_m dy[m,c]  (fp32 [D]).  partials: scratch of
+ * d_scale[c] = sum_m dy[m,c] xhat[m,c], d_shift[c] = sum_m dy[m,c]  (fp32 [D]; both NULL = not wanted).  partials: scratch of
  * rf_train_partials_bytes(D) bytes.  D % 8 == 0, D <= 3072. */
 int64_t rf_train_partials_bytes(int32_t D);
 int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* dres, int64_t lddres,

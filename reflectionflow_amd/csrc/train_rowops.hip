@@ -613,7 +613,8 @@ extern "C" int64_t rf_train_partials_bytes(int32_t D) { return (int64_t)512 * 2 
 extern "C" int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const void* dres, int64_t lddres,
                                          void* dx, int64_t lddx, int32_t rows, int32_t D, const void* scale, float eps, float* d_scale,
                                          float* d_shift, float* partials, int64_t partials_bytes, void* stream) {
-  RF_REQUIRE(x && dy && dx && scale && d_scale && d_shift && partials, RF_ERR_NULL, "rf_layernorm_modulate_bwd: NULL operand");
+  RF_REQUIRE(x && dy && dx && scale && partials && ((d_scale == nullptr) == (d_shift == nullptr)), RF_ERR_NULL,
+             "rf_layernorm_modulate_bwd: NULL operand (d_scale and d_shift are given or omitted together)");
   RF_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 6 * 512 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && lddres % 8 == 0,
              RF_ERR_SHAPE, "rf_layernorm_modulate_bwd: rows=%d D=%d (D %% 8 == 0, D <= 3072)", rows, D);
   RF_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(scale) && (dres == nullptr || aligned16(dres)), RF_ERR_ALIGN,
@@ -633,14 +634,16 @@ extern "C" int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void*
   else RF_LNB(6);
 #undef RF_LNB
   RF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, st, (const float*)partials, nw, 2 * D, d_shift, d_scale, D);
-  RF_LAUNCH_CHECK();
+  if (d_scale != nullptr) {   // (the modulation rows of a stream without LoRA on its AdaLN linear need no gradient)
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(2 * D, 64)), dim3(256), 0, st, (const float*)partials, nw, 2 * D, d_shift, d_scale, D);
+    RF_LAUNCH_CHECK();
+  }
   return RF_OK;
 }
 
 extern "C" int rf_gate_bwd(const void* dy, int64_t lddy, const void* f, int64_t ldf, const void* gate, void* df, int64_t lddf, int32_t rows,
                            int32_t D, float* d_gate, float* partials, int64_t partials_bytes, void* stream) {
-  RF_REQUIRE(dy && f && gate && df && d_gate && partials, RF_ERR_NULL, "rf_gate_bwd: NULL operand");
+  RF_REQUIRE(dy && f && gate && df && partials, RF_ERR_NULL, "rf_gate_bwd: NULL operand");   // d_gate NULL: the column sum is not wanted
   RF_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 6 * 512 && lddy % 8 == 0 && ldf % 8 == 0 && lddf % 8 == 0, RF_ERR_SHAPE,
              "rf_gate_bwd: rows=%d D=%d", rows, D);
   RF_REQUIRE(aligned16(dy) && aligned16(f) && aligned16(gate) && aligned16(df), RF_ERR_ALIGN, "rf_gate_bwd: 16-byte alignment");
@@ -658,8 +661,10 @@ extern "C" int rf_gate_bwd(const void* dy, int64_t lddy, const void* f, int64_t 
   else RF_GB(6);
 #undef RF_GB
   RF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, (const float*)partials, nw, D, d_gate, d_gate, D);
-  RF_LAUNCH_CHECK();
+  if (d_gate != nullptr) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(D, 64)), dim3(256), 0, st, (const float*)partials, nw, D, d_gate, d_gate, D);
+    RF_LAUNCH_CHECK();
+  }
   return RF_OK;
 }
 

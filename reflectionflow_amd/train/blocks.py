@@ -75,27 +75,53 @@ def single_weights(block) -> TrainWeights:
     return tw
 
 
+class _FuseLora(torch.autograd.Function):
+    """(A_pad [r_pad, K], Bs_pad [N, r_pad]) from the LoRA parameters of sibling linears: A = the lora_A weights stacked along r,
+    Bs = block-diagonal of scaling * lora_B (one block per linear along N, one column range per (linear, adapter) along r).  As
+    torch ops (cat / mul / block_diag / pad, and their autograd) this was ~25 small launches per LoRA site and step forward plus as
+    many backward -- 10 % of a training step; here it is two zero-fills plus one copy and one scaled copy per (linear, adapter), and
+    the backward hands back VIEWS of dA and one scaled copy of each dB block."""
+
+    @staticmethod
+    def forward(ctx, layout, *params):
+        # layout: (K, N, r_pad, [(n0, n, r0, r, scaling) per (linear, adapter), in parameter order]); params = A_0, B_0, A_1, B_1, ...
+        K_, N, r_pad, entries = layout
+        ref = params[0]
+        A = torch.zeros(r_pad, K_, dtype=ref.dtype, device=ref.device)
+        B = torch.zeros(N, r_pad, dtype=ref.dtype, device=ref.device)
+        for i, (n0, n, r0, r, sc) in enumerate(entries):
+            A[r0:r0 + r].copy_(params[2 * i])
+            torch.mul(params[2 * i + 1], sc, out=B[n0:n0 + n, r0:r0 + r])
+        ctx.entries = entries
+        return A, B
+
+    @staticmethod
+    def backward(ctx, dA, dB):
+        grads = [None]
+        for i, (n0, n, r0, r, sc) in enumerate(ctx.entries):
+            grads.append(dA[r0:r0 + r] if ctx.needs_input_grad[1 + 2 * i] else None)
+            grads.append(dB[n0:n0 + n, r0:r0 + r] * sc if ctx.needs_input_grad[2 + 2 * i] else None)
+        return tuple(grads)
+
+
 def fused_lora(linears, device=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """(A [r_pad, K], Bs [N, r_pad]) of sibling linears fused along N -- the layout of engine._fused_lora -- built with torch
-    ops from the modules' PARAMETERS, so autograd carries the gradients of the fused tensors back to every lora_A / lora_B."""
+    """(A [r_pad, K], Bs [N, r_pad]) of sibling linears fused along N -- the layout of engine._fused_lora -- as ONE autograd node over
+    the modules' PARAMETERS, so the gradients of the fused tensors reach every lora_A / lora_B."""
     from ..flux.modules import LoraLinear
     if not any(isinstance(l, LoraLinear) for l in linears):
         return None, None
-    As, Bs = [], []
+    entries, params = [], []
+    n0 = r0 = 0
     for l in linears:
         if isinstance(l, LoraLinear):
-            As.append(torch.cat([l.lora_A[a].weight for a in l.active_adapters], 0))
-            Bs.append(torch.cat([l.lora_B[a].weight * l.scaling[a] for a in l.active_adapters], 1))
-        else:
-            As.append(torch.zeros(0, l.in_features, dtype=l.weight.dtype, device=l.weight.device))
-            Bs.append(torch.zeros(l.out_features, 0, dtype=l.weight.dtype, device=l.weight.device))
-    A = torch.cat(As, 0)
-    B = torch.block_diag(*Bs)
-    r = A.shape[0]
-    r_pad = (r + 63) // 64 * 64
-    A = torch.nn.functional.pad(A, (0, 0, 0, r_pad - r))
-    B = torch.nn.functional.pad(B, (0, r_pad - r))
-    return A.contiguous(), B.contiguous()
+            for a in l.active_adapters:
+                wa, wb = l.lora_A[a].weight, l.lora_B[a].weight
+                entries.append((n0, l.out_features, r0, wa.shape[0], float(l.scaling[a])))
+                params += [wa, wb]
+                r0 += wa.shape[0]
+        n0 += l.out_features
+    r_pad = (r0 + 63) // 64 * 64
+    return _FuseLora.apply((linears[0].in_features, n0, r_pad, tuple(entries)), *params)
 
 
 # ------------------------------------------------------------------------------------------------------------------ helpers
@@ -199,14 +225,17 @@ def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_im
     return [Y[s.sl] for s in st]
 
 
-def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor], cos, sin, lora: dict):
-    """-> (dxs [per stream], dmods [per stream, bf16 [6 D]], dlora {"qkv": (dA, dBs) | None, ...})"""
+def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor], cos, sin, lora: dict,
+                          need_dmod: Optional[Sequence[bool]] = None):
+    """-> (dxs [per stream], dmods [per stream, bf16 [6 D] or None], dlora {"qkv": (dA, dBs) | None, ...}).  need_dmod[i] = False:
+    stream i's modulation rows need no gradient (no LoRA on its AdaLN linear) -- its six column reductions are not launched."""
     D, H, mlp = tw.D, tw.heads, tw.mlp
     st: List[_Stream] = kp["st"]
     S, dev = kp["XN"].shape[0], kp["XN"].device
     new = lambda *shape: torch.empty(*shape, dtype=BF, device=dev)   # noqa: E731
     dlora: Dict[str, Optional[Tuple[torch.Tensor, torch.Tensor]]] = {"qkv": None, "out": None, "ff2": None}
     dmod = [[None] * 6 for _ in st]
+    nd = [True] * len(st) if need_dmod is None else list(need_dmod)
 
     def lora_of(tag, x_buf, dy_buf):
         """LoRA gradients of linear `tag` over its LoRA streams; returns {stream index: dT} for the dX GEMM."""
@@ -226,7 +255,7 @@ def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     # y = x1 + gate_mlp o f
     DF = new(S, D)
     for i, (s, dy) in enumerate(zip(st, dys)):
-        _, dmod[i][5] = K.gate_bwd(dy.contiguous(), kp["FF"][s.sl], s.mod[5], out=DF[s.sl])
+        _, dmod[i][5] = K.gate_bwd(dy.contiguous(), kp["FF"][s.sl], s.mod[5], out=DF[s.sl], need_dmod=nd[i])
     dTs, A = lora_of("ff2", kp["HH"], DF)
     DH = new(S, mlp)
     _dx_grouped(st, DF, [(tw, s.ff2[0], None) for s in st], mlp, DH, dTs, A)
@@ -235,11 +264,12 @@ def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     _dx_grouped(st, DZ1, [(tw, s.ff1[0], None) for s in st], D, DXN2)
     DX1 = new(S, D)
     for i, (s, dy) in enumerate(zip(st, dys)):
-        _, dmod[i][4], dmod[i][3] = K.layernorm_modulate_bwd(kp["X1"][s.sl], DXN2[s.sl], s.mod[4], dres=dy.contiguous(), out=DX1[s.sl])
+        _, dmod[i][4], dmod[i][3] = K.layernorm_modulate_bwd(kp["X1"][s.sl], DXN2[s.sl], s.mod[4], dres=dy.contiguous(), out=DX1[s.sl],
+                                                             need_dmod=nd[i])
     # x1 = x + gate_msa o a_out
     DAO = new(S, D)
     for i, s in enumerate(st):
-        _, dmod[i][2] = K.gate_bwd(DX1[s.sl], kp["AOUT"][s.sl], s.mod[2], out=DAO[s.sl])
+        _, dmod[i][2] = K.gate_bwd(DX1[s.sl], kp["AOUT"][s.sl], s.mod[2], out=DAO[s.sl], need_dmod=nd[i])
     dTs, A = lora_of("out", kp["ATT"], DAO)
     DATT = new(S, D)
     _dx_grouped(st, DAO, [(tw, s.out[0], None) for s in st], D, DATT, dTs, A)
@@ -251,9 +281,9 @@ def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     _dx_grouped(st, DRAW, [(tw, s.qkv[0], None) for s in st], D, DXN, dTs, A)
     dxs = []
     for i, s in enumerate(st):
-        dx, dmod[i][1], dmod[i][0] = K.layernorm_modulate_bwd(s.x, DXN[s.sl], s.mod[1], dres=DX1[s.sl])
+        dx, dmod[i][1], dmod[i][0] = K.layernorm_modulate_bwd(s.x, DXN[s.sl], s.mod[1], dres=DX1[s.sl], need_dmod=nd[i])
         dxs.append(dx)
-    return dxs, [torch.cat(m).to(BF) for m in dmod], dlora
+    return dxs, [torch.cat(m).to(BF) if nd[i] else None for i, m in enumerate(dmod)], dlora
 
 
 class DoubleBlockFn(torch.autograd.Function):
@@ -278,7 +308,8 @@ class DoubleBlockFn(torch.autograd.Function):
         dys = [dy_txt if dy_txt is not None else zeros(x_txt), dy_img if dy_img is not None else zeros(x_img)]
         if ctx.has_cond:
             dys.append(dy_cond if dy_cond is not None else zeros(x_cond))
-        dxs, dmods, dl = double_train_backward(ctx.tw, kp, dys, cos, sin, lora)
+        nd = [ctx.needs_input_grad[5], ctx.needs_input_grad[6]] + ([ctx.needs_input_grad[7]] if ctx.has_cond else [])
+        dxs, dmods, dl = double_train_backward(ctx.tw, kp, dys, cos, sin, lora, need_dmod=nd)
         g = lambda tag, j: None if dl[tag] is None else dl[tag][j]   # noqa: E731
         return (None, None, dxs[0], dxs[1], dxs[2] if ctx.has_cond else None, dmods[0], dmods[1], dmods[2] if ctx.has_cond else None,
                 None, None, g("qkv", 0), g("qkv", 1), g("out", 0), g("out", 1), g("ff2", 0), g("ff2", 1))
@@ -329,16 +360,18 @@ def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, c
     return [Y[s.sl] for s in st]
 
 
-def single_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor], cos, sin, lora: dict):
+def single_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor], cos, sin, lora: dict,
+                          need_dmod: Optional[Sequence[bool]] = None):
     D, H, mlp = tw.D, tw.heads, tw.mlp
     st: List[_Stream] = kp["st"]
     S, dev = kp["XN"].shape[0], kp["XN"].device
     new = lambda *shape: torch.empty(*shape, dtype=BF, device=dev)   # noqa: E731
     dlora: Dict[str, Optional[Tuple[torch.Tensor, torch.Tensor]]] = {"qkv_mlp": None, "out": None}
     dmod = [[None] * 3 for _ in st]
+    nd = [True] * len(st) if need_dmod is None else list(need_dmod)
     DF = new(S, D)
     for i, (s, dy) in enumerate(zip(st, dys)):
-        _, dmod[i][2] = K.gate_bwd(dy.contiguous(), kp["FF"][s.sl], s.mod[2], out=DF[s.sl])
+        _, dmod[i][2] = K.gate_bwd(dy.contiguous(), kp["FF"][s.sl], s.mod[2], out=DF[s.sl], need_dmod=nd[i])
     # f = [att | hm] W_out^T (+ LoRA):  d[att | hm] = df W_out (+ dT A)
     A_o, B_o = lora.get("out", (None, None))
     dTs = {}
@@ -368,9 +401,9 @@ def single_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     _dx_grouped(st, DZ, [(tw, "w_qkv_mlp", None) for _ in st], D, DXN, dTs, A_q)
     dxs = []
     for i, (s, dy) in enumerate(zip(st, dys)):
-        dx, dmod[i][1], dmod[i][0] = K.layernorm_modulate_bwd(s.x, DXN[s.sl], s.mod[1], dres=dy.contiguous())
+        dx, dmod[i][1], dmod[i][0] = K.layernorm_modulate_bwd(s.x, DXN[s.sl], s.mod[1], dres=dy.contiguous(), need_dmod=nd[i])
         dxs.append(dx)
-    return dxs, [torch.cat(m).to(BF) for m in dmod], dlora
+    return dxs, [torch.cat(m).to(BF) if nd[i] else None for i, m in enumerate(dmod)], dlora
 
 
 class SingleBlockFn(torch.autograd.Function):
@@ -393,7 +426,8 @@ class SingleBlockFn(torch.autograd.Function):
         dys = [dy_main if dy_main is not None else torch.zeros_like(x_main)]
         if ctx.has_cond:
             dys.append(dy_cond if dy_cond is not None else torch.zeros_like(x_cond))
-        dxs, dmods, dl = single_train_backward(ctx.tw, kp, dys, cos, sin, lora)
+        nd = [ctx.needs_input_grad[4]] + ([ctx.needs_input_grad[5]] if ctx.has_cond else [])
+        dxs, dmods, dl = single_train_backward(ctx.tw, kp, dys, cos, sin, lora, need_dmod=nd)
         g = lambda tag, j: None if dl[tag] is None else dl[tag][j]   # noqa: E731
         return (None, None, dxs[0], dxs[1] if ctx.has_cond else None, dmods[0], dmods[1] if ctx.has_cond else None, None, None,
                 g("qkv_mlp", 0), g("qkv_mlp", 1), g("out", 0), g("out", 1))

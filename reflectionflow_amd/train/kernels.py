@@ -100,32 +100,33 @@ def attention_bwd(a: AttnOperands, o: torch.Tensor, dout: torch.Tensor,
     return dq, dk, dv
 
 
-def layernorm_modulate_bwd(x, dy, scale, dres: Optional[torch.Tensor] = None, eps: float = 1e-6, out: Optional[torch.Tensor] = None):
-    """-> (dx bf16 [rows, D] (+ dres), d_scale fp32 [D], d_shift fp32 [D])"""
+def layernorm_modulate_bwd(x, dy, scale, dres: Optional[torch.Tensor] = None, eps: float = 1e-6, out: Optional[torch.Tensor] = None,
+                           need_dmod: bool = True):
+    """-> (dx bf16 [rows, D] (+ dres), d_scale fp32 [D], d_shift fp32 [D]); need_dmod=False: (dx, None, None), no column reduction"""
     x, dy = _rows2d(x, "x"), _rows2d(dy, "dy")
     rows, D = x.shape
     dx = torch.empty(rows, D, dtype=BF, device=x.device) if out is None else _rows2d(out, "dx")
-    dsc = torch.empty(D, dtype=torch.float32, device=x.device)
-    dsh = torch.empty_like(dsc)
+    dsc = torch.empty(D, dtype=torch.float32, device=x.device) if need_dmod else None
+    dsh = torch.empty_like(dsc) if need_dmod else None
     part = _partials(x.device, D)
     if dres is not None:
         dres = _rows2d(dres, "dres")
     L.check(L.load().rf_layernorm_modulate_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), ptr(dres),
                                                dres.stride(0) if dres is not None else 0, dx.data_ptr(), dx.stride(0), rows, D,
-                                               _chk(scale, "scale").data_ptr(), eps, dsc.data_ptr(), dsh.data_ptr(), part.data_ptr(),
+                                               _chk(scale, "scale").data_ptr(), eps, ptr(dsc), ptr(dsh), part.data_ptr(),
                                                part.numel() * 4, stream_ptr()), "rf_layernorm_modulate_bwd")
     return dx, dsc, dsh
 
 
-def gate_bwd(dy, f, gate, out: Optional[torch.Tensor] = None):
-    """y = res + gate o f  ->  (df = gate o dy  bf16, d_gate fp32 [D])"""
+def gate_bwd(dy, f, gate, out: Optional[torch.Tensor] = None, need_dmod: bool = True):
+    """y = res + gate o f  ->  (df = gate o dy  bf16, d_gate fp32 [D]); need_dmod=False: (df, None), no column reduction"""
     dy, f = _rows2d(dy, "dy"), _rows2d(f, "f")
     rows, D = dy.shape
     df = torch.empty(rows, D, dtype=BF, device=dy.device) if out is None else _rows2d(out, "df")
-    dg = torch.empty(D, dtype=torch.float32, device=dy.device)
+    dg = torch.empty(D, dtype=torch.float32, device=dy.device) if need_dmod else None
     part = _partials(dy.device, D)
     L.check(L.load().rf_gate_bwd(dy.data_ptr(), dy.stride(0), f.data_ptr(), f.stride(0), _chk(gate, "gate").data_ptr(), df.data_ptr(),
-                                 df.stride(0), rows, D, dg.data_ptr(), part.data_ptr(), part.numel() * 4, stream_ptr()), "rf_gate_bwd")
+                                 df.stride(0), rows, D, ptr(dg), part.data_ptr(), part.numel() * 4, stream_ptr()), "rf_gate_bwd")
     return df, dg
 
 
