@@ -149,7 +149,7 @@ def test_gemm_tn_skinny(dev, S, N, R):
     assert torch.equal(K.gemm_tn(big, sk), out)
 
 
-@pytest.mark.parametrize("H,S", [(2, 112), (3, 256), (2, 1000), (24, 1024), (4, 4608)])
+@pytest.mark.parametrize("H,S", [(2, 112), (3, 256), (2, 1000), (24, 1024), (4, 4608), (8, 2304)])   # (8, 2304): the split-key launches qualify
 def test_attention_bwd_vs_fp32_autograd(dev, H, S):
     from reflectionflow_amd import ops
     from reflectionflow_amd.train import kernels as K
