@@ -374,14 +374,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
 // ---- dK, dV -----------------------------------------------------------------------------------------------------------------
 // grid (s_pad / (64 KT), heads), 256 threads; a wave owns KT tiles of 16 keys (their k, v fragments stay in registers).
 // LDS per step of 32 queries: q~ rows | dO rows | q~^T tile | dO^T tile | lse[32] | D[32].
-template <int KT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qt,
+// RING = LDS ring slots, WPE = waves per SIMD the register budget must allow (2: two workgroups share a CU)
+template <int KT, int RING = AB_RING, int WPE = 1>
+__global__ __launch_bounds__(256, WPE) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ qt,
                                                            const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                            const bf16_t* __restrict__ dout, int64_t lddo, const bf16_t* __restrict__ dot,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int S, int s_pad) {
   constexpr int BUF = 4 * AB_ROWS + 512;                 // q~ rows | dO rows | q~^T tile | dO^T tile | lse2[64] | D[64]
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // AB_RING * BUF = 133 120 bytes (dynamic)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // RING * BUF = 133 120 bytes (dynamic)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
   const int head = blockIdx.y;
   const int64_t hb = (int64_t)head * s_pad;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   dma_row_offsets<4>(off_do, (uint32_t)(lddo * 2), w, lane);
   constexpr int PER = 10;                                   // DMA instructions per stage and wave
   auto issue = [&](const int st) {
-    char* buf = smem + (st % AB_RING) * BUF;
+    char* buf = smem + (st % RING) * BUF;
     const int q0 = st * 32;
     dma_rows<4>(r_q, buf, off_q, (uint32_t)((hb + q0) * 256), w);
     dma_rows<4>(r_do, buf + AB_ROWS, off_do, (uint32_t)(((int64_t)q0 * lddo + head * 128) * 2), w);
@@ -424,14 +425,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     RF_BUF_LOAD_LDS4(r_d, (lds_void*)(buf + 4 * AB_ROWS + 256), (uint32_t)(lane * 4), (uint32_t)((hb + q0) * 4));
   };
 #pragma unroll
-  for (int st = 0; st < AB_RING - 1; ++st)
+  for (int st = 0; st < RING - 1; ++st)
     if (st < nsteps) issue(st);
   for (int st = 0; st < nsteps; ++st) {
-    dma_wait<PER>(min(AB_RING - 2, nsteps - 1 - st));     // stage st has landed (this wave's pieces) ...
+    dma_wait<PER>(min(RING - 2, nsteps - 1 - st));     // stage st has landed (this wave's pieces) ...
     __syncthreads();                                      // ... and everybody's; every wave is done with step st - 1
-    if (st + AB_RING - 1 < nsteps) issue(st + AB_RING - 1);   // into the slot step st - 1 used
+    if (st + RING - 1 < nsteps) issue(st + RING - 1);   // into the slot step st - 1 used
     __builtin_amdgcn_sched_barrier(0);
-    const char* ql = smem + (st % AB_RING) * BUF;
+    const char* ql = smem + (st % RING) * BUF;
     const char* dol = ql + AB_ROWS;
     const char* qtl = ql + 2 * AB_ROWS;
     const char* dotl = ql + 3 * AB_ROWS;
@@ -549,6 +550,7 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
 #undef RF_DQ_ATTR
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<2, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DKV_LDS / 2));
     attr_set = true;
   }
 #define RF_DQ_LAUNCH(QT_, NW_)                                                                                                          \
@@ -572,12 +574,20 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
 #undef RF_DQ_LAUNCH
 #undef RF_DQ_ALL
   RF_LAUNCH_CHECK();
-#define RF_DKV_LAUNCH(KT_)                                                                                                              \
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<KT_>, dim3((sp + 64 * KT_ - 1) / (64 * KT_), H), dim3(256), DKV_LDS, st, (const bf16_t*)d->q,  \
-                     (const bf16_t*)d->qt, (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->dout, d->lddo,                   \
-                     (const bf16_t*)d->dot, (const float*)d->lse, (const float*)d->dsum, (bf16_t*)d->dk, (bf16_t*)d->dv, S, sp)
-  if (cost(128) < cost(192)) RF_DKV_LAUNCH(2);
-  else RF_DKV_LAUNCH(3);
+#define RF_DKV_LAUNCH(KERNEL, KT_, LDS_)                                                                                                  \
+  hipLaunchKernelGGL(KERNEL, dim3((sp + 64 * KT_ - 1) / (64 * KT_), H), dim3(256), LDS_, st, (const bf16_t*)d->q, (const bf16_t*)d->qt,   \
+                     (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->dout, d->lddo, (const bf16_t*)d->dot,                    \
+                     (const float*)d->lse, (const float*)d->dsum, (bf16_t*)d->dk, (bf16_t*)d->dv, S, sp)
+  {
+    // 128-key workgroups also come in a two-per-CU form (2-slot ring, <= 256 registers, 12 dwords of scratch outside the MFMA
+    // section): twice the slots per round, each workgroup 1.77x slower for sharing its CU (S = 2560 x 24 heads: 480 workgroups in
+    // ONE round of 512 slots, 210 us against 237 us as two rounds of 256)
+    const int64_t wg128 = (int64_t)((sp + 127) / 128) * H;
+    const int64_t c2 = ((wg128 + 2 * num_cus - 1) / (2 * num_cus)) * 226;   // 128 rows x 1.77
+    if (c2 < cost(128) && c2 < cost(192)) RF_DKV_LAUNCH((attn_bwd_dkv_kernel<2, 2, 2>), 2, DKV_LDS / 2);
+    else if (cost(128) < cost(192)) RF_DKV_LAUNCH((attn_bwd_dkv_kernel<2>), 2, DKV_LDS);
+    else RF_DKV_LAUNCH((attn_bwd_dkv_kernel<3>), 3, DKV_LDS);
+  }
 #undef RF_DKV_LAUNCH
   RF_LAUNCH_CHECK();
   return RF_OK;
