@@ -132,3 +132,29 @@ def test_fused_lora_node_equals_the_torch_op_construction():
         for x, y in zip(torch.autograd.grad([A, B], ps, [gA, gB]), torch.autograd.grad([A0, B0], ps, [gA, gB])):
             assert torch.allclose(x, y)
     assert fused_lora([lin(8, 8)]) == (None, None)
+
+
+def test_batched_adaln_lora_terms_equal_the_per_block_form():
+    """train.step._lora_terms_batched: the LoRA terms of all blocks' AdaLN linears from ONE stacked product must equal the per-linear
+    F.linear(F.linear(s, A), B) * scaling, values and parameter gradients; mixed shapes fall back to the per-linear form."""
+    import torch.nn as nn
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.train.step import _lora_term, _lora_terms_batched
+    torch.manual_seed(1)
+
+    def lin(i, o, r):
+        l = M.LoraLinear(nn.Linear(i, o), r, 2 * r)
+        for p in (l.lora_A["default"].weight, l.lora_B["default"].weight):
+            nn.init.normal_(p)
+        return l
+    s = torch.randn(1, 64)
+    for lins in ([lin(64, 96, 8) for _ in range(5)], [lin(64, 96, 8), lin(64, 48, 4)], [lin(64, 96, 8), nn.Linear(64, 96)]):
+        got = _lora_terms_batched(lins, s)
+        ref = [None if (t := _lora_term(l, s)) is None else t[0] for l in lins]
+        ps = [p for l in lins if isinstance(l, M.LoraLinear) for p in (l.lora_A["default"].weight, l.lora_B["default"].weight)]
+        live = [(a, b) for a, b in zip(got, ref) if b is not None]
+        assert all((a is None) == (b is None) for a, b in zip(got, ref))
+        assert all(torch.allclose(a, b, atol=1e-5) for a, b in live)
+        gs = [torch.randn_like(b) for _, b in live]
+        for x, y in zip(torch.autograd.grad([a for a, _ in live], ps, gs), torch.autograd.grad([b for _, b in live], ps, gs)):
+            assert torch.allclose(x, y, atol=1e-4)
