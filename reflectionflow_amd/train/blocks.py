@@ -133,14 +133,21 @@ class _Stream:
         self.qkv, self.out, self.ff1, self.ff2 = qkv, out, ff1, ff2      # weight names (w, b) of this stream
 
 
-def _grouped(streams, A_buf, names, N, out_buf, loras=None, keep=None, tag=""):
-    """One grouped STORE launch: per stream  out = A W^T + b (+ (A lora_A^T) lora_Bs^T on LoRA streams)."""
+def _grouped(streams, A_buf, names, N, out_buf, loras=None, keep=None, tag="", tc=None):
+    """One grouped STORE launch: per stream  out = A W^T + b (+ (A lora_A^T) lora_Bs^T on LoRA streams).  tc: the block's cache of
+    LoRA down-projections T = A lora_A^T -- the forward fills it, the recompute inside the backward takes them from it (they are a
+    few hundred KB per site, and the only part of a block the checkpoint keeps besides its inputs)."""
     groups = []
     for i, (s, (tw, wn, bn)) in enumerate(zip(streams, names)):
         a = A_buf[s.sl]
         segs = [Seg(a, tw.w(wn))]
         if s.lora and loras is not None and loras[0] is not None:
-            t = ops.linear(a, loras[0])
+            key = f"T_{tag}_{i}"
+            t = tc.get(key) if tc is not None else None
+            if t is None:
+                t = ops.linear(a, loras[0])
+                if tc is not None:
+                    tc[key] = t
             segs.append(Seg(t, loras[1]))
             if keep is not None:
                 keep[f"T_{tag}_{i}"] = t
@@ -190,7 +197,7 @@ def _double_streams(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_img, mo
 
 
 def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora: dict,
-                         latent_lora: bool = False, keep: Optional[dict] = None):
+                         latent_lora: bool = False, keep: Optional[dict] = None, tc: Optional[dict] = None):
     """Training form of block.py:173-272 for ONE sample: x_* [rows, D] bf16, mod_* [6 D] bf16, lora = {"qkv": (A, Bs), "out": ...,
     "ff2": ...} (entries may be (None, None)).  Returns [y_txt, y_img, y_cond?]; `keep` (a dict) receives the intermediates."""
     D, H, mlp = tw.D, tw.heads, tw.mlp
@@ -200,14 +207,14 @@ def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_im
     XN, RAW = new(S, D), new(S, 3 * D)
     for s in st:
         ops.layernorm_modulate(s.x, s.mod[1], s.mod[0], out=XN[s.sl])
-    _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D, RAW, lora.get("qkv"), keep, "qkv")
+    _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D, RAW, lora.get("qkv"), keep, "qkv", tc)
     norms = (tw.w("norm_q"), tw.w("norm_k"), tw.w("norm_added_q"), tw.w("norm_added_k"))
     a = K.qkv_train_fwd(RAW, H, st[0].rows, norms, cos, sin)
     # (recompute inside the backward: the forward kernel also emits the row statistics its backward needs)
     LSE = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev) if keep is not None else None
     ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0, lse=LSE)
     AOUT = new(S, D)
-    _grouped(st, ATT, [(tw,) + s.out for s in st], D, AOUT, lora.get("out"), keep, "out")
+    _grouped(st, ATT, [(tw,) + s.out for s in st], D, AOUT, lora.get("out"), keep, "out", tc)
     X1, XN2 = new(S, D), new(S, D)
     for s in st:
         K.gate_residual(AOUT[s.sl], s.mod[2], s.x, out=X1[s.sl])
@@ -216,7 +223,7 @@ def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_im
     _grouped(st, XN2, [(tw,) + s.ff1 for s in st], mlp, Z1)
     HH = K.gelu(Z1)
     FF = new(S, D)
-    _grouped(st, HH, [(tw,) + s.ff2 for s in st], D, FF, lora.get("ff2"), keep, "ff2")
+    _grouped(st, HH, [(tw,) + s.ff2 for s in st], D, FF, lora.get("ff2"), keep, "ff2", tc)
     Y = new(S, D)
     for s in st:
         K.gate_residual(FF[s.sl], s.mod[5], X1[s.sl], out=Y[s.sl])
@@ -293,7 +300,8 @@ class DoubleBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tw, latent_lora, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo):
         lora = {"qkv": (lo[0], lo[1]), "out": (lo[2], lo[3]), "ff2": (lo[4], lo[5])}
-        ys = double_train_forward(tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, latent_lora)
+        ctx.tc = {}
+        ys = double_train_forward(tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, latent_lora, tc=ctx.tc)
         ctx.tw, ctx.latent_lora, ctx.has_cond = tw, latent_lora, x_cond is not None
         ctx.save_for_backward(x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo)
         return (ys[0], ys[1], ys[2] if x_cond is not None else None)
@@ -303,7 +311,7 @@ class DoubleBlockFn(torch.autograd.Function):
         x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo = ctx.saved_tensors
         lora = {"qkv": (lo[0], lo[1]), "out": (lo[2], lo[3]), "ff2": (lo[4], lo[5])}
         kp: dict = {}
-        double_train_forward(ctx.tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp)   # recompute
+        double_train_forward(ctx.tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp, tc=ctx.tc)   # recompute
         zeros = lambda x: torch.zeros_like(x)   # noqa: E731
         dys = [dy_txt if dy_txt is not None else zeros(x_txt), dy_img if dy_img is not None else zeros(x_img)]
         if ctx.has_cond:
@@ -317,7 +325,7 @@ class DoubleBlockFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------------------------ SingleStream
 def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, cos, sin, lora: dict, latent_lora: bool = False,
-                         keep: Optional[dict] = None):
+                         keep: Optional[dict] = None, tc: Optional[dict] = None):
     """Training form of block.py:275-333 for ONE sample: x_main = [text; image] rows, mod_* [3 D] = (shift, scale, gate);
     lora = {"qkv_mlp": (A [r, D], Bs [3 D + mlp, r]), "out": (A [r, D + mlp], Bs [D, r])}."""
     D, H, mlp = tw.D, tw.heads, tw.mlp
@@ -331,7 +339,7 @@ def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, c
     XN, Z = new(S, D), new(S, 3 * D + mlp)
     for s in st:
         ops.layernorm_modulate(s.x, s.mod[1], s.mod[0], out=XN[s.sl])
-    _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D + mlp, Z, lora.get("qkv_mlp"), keep, "qkv_mlp")
+    _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D + mlp, Z, lora.get("qkv_mlp"), keep, "qkv_mlp", tc)
     norms = (tw.w("norm_q"), tw.w("norm_k"), None, None)
     a = K.qkv_train_fwd(Z, H, 0, norms, cos, sin)
     # (recompute inside the backward: the forward kernel also emits the row statistics its backward needs)
@@ -345,8 +353,12 @@ def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, c
     for i, s in enumerate(st):
         segs = [Seg(ATT[s.sl], w_out[:, :D]), Seg(HM[s.sl], w_out[:, D:])]
         if s.lora and A_o is not None:
-            t = torch.empty(s.rows, A_o.shape[0], dtype=BF, device=dev)
-            ops.gemm([Group([Seg(ATT[s.sl], A_o[:, :D]), Seg(HM[s.sl], A_o[:, D:])], out=t)], A_o.shape[0], RF_EPI_STORE)
+            t = tc.get(f"T_out_{i}") if tc is not None else None
+            if t is None:
+                t = torch.empty(s.rows, A_o.shape[0], dtype=BF, device=dev)
+                ops.gemm([Group([Seg(ATT[s.sl], A_o[:, :D]), Seg(HM[s.sl], A_o[:, D:])], out=t)], A_o.shape[0], RF_EPI_STORE)
+                if tc is not None:
+                    tc[f"T_out_{i}"] = t
             segs.append(Seg(t, B_o))
             if keep is not None:
                 keep[f"T_out_{i}"] = t
@@ -412,7 +424,8 @@ class SingleBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tw, latent_lora, x_main, x_cond, mod_main, mod_cond, cos, sin, *lo):
         lora = {"qkv_mlp": (lo[0], lo[1]), "out": (lo[2], lo[3])}
-        ys = single_train_forward(tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, latent_lora)
+        ctx.tc = {}
+        ys = single_train_forward(tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, latent_lora, tc=ctx.tc)
         ctx.tw, ctx.latent_lora, ctx.has_cond = tw, latent_lora, x_cond is not None
         ctx.save_for_backward(x_main, x_cond, mod_main, mod_cond, cos, sin, *lo)
         return (ys[0], ys[1] if x_cond is not None else None)
@@ -422,7 +435,7 @@ class SingleBlockFn(torch.autograd.Function):
         x_main, x_cond, mod_main, mod_cond, cos, sin, *lo = ctx.saved_tensors
         lora = {"qkv_mlp": (lo[0], lo[1]), "out": (lo[2], lo[3])}
         kp: dict = {}
-        single_train_forward(ctx.tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp)               # recompute
+        single_train_forward(ctx.tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp, tc=ctx.tc)    # recompute
         dys = [dy_main if dy_main is not None else torch.zeros_like(x_main)]
         if ctx.has_cond:
             dys.append(dy_cond if dy_cond is not None else torch.zeros_like(x_cond))
