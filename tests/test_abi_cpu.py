@@ -40,13 +40,14 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
     from reflectionflow_amd import _lib
-    structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_attn_desc", "rf_lora_seg", "rf_double_block_weights",
+    structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_attn_desc", "rf_attn_bwd_desc", "rf_lora_seg", "rf_double_block_weights",
                "rf_single_block_weights", "rf_flux_dims", "rf_workspace", "rf_flux_model"] + \
         ["rf_vae_conv", "rf_vae_norm", "rf_vae_resnet", "rf_vae_attn", "rf_vae_weights", "rf_t5_layer", "rf_t5_weights", "rf_clip_layer", "rf_clip_weights"]
     src = '#include "rf_flux.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){\n' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));\n' for s in structs) + \
         'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\n' \
-        'printf("off_sched %zu\\n", offsetof(rf_gemm_desc, schedule));\nprintf("off_kernel %zu\\n", offsetof(rf_attn_desc, kernel));\nreturn 0;}\n'
+        'printf("off_sched %zu\\n", offsetof(rf_gemm_desc, schedule));\nprintf("off_kernel %zu\\n", offsetof(rf_attn_desc, kernel));\n' \
+        'printf("off_lse %zu\\n", offsetof(rf_attn_desc, lse));\nprintf("off_given %zu\\n", offsetof(rf_attn_bwd_desc, lse_given));\nreturn 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -59,6 +60,7 @@ def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
     assert int(out["off_out"]) == _lib.rf_gemm_group.out.offset
     assert int(out["off_sched"]) == _lib.rf_gemm_desc.schedule.offset
     assert int(out["off_kernel"]) == _lib.rf_attn_desc.kernel.offset
+    assert int(out["off_lse"]) == _lib.rf_attn_desc.lse.offset and int(out["off_given"]) == _lib.rf_attn_bwd_desc.lse_given.offset
 
 
 def test_no_kernel_selecting_switch_is_exported(lib):
