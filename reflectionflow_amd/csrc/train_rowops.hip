@@ -411,10 +411,13 @@ static int row_blocks(int rows) {
 // rf_gemm_bf16 meant writing dY^T and x^T out first (two full-size transposes per LoRA site and step: 6 % of a training step at the
 // reference's shape).  Here the transpose happens on the way INTO the LDS: a thread's 16-byte load (8 columns of one token) is
 // scattered as eight 2-byte writes into a [column][32 tokens] image, whose rows are then exactly the 16-byte MFMA fragments
-// (16x16x32: lane (g, i) <- row i, tokens 8 g .. 8 g + 7; chunk g of row n sits at g ^ ((n >> 2) & 3): conflict-free reads).
+// (16x16x32: lane (g, i) <- row i, tokens 8 g .. 8 g + 7; chunk g of row n sits at g ^ {0, 2, 3, 1}[(n >> 2) & 3]: conflict-free reads).
 // grid (ceil(N / 128), chunks of TN_CHUNK tokens): fp32 partial tiles [chunk][N][R] -> tn_reduce_kernel sums them in chunk order
 // (deterministic) and writes bf16, optionally transposed ([R][N]: dA).
 constexpr int TN_COLS = 128, TN_CHUNK = 128;
+// chunk g of a 64-byte image row n sits at position g ^ tn_swz((n >> 2) & 3), {0, 2, 3, 1}: conflict-free under ds_read_b128's
+// NON-contiguous 16-lane groups (the plain g ^ ((n >> 2) & 3) is 2-way conflicted there; tests/test_lds_layouts_cpu.py holds the model)
+__device__ __forceinline__ int tn_swz(int h) { return (0x78 >> (2 * h)) & 3; }
 __device__ __forceinline__ f32x4 mfma16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
       const int n = col0 + e;
       const uint32_t word = v[e >> 1];
       const uint16_t h = (e & 1) ? (uint16_t)(word >> 16) : (uint16_t)(word & 0xffffu);
-      *(uint16_t*)(img + n * 64 + (((tok >> 3) ^ ((n >> 2) & 3)) << 4) + (tok & 7) * 2) = h;
+      *(uint16_t*)(img + n * 64 + (((tok >> 3) ^ tn_swz((n >> 2) & 3)) << 4) + (tok & 7) * 2) = h;
     }
   };
   auto commit = [&](const int buf) {
@@ -489,12 +492,12 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int b = 0; b < RT; ++b) {
       const int j = 16 * b + l15;
-      bf[b] = *(const bf16x8*)(skT[buf] + j * 64 + ((g ^ ((j >> 2) & 3)) << 4));
+      bf[b] = *(const bf16x8*)(skT[buf] + j * 64 + ((g ^ tn_swz((j >> 2) & 3)) << 4));
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int n = 16 * (2 * w + a) + l15;                    // this wave's column tiles 2 w, 2 w + 1
-      const bf16x8 af = *(const bf16x8*)(bigT[buf] + n * 64 + ((g ^ ((n >> 2) & 3)) << 4));
+      const bf16x8 af = *(const bf16x8*)(bigT[buf] + n * 64 + ((g ^ tn_swz((n >> 2) & 3)) << 4));
 #pragma unroll
       for (int b = 0; b < RT; ++b) acc[a][b] = mfma16x16x32(af, bf[b], acc[a][b]);
     }
