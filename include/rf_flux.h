@@ -35,7 +35,7 @@ typedef enum rf_status {
 } rf_status;
 
 const char* rf_last_error(void);
-/* ABI version: bump on any struct/signature change (v12: rf_attn_desc.lse, rf_attn_bwd_desc.lse_given). */
+/* ABI version: bump on any struct/signature change (v13: rf_attn_bwd_desc.kernel, rf_lora_adamw / rf_lora_prodigy). */
 int rf_abi_version(void);
 /* Returns 950 when the library was compiled for gfx950. */
 int rf_target_arch(void);
@@ -516,6 +516,15 @@ int rf_qkv_train_bwd(const void* raw, int64_t ld_raw, int32_t heads, int32_t S, 
  *   q (scaled), k, v, qt, kt from rf_qkv_train_fwd;  o = the forward's output, dout = its gradient, both [S][ld] token-major;
  *   dq, dk, dv: [heads][s_pad][128] bf16;  dot ([heads][s_pad/32][128][32] bf16), lse, dsum (fp32 [heads][s_pad]): scratch.
  * Three launches: D = rowsum(dO o O) + dO^T tiles; per 64 queries the row statistics then dq; per 128 keys dk, dv. */
+typedef enum rf_attn_bwd_kernel {
+  RF_ATTN_BWD_AUTO = 0,          /* per kernel: the form with the fewest CU rounds x rows for this (heads, s_pad)        */
+  RF_ATTN_BWD_DQ_256 = 1,        /* dq: 8 waves x 32 queries per workgroup                                             */
+  RF_ATTN_BWD_DQ_128 = 2,        /* dq: 4 waves x 32 queries                                                           */
+  RF_ATTN_BWD_DQ_192 = 3,        /* dq: 4 waves x 48 queries                                                           */
+  RF_ATTN_BWD_DKV_128 = 1 << 8,  /* dK / dV: 128 keys per workgroup, one workgroup per CU (4-slot ring)                 */
+  RF_ATTN_BWD_DKV_192 = 2 << 8,  /* dK / dV: 192 keys per workgroup                                                    */
+  RF_ATTN_BWD_DKV_128X2 = 3 << 8 /* dK / dV: 128 keys per workgroup, two workgroups per CU (2-slot ring)               */
+} rf_attn_bwd_kernel;
 typedef struct rf_attn_bwd_desc {
   const void *q, *k, *v, *qt, *kt;
   const void *o, *dout; int64_t ldo, lddo;
@@ -524,7 +533,8 @@ typedef struct rf_attn_bwd_desc {
   int32_t heads, S, s_pad, mode;
   int32_t lse_given;   /* 1: lse[heads][s_pad] holds the forward's row statistics for rows < S (rf_attn_desc.lse of the SAME q, k): the
                           dq kernel skips its own statistics pass over the keys (a quarter of its work).  0: lse is scratch. */
-  int32_t _pad;
+  int32_t kernel;      /* rf_attn_bwd_kernel: RF_ATTN_BWD_AUTO, or one dq form | one dK / dV form.  Every form gives the same gradients to
+                          rounding; the forms differ in queries / keys per workgroup, i.e. in how a (heads, S) fills the CUs. */
 } rf_attn_bwd_desc;
 int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream);
 
@@ -556,6 +566,26 @@ int rf_gemm_tn_skinny(const void* big, int64_t ld_big, const void* skinny, int64
 /* dst[c][r] = src[r][c], r < rows; zero for rows <= r < rows_pad (the K % 64 padding of a token-axis contraction) */
 int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, int32_t cols, void* dst, int64_t ld_dst,
                       int32_t rows_pad, void* stream);
+
+/* Optimizer update of the LoRA factors (train_flux/train/model.py:105-117: torch.optim.AdamW or prodigyopt.Prodigy over the LoRA
+ * parameters; config.yaml:55-61 ships Prodigy lr 1, use_bias_correction, safeguard_warmup, weight_decay 0.01) over ONE flat bucket:
+ *   param, grad : bf16 [n] (every LoRA factor / its gradient is a view into them; n % 8 == 0);
+ *   exp_avg, exp_avg_sq (, s) : bf16 [n] (what torch / prodigyopt keep for bf16 parameters) or fp32 [n] when state_fp32;
+ *   grad_scale  : multiplies every gradient on the way in (1 / world_size behind a SUM all-reduce: the averaging pass is fused away).
+ * rf_lora_adamw = one step of torch.optim.AdamW (decoupled decay, bias correction, amsgrad off); `step` is 1-based.
+ * rf_lora_prodigy = one step of Prodigy's Adam form (Mishchenko & Defazio 2023, Algorithm 4; option names and defaults of prodigyopt,
+ * which is not available offline: PARITY UNPINNED, restated in oracle/optim_oracle.py):  p0 = the parameters at step 0 (bf16 [n]);
+ * dstate = 8 doubles ON THE DEVICE {d, d_max, d_numerator, d_denom, d_hat, k, dlr of the last step, d0}, initialised by the caller to
+ * {d0, d0, 0, 0, d0, 0, 0, d0}: the distance estimate never crosses to the host inside a step (the package reads one .item() per
+ * parameter tensor), the two global sums are fixed-order two-stage sums over `partials` (rf_lora_prodigy_partials_bytes).
+ * beta3 <= 0 means sqrt(beta2).  Three launches: moments + partial sums, the new d (one workgroup), the parameter update. */
+int rf_lora_adamw(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, int64_t n, int32_t state_fp32, int32_t step,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int64_t rf_lora_prodigy_partials_bytes(int64_t n);
+int rf_lora_prodigy(void* param, const void* grad, void* exp_avg, void* exp_avg_sq, void* s, const void* p0, int64_t n,
+                    int32_t state_fp32, double* dstate, float lr, float beta1, float beta2, float beta3, float eps,
+                    float weight_decay, int32_t decouple, int32_t use_bias_correction, int32_t safeguard_warmup, float d_coef,
+                    float growth_rate, float grad_scale, float* partials, int64_t partials_bytes, void* stream);
 
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
  * shape with hipEvents on `stream`; returns average microseconds in *us. */

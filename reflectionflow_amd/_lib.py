@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -20,6 +20,9 @@ RF_SCHED_AUTO, RF_SCHED_TILE128, RF_SCHED_TILE256, RF_SCHED_STREAMK, RF_SCHED_PE
 RF_ATTN_AUTO, RF_ATTN_ONLINE128, RF_ATTN_ONLINE256 = 0, 1, 2
 RF_ATTN_BOUNDED32, RF_ATTN_BOUNDED16, RF_ATTN_BOUNDED16_SPLIT, RF_ATTN_LAGGED16, RF_ATTN_LAGGED16_SPLIT = 4, 5, 6, 8, 9
 RF_ATTN_BOUNDED16_MIX, RF_ATTN_LAGGED16_MIX = 10, 11
+# rf_attn_bwd_kernel (rf_attn_bwd_desc.kernel): one dq form | one dK / dV form, 0 = AUTO for that kernel
+RF_ATTN_BWD_AUTO, RF_ATTN_BWD_DQ_256, RF_ATTN_BWD_DQ_128, RF_ATTN_BWD_DQ_192 = 0, 1, 2, 3
+RF_ATTN_BWD_DKV_128, RF_ATTN_BWD_DKV_192, RF_ATTN_BWD_DKV_128X2 = 1 << 8, 2 << 8, 3 << 8
 
 
 class RFError(RuntimeError):
@@ -57,7 +60,7 @@ class rf_attn_desc(C.Structure):
 class rf_attn_bwd_desc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "qt", "kt", "o", "dout")] + [("ldo", C.c_int64), ("lddo", C.c_int64)] + [
         (n, C.c_void_p) for n in ("dq", "dk", "dv", "dot", "lse", "dsum")] + [
-        ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("mode", C.c_int32), ("lse_given", C.c_int32), ("_pad", C.c_int32)]
+        ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("mode", C.c_int32), ("lse_given", C.c_int32), ("kernel", C.c_int32)]
 
 
 class rf_w8(C.Structure):
@@ -208,6 +211,10 @@ _SIGS = {
     "rf_transpose_bf16": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int64, C.c_int32, _P]),
     "rf_gemm_tn_skinny_ws_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "rf_gemm_tn_skinny": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    "rf_lora_adamw": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "rf_lora_prodigy_partials_bytes": (C.c_int64, [C.c_int64]),
+    "rf_lora_prodigy": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P] + [C.c_float] * 6 + [C.c_int32] * 3 + [C.c_float] * 3 +
+                        [_P, C.c_int64, _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),
     "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int32)]),
@@ -215,7 +222,7 @@ _SIGS = {
 RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant", "attention_bwd")
 # read-only introspection (tests, bench); not part of the declared drop-in surface.  librf_flux.so exports NO kernel-selecting
 # switch: tests pin a kernel per launch through rf_gemm_desc.schedule / rf_attn_desc.kernel.
-_EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),
+_EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_attn_bwd_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_clock_probe": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
                "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)]),
                "rf_debug_attn_mix_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)])}

@@ -27,7 +27,7 @@
 // only moves when a tile overflows 2^30 -- checked on the row sums the kernel forms anyway).  attn_fwd_kernel_v4 is the
 // 32x32x16 form of the bounded kernel (shipped above 8192 keys).  The kernel of a launch is picked from the shape or by the
 // CALLER per launch (rf_attn_desc.kernel) -- no process-global switch.  The knock-out, ping-pong (v7) and one-wave-per-SIMD
-// variants of the round-2/3 studies are retired sources (experiments/retired/, git 6cfca97); profiles/r02_attention.md /
+// variants of the round-2/3 studies left the tree in round 5 (git 6cfca97 has them); profiles/r02_attention.md /
 // r03_attention.md have the story.
 #include "common.hpp"
 #include <algorithm>

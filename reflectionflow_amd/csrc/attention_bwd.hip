@@ -532,7 +532,11 @@ __global__ __launch_bounds__(256, WPE) void attn_bwd_dkv_kernel(const bf16_t* __
   }
 }
 
+static int g_last_attn_bwd_path = 0;
 }  // namespace rf
+
+/* which forms the last rf_attention_bwd launched (rf_attn_bwd_kernel bits): lets a test see what AUTO picked */
+extern "C" int rf_debug_last_attn_bwd_path(void) { return rf::g_last_attn_bwd_path; }
 
 extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
   using namespace rf;
@@ -591,12 +595,16 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
                          (const bf16_t*)d->k, (const bf16_t*)d->v, (const bf16_t*)d->kt, (const bf16_t*)d->dout, d->lddo,               \
                          (const float*)d->dsum, d->lse, (bf16_t*)d->dq, S, sp);                                                        \
   }
-  {
+  int dq_form = d->kernel & 0xff, dkv_form = d->kernel & 0xff00;
+  RF_REQUIRE((d->kernel & ~0xffff) == 0 && dq_form <= RF_ATTN_BWD_DQ_192 && dkv_form <= RF_ATTN_BWD_DKV_128X2, RF_ERR_UNSUPPORTED,
+             "rf_attention_bwd: kernel=0x%x is not an rf_attn_bwd_kernel combination", d->kernel);
+  if (dq_form == RF_ATTN_BWD_AUTO) {
     const int64_t c256 = cost(256), c192 = cost(192), c128 = cost(128);
-    if (c192 < c256 && c192 <= c128) RF_DQ_LAUNCH(3, 4)
-    else if (c128 < c256) RF_DQ_LAUNCH(2, 4)
-    else RF_DQ_LAUNCH(2, 8)
+    dq_form = (c192 < c256 && c192 <= c128) ? RF_ATTN_BWD_DQ_192 : c128 < c256 ? RF_ATTN_BWD_DQ_128 : RF_ATTN_BWD_DQ_256;
   }
+  if (dq_form == RF_ATTN_BWD_DQ_192) RF_DQ_LAUNCH(3, 4)
+  else if (dq_form == RF_ATTN_BWD_DQ_128) RF_DQ_LAUNCH(2, 4)
+  else RF_DQ_LAUNCH(2, 8)
 #undef RF_DQ_LAUNCH
 #undef RF_DQ_ALL
   RF_LAUNCH_CHECK();
@@ -608,12 +616,16 @@ extern "C" int rf_attention_bwd(const rf_attn_bwd_desc* d, void* stream) {
     // 128-key workgroups also come in a two-per-CU form (2-slot ring, <= 256 registers, 12 dwords of scratch outside the MFMA
     // section): twice the slots per round, each workgroup 1.77x slower for sharing its CU (S = 2560 x 24 heads: 480 workgroups in
     // ONE round of 512 slots, 210 us against 237 us as two rounds of 256)
-    const int64_t wg128 = (int64_t)((sp + 127) / 128) * H;
-    const int64_t c2 = ((wg128 + 2 * num_cus - 1) / (2 * num_cus)) * 226;   // 128 rows x 1.77
-    if (c2 < cost(128) && c2 < cost(192)) RF_DKV_LAUNCH((attn_bwd_dkv_kernel<2, 2, 2>), 2, DKV_LDS / 2);
-    else if (cost(128) < cost(192)) RF_DKV_LAUNCH((attn_bwd_dkv_kernel<2>), 2, DKV_LDS);
+    if (dkv_form == RF_ATTN_BWD_AUTO) {
+      const int64_t wg128 = (int64_t)((sp + 127) / 128) * H;
+      const int64_t c2 = ((wg128 + 2 * num_cus - 1) / (2 * num_cus)) * 226;   // 128 rows x 1.77
+      dkv_form = (c2 < cost(128) && c2 < cost(192)) ? RF_ATTN_BWD_DKV_128X2 : cost(128) < cost(192) ? RF_ATTN_BWD_DKV_128 : RF_ATTN_BWD_DKV_192;
+    }
+    if (dkv_form == RF_ATTN_BWD_DKV_128X2) RF_DKV_LAUNCH((attn_bwd_dkv_kernel<2, 2, 2>), 2, DKV_LDS / 2);
+    else if (dkv_form == RF_ATTN_BWD_DKV_128) RF_DKV_LAUNCH((attn_bwd_dkv_kernel<2>), 2, DKV_LDS);
     else RF_DKV_LAUNCH((attn_bwd_dkv_kernel<3>), 3, DKV_LDS);
   }
+  g_last_attn_bwd_path = dq_form | dkv_form;
 #undef RF_DKV_LAUNCH
   RF_LAUNCH_CHECK();
   return RF_OK;

@@ -46,6 +46,9 @@ ProfScope::ProfScope(int cls, double work, hipStream_t s) : idx_(-1), s_(s) {
   (void)hipEventRecord(g_prof.ev[idx_], s_);
 }
 ProfScope::~ProfScope() {}
+void ProfScope::reclass(int cls) {
+  if (idx_ >= 0) g_prof.cls[idx_] = cls;
+}
 bool prof_open() { return g_prof.on; }
 
 static void prof_free() {
@@ -105,5 +108,5 @@ extern "C" int rf_profile_end(double* us_sum, int64_t* launches, double* work_su
 }
 
 extern "C" const char* rf_last_error(void) { return rf::g_err; }
-extern "C" int rf_abi_version(void) { return 12; }
+extern "C" int rf_abi_version(void) { return 13; }
 extern "C" int rf_target_arch(void) { return 950; }

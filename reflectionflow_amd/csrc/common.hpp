@@ -60,6 +60,7 @@ int hip_fail(hipError_t e, const char* what);
 struct ProfScope {
   ProfScope(int cls, double work, hipStream_t s);
   ~ProfScope();
+  void reclass(int cls);   // the launch turned out to belong to another class (the event stays where it was recorded)
   ProfScope(const ProfScope&) = delete;
   ProfScope& operator=(const ProfScope&) = delete;
  private:

@@ -26,7 +26,7 @@
 // splitk_reduce_kernel, dispatch() and the C entry points.  The schedule of a launch is picked by dispatch() from the shape or
 // by the CALLER per launch (rf_gemm_desc.schedule) -- there is no process-global kernel switch in this library.
 // The loops of the A/B studies in profiles/r01..r03 (round-1 phases, 32x32x16 MFMA shapes, skinny-N, knock-outs, the s_memtime
-// timeline) are not in this tree any more: they are retired sources under csrc/experiments/retired/ that built against git 6cfca97.
+// timeline) are not in this tree any more: git 6cfca97 holds the last tree that built them (csrc/experiments/).
 #include "common.hpp"
 #include <type_traits>
 #include <stdlib.h>
@@ -575,8 +575,15 @@ __device__ __forceinline__ void tile_coords(const int lt, const int tiles_m, con
 }
 
 // VEC: LDS-staged 16-byte epilogue (all pointers 16-byte aligned, N % 8 == 0) vs the per-element fallback
+// NO PACKED-FP32 VALU OPS IN THIS KERNEL (round 5).  Two workgroups of the 128 x 128 form share a CU (67.5 KiB of LDS, 224 registers:
+// two waves per SIMD from DIFFERENT workgroups, one in its K loop while the other is in its epilogue).  In that state the fused
+// RMSNorm + RoPE epilogue returned wrong values -- the low half of a `v_pk_fma_f32 ... neg_lo neg_hi` result, lanes 48-63 only, a
+// different handful of q / k rows on every run (tools/kb_qkv_bitstable.py: > 256 tiles + fused RoPE: every run differs; one workgroup
+// per CU, or the same code compiled without packed-fp32 ops: bit-stable; waiting out every load before the arithmetic: no change).
+// The 256 x 256 kernels run one workgroup per CU with a barrier between K loop and epilogue and have never shown it (bit-stability
+// tests at cfg2 / cfg4 / cfg5 sizes).  Found by tests/test_fullsize_gpu.py::test_fast_denoise_is_bit_equal_... at 512 + 256 tokens.
 template <int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+__attribute__((target("no-packed-fp32-ops"))) __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1655,7 +1662,10 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
                         : try_launch_gemm_sk<256, 256, 4, 2, false>(p, ws_base, ws_total, stream);
     if (rc != 0) return rc < 0 ? rc : RF_OK;
   }
-  if (sk_or_128) tile = 128;
+  if (sk_or_128) {  // AUTO sized it at 256^2 for stream-K only; stream-K declined: it runs on 128^2 tiles and is booked as such
+    tile = 128;
+    prof.reclass(RF_KC_GEMM_SMALL);
+  }
   if (ws_bytes > 0 && tile == 128 && p.ngroups == 1 && p.epi == RF_EPI_STORE && p.vec_ok) {
     const GemmGroupDev& G = p.g[0];
     const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;

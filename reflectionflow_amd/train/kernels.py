@@ -75,10 +75,11 @@ def qkv_train_bwd(raw: torch.Tensor, heads: int, n_added: int, norms, cos, sin, 
     return d_raw
 
 
-def attention_bwd(a: AttnOperands, o: torch.Tensor, dout: torch.Tensor,
-                  lse: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def attention_bwd(a: AttnOperands, o: torch.Tensor, dout: torch.Tensor, lse: Optional[torch.Tensor] = None,
+                  kernel: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(dq (w.r.t. the scaled q), dk, dv), each [heads, s_pad, 128] bf16.  lse: the row statistics ops.attention(..., lse=) wrote for
-    the SAME operands ([heads, s_pad] fp32; rows >= S are filled in here) -- without it the dq kernel makes its own pass for them."""
+    the SAME operands ([heads, s_pad] fp32; rows >= S are filled in here) -- without it the dq kernel makes its own pass for them.
+    kernel: rf_attn_bwd_kernel bits (_lib.RF_ATTN_BWD_*), 0 = the library sizes both launches for the device."""
     o, dout = _rows2d(o, "o"), _rows2d(dout, "dout")
     H, dev = a.q.shape[0], a.q.device
     dq, dk, dv = torch.empty_like(a.q), torch.empty_like(a.q), torch.empty_like(a.q)
@@ -95,7 +96,7 @@ def attention_bwd(a: AttnOperands, o: torch.Tensor, dout: torch.Tensor,
     d.q, d.k, d.v, d.qt, d.kt = a.q.data_ptr(), a.k.data_ptr(), a.v.data_ptr(), a.qt.data_ptr(), a.kt.data_ptr()
     d.o, d.dout, d.ldo, d.lddo = o.data_ptr(), dout.data_ptr(), o.stride(0), dout.stride(0)
     d.dq, d.dk, d.dv, d.dot, d.lse, d.dsum = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dot.data_ptr(), lse.data_ptr(), dsum.data_ptr()
-    d.heads, d.S, d.s_pad, d.mode, d.lse_given = H, a.S, a.s_pad, 0, 1 if given else 0
+    d.heads, d.S, d.s_pad, d.mode, d.lse_given, d.kernel = H, a.S, a.s_pad, 0, 1 if given else 0, int(kernel)
     L.check(L.load().rf_attention_bwd(C.byref(d), stream_ptr()), "rf_attention_bwd")
     return dq, dk, dv
 

@@ -6,8 +6,11 @@ pooled-text embedding, the LoRA terms of the AdaLN linears and of x_embedder (a 
 AdaLayerNormContinuous + proj_out (64 output channels) and the MSE.  torch.autograd links those pieces and the block Functions;
 every block re-computes itself in its backward (train_flux/flux/transformer.py:139-157, `gradient_checkpointing: true`).
 
-Data parallelism ("DDP all-reduce of ~116 M LoRA grads"): `allreduce_lora_grads` -- ONE flat bf16 bucket over all
-LoRA gradients (232 MB at r = 32: a single ring all-reduce is per-link bound on xGMI, so fewer, larger collectives), averaged.
+Data parallelism ("DDP all-reduce of ~116 M LoRA grads"): ONE flat bf16 bucket over all LoRA gradients (232 MB at
+r = 32: a single ring all-reduce is per-link bound on xGMI, so fewer, larger collectives).  With `configure_optimizers()` the factors
+and their gradients LIVE in flat buffers (train/optim.py): the all-reduce runs on the gradient buffer as it lies and the averaging is
+a scalar of the optimizer kernel; `allreduce_lora_grads` is the stand-alone form for callers that keep torch.optim (pack, reduce,
+average, unpack).
 """
 from __future__ import annotations
 
@@ -83,6 +86,35 @@ class FluxTrainer:
             p.requires_grad_(True)                          # :102-103
         self.eng = E.engine_for(transformer)
         self.latent_lora = bool(self.cfg.get("latent_lora", False))
+        self.optimizer = None
+
+    def configure_optimizers(self, optimizer_config: Optional[dict] = None, state_dtype: torch.dtype = BF):
+        """train/model.py:94-117 (`configure_optimizers`): the optimizer over the LoRA factors, built from the reference's
+        `optimizer_config` ({"type": "Prodigy" | "AdamW", "params": {...}}; default: the shipped config.yaml:55-61).  The factors move
+        into ONE flat bucket (train/optim.py: gradients accumulate straight into it, the data-parallel all-reduce and the update run on
+        it as it lies), so the engine's packed pointers are re-made."""
+        from .optim import build_optimizer
+        if optimizer_config is None:
+            optimizer_config = {"type": "Prodigy", "params": {"lr": 1, "use_bias_correction": True, "safeguard_warmup": True, "weight_decay": 0.01}}
+        self.optimizer = build_optimizer(lora_parameters(self.tr), optimizer_config, state_dtype=state_dtype)
+        E.invalidate(self.tr)
+        self.eng = E.engine_for(self.tr)
+        return self.optimizer
+
+    def training_step(self, batch: Dict[str, torch.Tensor], world_size: int = 1, group=None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """One optimisation step as the reference's Lightning loop runs it (zero_grad -> step() -> backward -> DDP all-reduce ->
+        optimizer.step): returns the detached loss.  Needs configure_optimizers() first."""
+        if self.optimizer is None:
+            raise ops.RFError("FluxTrainer.training_step: call configure_optimizers() first")
+        opt = self.optimizer
+        opt.zero_grad()
+        loss = self.step(batch, generator=generator)
+        loss.backward()
+        if world_size > 1:
+            opt.bucket.all_reduce(world_size, group)
+            opt.grad_scale = 1.0 / world_size
+        opt.step()
+        return loss.detach()
 
     # -------------------------------------------------------------------------------------------------- pieces
     def _mods(self, temb: torch.Tensor, lora_on: bool):

@@ -47,7 +47,8 @@ def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
         f'printf("{s} %zu\\n", sizeof({s}));\n' for s in structs) + \
         'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\n' \
         'printf("off_sched %zu\\n", offsetof(rf_gemm_desc, schedule));\nprintf("off_kernel %zu\\n", offsetof(rf_attn_desc, kernel));\n' \
-        'printf("off_lse %zu\\n", offsetof(rf_attn_desc, lse));\nprintf("off_given %zu\\n", offsetof(rf_attn_bwd_desc, lse_given));\nreturn 0;}\n'
+        'printf("off_lse %zu\\n", offsetof(rf_attn_desc, lse));\nprintf("off_given %zu\\n", offsetof(rf_attn_bwd_desc, lse_given));\n' \
+        'printf("off_bwdk %zu\\n", offsetof(rf_attn_bwd_desc, kernel));\nreturn 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -61,6 +62,7 @@ def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
     assert int(out["off_sched"]) == _lib.rf_gemm_desc.schedule.offset
     assert int(out["off_kernel"]) == _lib.rf_attn_desc.kernel.offset
     assert int(out["off_lse"]) == _lib.rf_attn_desc.lse.offset and int(out["off_given"]) == _lib.rf_attn_bwd_desc.lse_given.offset
+    assert int(out["off_bwdk"]) == _lib.rf_attn_bwd_desc.kernel.offset
 
 
 def test_no_kernel_selecting_switch_is_exported(lib):
@@ -69,7 +71,8 @@ def test_no_kernel_selecting_switch_is_exported(lib):
     from reflectionflow_amd import _lib
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     dbg = sorted(set(re.findall(r"\b(rf_debug_[a-z0-9_]+)", out)))
-    assert dbg == ["rf_debug_attn_mix_plan", "rf_debug_clock_probe", "rf_debug_last_attn_path", "rf_debug_last_gemm_path", "rf_debug_sk_plan"], dbg
+    assert dbg == ["rf_debug_attn_mix_plan", "rf_debug_clock_probe", "rf_debug_last_attn_bwd_path", "rf_debug_last_attn_path",
+                   "rf_debug_last_gemm_path", "rf_debug_sk_plan"], dbg
     d = _lib.rf_gemm_desc()
     d.N, d.num_groups, d.schedule = 64, 1, 17
     assert lib.rf_gemm_bf16(C.byref(d), None) == -1 and b"schedule=17" in lib.rf_last_error()

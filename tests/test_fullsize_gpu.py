@@ -137,6 +137,46 @@ def test_cfg4_forward_with_lora_on_condition_rows(full, latent_lora):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("use_cond", [False, True])
+def test_fast_denoise_is_bit_equal_to_the_per_step_path_at_50_steps(full, use_cond):
+    """bench.py times the fast path (all T modulation tables up front, T steps in one C call / hipGraph); the
+    parity suite pins the per-step path (tranformer_forward + scheduler.step per step, transformer.py:95-114 forming the time
+    embedding at M = B).  Up to round 4 the two differed in the last bit of temb at T = 50 (PyTorch's linears at M = 50 vs M = 1) and
+    by 6.7e-3 after 50 steps.  time_text_embed now runs on the row-invariant rf_gemm_bf16 in both: the 57-block FLUX-width model,
+    T = 50, with and without a condition stream, must give IDENTICAL latents, and temb / modulation rows must not depend on M."""
+    from reflectionflow_amd import engine as E
+    from reflectionflow_amd.flux.condition import Condition
+    from reflectionflow_amd.flux.generate import generate
+    dev, pipe, om, ob = full
+    eng = E.engine_for(pipe.transformer)
+    St, Si, Sc, T_ = 512, 256, 64, 50                                             # 256 x 256 latents, 128 x 128 condition
+    pe, pooled, lat, cond, _, _ = _inputs(dev, St, Si, Sc, seed=5)
+    pipe.scheduler.set_timesteps(T_, device=dev, mu=0.8)
+    ts = (pipe.scheduler.timesteps.to(dev).to(BF) / 1000).to(BF) * 1000
+    gd = torch.full((T_,), 3.5, device=dev).to(BF) * 1000
+    te_all = eng.temb(ts, gd, pooled.expand(T_, -1))
+    te_one = torch.cat([eng.temb(ts[i:i + 1], gd[i:i + 1], pooled) for i in range(T_)])
+    assert torch.equal(te_all, te_one), "time embedding depends on how many rows are evaluated at once"
+    assert torch.equal(eng.mod_table(te_all)[7:8], eng.mod_table(te_all[7:8]))
+    # ... and it is the reference's arithmetic: against the fp32 modules of the product model on the same inputs
+    te32 = copy.deepcopy(pipe.transformer.time_text_embed).float()(ts.float(), gd.float(), pooled.float().expand(T_, -1))
+    te_bf = pipe.transformer.time_text_embed(ts, gd, pooled.expand(T_, -1))
+    e_hip, e_t = rel_l2(te_all, te32), rel_l2(te_bf, te32)
+    print(f"  time_text_embed T=50 rows: rel-L2 hip {e_hip:.3e}  torch-bf16 modules {e_t:.3e}")
+    assert e_hip <= 2.0 * e_t + 2e-3
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    conds = [Condition("cot", tokens=cond, ids=O.condition_ids_for(128).to(dev))] if use_cond else None
+    common = dict(conditions=conds, model_config=cfg, default_lora=True, height=256, width=256, num_inference_steps=T_,
+                  guidance_scale=3.5, prompt_embeds=pe, pooled_prompt_embeds=pooled, output_type="latent")
+    fast = generate(pipe, latents=lat.clone(), **common).images
+    n = []
+    slow = generate(pipe, latents=lat.clone(), callback_on_step_end=lambda p, i, t, kw: n.append(i) or {}, **common).images
+    assert len(n) == T_
+    assert torch.isfinite(fast.float()).all()
+    assert torch.equal(fast, slow), f"fast vs per-step path at T=50 differ: rel-L2 {rel_l2(fast, slow):.3e}"
+
+
+@torch.no_grad()
 def test_cfg5_generate_two_steps_2048(full):
     """BASELINE cfg5 geometry in bf16 (fp8 weights: tests/test_w8_gpu.py): 2048 x 2048 latents (16384 tokens) + 512^2
     condition (1024 tokens) + 512 text = 17920 joint tokens, 2 Euler steps through generate()."""

@@ -206,3 +206,30 @@ def test_joint_attention_kwargs_scale_is_not_silently_ignored():
     assert pipe.joint_attention_kwargs is None
     pipe._joint_attention_kwargs = {"scale": 0.5}
     assert pipe.joint_attention_kwargs == {"scale": 0.5}
+
+
+def test_rope_table_cache_works_under_inference_mode():
+    """FluxEngine.rope_tables keyed its identity fast path on Tensor._version, which raises for tensors created
+    under torch.inference_mode() -- a caller wrapping generate() in inference_mode crashed.  The cache must fall through to the
+    value-level compare there and keep the identity fast path for ordinary tensors (host logic only: a bare engine object on CPU)."""
+    from reflectionflow_amd import engine as E
+    from reflectionflow_amd.flux import modules as M
+
+    class _Tr:
+        pos_embed = M.FluxPosEmbed(10000, (16, 56, 56))
+    eng = E.FluxEngine.__new__(E.FluxEngine)
+    eng._rope_cache, eng.device, eng.tr = {}, torch.device("cpu"), _Tr()
+    txt, img = torch.zeros(8, 3), O.prepare_latent_image_ids(4, 4)
+    cos, sin = eng.rope_tables(txt, img)
+    ref_cos, ref_sin = O.FluxPosEmbed(10000, (16, 56, 56))(torch.cat([txt, img.float()], 0))
+    assert torch.equal(cos, ref_cos) and torch.equal(sin, ref_sin)
+    assert eng.rope_tables(txt, img)[0] is cos                                   # identity fast path
+    with torch.inference_mode():
+        t2, i2 = torch.zeros(8, 3), O.prepare_latent_image_ids(4, 4)
+        assert t2.is_inference()
+        c2, s2 = eng.rope_tables(t2, i2)                                          # used to raise RuntimeError
+        assert c2 is cos and s2 is sin                                            # value-level hit
+        c3, _ = eng.rope_tables(torch.zeros(9, 3), i2)                            # a miss computes inside inference mode
+        assert c3.shape[0] == 9 + 16
+    img.add_(1)                                                                   # an in-place edit must miss
+    assert not torch.equal(eng.rope_tables(txt, img)[0], cos)

@@ -203,6 +203,99 @@ def test_attention_bwd_vs_fp32_autograd(dev, H, S):
     assert ran >= 2
 
 
+_ATTN_CASES = {}
+
+
+def _attn_bwd_case(dev, H, S):
+    """operands, the product forward (+ lse) and the fp32-autograd reference of one (heads, S) -- built once per module"""
+    if (H, S) in _ATTN_CASES:
+        return _ATTN_CASES[(H, S)]
+    from reflectionflow_amd import ops
+    from reflectionflow_amd.train import kernels as K
+    D = H * 128
+    raw = rnd(dev, S, 3 * D, seed=3, sc=1.5)
+    w = torch.ones(128, device=dev).to(BF)
+    ids = torch.stack([torch.zeros(S), torch.arange(S) // 64, torch.arange(S) % 64], 1).to(dev)
+    cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
+    a = K.qkv_train_fwd(raw, H, 0, (w, w, None, None), cos, sin)
+    lse = torch.full((H, a.s_pad), float("nan"), dtype=torch.float32, device=dev)
+    out = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, lse=lse)
+    dout = rnd(dev, S, D, seed=4)
+    gq, gk, gv, lse_ref = [], [], [], []
+    for h0 in range(0, H, 4):                                            # fp32 autograd, four heads at a time (S^2 fp32 each)
+        qf, kf, vf = (t[h0:h0 + 4, :S].float().detach().requires_grad_(True) for t in (a.q, a.k, a.v))
+        s2 = qf @ kf.transpose(1, 2)
+        ref = torch.softmax(s2 * LN2, -1) @ vf
+        ref.backward(dout.float().view(S, H, 128).permute(1, 0, 2)[h0:h0 + 4])
+        assert rel_l2(out.view(S, H, 128)[:, h0:h0 + 4], ref.detach().permute(1, 0, 2)) < 1e-2
+        lse_ref.append((torch.logsumexp(s2.detach().double() * LN2, -1) / LN2))
+        gq.append(qf.grad), gk.append(kf.grad), gv.append(vf.grad)
+        del s2, ref
+    case = dict(a=a, out=out, dout=dout, lse=lse, lse_ref=torch.cat(lse_ref), g=(torch.cat(gq), torch.cat(gk), torch.cat(gv)))
+    _ATTN_CASES.clear()                                                   # one case resident at a time (24 x 5632 is ~2 GB)
+    _ATTN_CASES[(H, S)] = case
+    return case
+
+
+def _bwd_forms():
+    from reflectionflow_amd import _lib as L
+    dq = [("dq256", L.RF_ATTN_BWD_DQ_256), ("dq128", L.RF_ATTN_BWD_DQ_128), ("dq192", L.RF_ATTN_BWD_DQ_192)]
+    dkv = [("dkv128", L.RF_ATTN_BWD_DKV_128), ("dkv192", L.RF_ATTN_BWD_DKV_192), ("dkv128x2", L.RF_ATTN_BWD_DKV_128X2)]
+    return dq, dkv
+
+
+@pytest.mark.parametrize("H,S", [(3, 1000), (5, 448), (24, 2560), (24, 5632), (6, 4608)])
+def test_attention_bwd_every_kernel_form(dev, H, S):
+    """rf_attention_bwd sizes its two launches by CU rounds, so on a 256-CU part the small test shapes only ever
+    reached dq<2,4 waves> + dkv<2>.  Here every dq form {256, 128, 192 queries per workgroup} x every dK / dV form {128, 192, 128 keys
+    two-per-CU} is FORCED through rf_attn_bwd_desc.kernel on every shape -- ragged (1000), short (448), the two training shapes
+    24 x 2560 (target 512 + condition 512 + text) and 24 x 5632 (target 1024 + condition 512 + text, config.yaml:39-40) and the cfg2
+    token count -- with and without the forward's row statistics: dq / dk / dv against fp32 autograd of
+    F.scaled_dot_product_attention (block.py:123-125), padded rows exactly zero, the forward's lse against fp64, bit-reproducible, and
+    what AUTO picks is one of the forms just checked (rf_debug_last_attn_bwd_path)."""
+    from reflectionflow_amd import _lib as L
+    from reflectionflow_amd.train import kernels as K
+    c = _attn_bwd_case(dev, H, S)
+    a, out, dout, ref = c["a"], c["out"], c["dout"], c["g"]
+    err_lse = float((c["lse"][:, :S].double() - c["lse_ref"]).abs().max())
+    print(f"  forward lse H={H} S={S}: max |lse - fp64| = {err_lse:.2e} (log2 units)")
+    assert err_lse < 2e-2
+    dq_forms, dkv_forms = _bwd_forms()
+    worst, results = 0.0, {}
+    for given in (True, False):
+        for qn, qf_ in dq_forms:
+            for kn, kf_ in dkv_forms:
+                lse = c["lse"].clone() if given else None
+                g = K.attention_bwd(a, out, dout, lse=lse, kernel=qf_ | kf_)
+                assert L.load().rf_debug_last_attn_bwd_path() == (qf_ | kf_)
+                e = [rel_l2(x[:, :S], r) for x, r in zip(g, ref)]
+                worst = max(worst, max(e))
+                assert max(e) < 1.2e-2, (qn, kn, given, e)
+                if a.s_pad > S:
+                    assert all(float(x[:, S:].abs().max()) == 0.0 for x in g), (qn, kn, "padded rows must be zero")
+                    if given:
+                        assert bool((lse[:, S:] == 1e30).all())
+                results[(given, qn, kn)] = g
+    print(f"  attention bwd H={H} S={S}: 18 forced form pairs, worst rel-L2 vs fp32 autograd {worst:.2e}")
+    # dq depends only on the dq form; dk / dv only on the dK / dV form when the row statistics are the forward's (without them the dq
+    # launch computes them for the dK / dV launch, and its forms may round the statistics differently)
+    for given in (True, False):
+        for qn, _ in dq_forms:
+            assert all(torch.equal(results[(given, qn, "dkv128")][0], results[(given, qn, kn)][0]) for kn, _ in dkv_forms)
+    for kn, _ in dkv_forms:
+        assert all(torch.equal(results[(True, "dq256", kn)][i], results[(True, qn, kn)][i]) for qn, _ in dq_forms for i in (1, 2))
+    # AUTO: one of the forms above, reproducibly
+    g_auto = K.attention_bwd(a, out, dout, lse=c["lse"].clone())
+    path = L.load().rf_debug_last_attn_bwd_path()
+    names = {f: n for n, f in dq_forms + dkv_forms}
+    qn, kn = names[path & 0xff], names[path & 0xff00]
+    print(f"  AUTO at H={H} S={S}: {qn} + {kn}")
+    assert all(torch.equal(x, y) for x, y in zip(g_auto, results[(True, qn, kn)]))
+    assert all(torch.equal(x, y) for x, y in zip(K.attention_bwd(a, out, dout, lse=c["lse"].clone()), g_auto)), "not bit-reproducible"
+    with pytest.raises(Exception):
+        K.attention_bwd(a, out, dout, kernel=7)
+
+
 # ------------------------------------------------------------------------------------------------- the whole step
 def _product_step(pipe, batch, cfg):
     from reflectionflow_amd.train.step import FluxTrainer, lora_parameters
@@ -223,9 +316,13 @@ def _oracle_grads(m, key=lambda n: n.replace(".lora_A.default.weight", ".lora_A"
     return {key(n): (None if p.grad is None else p.grad.float().clone()) for n, p in TO.lora_parameters(m).items()}
 
 
-def _compare(name, hip, ref32, tbf):
-    worst = 0.0
-    checked = 0
+ADD_TOL = 1e-2          # additive term of the gradient rule (module docstring); the ratio to the inference rule's 2e-3 is printed
+
+
+def _compare(name, hip, ref32, tbf, add=ADD_TOL):
+    """every non-zero reference gradient: rel-L2(hip, fp32) <= 2 rel-L2(torch-bf16, fp32) + add.  Returns (#checked, worst ratio to
+    that bound, worst ratio to the bound with the inference rule's additive term 2e-3)."""
+    worst, worst_tight, checked = 0.0, 0.0, 0
     for n, g32 in ref32.items():
         gh, gb = hip[n], tbf[n]
         if float(g32.abs().max()) == 0.0:
@@ -233,10 +330,10 @@ def _compare(name, hip, ref32, tbf):
             continue
         assert gh is not None, f"{n}: no gradient"
         e_h, e_b = rel_l2(gh, g32), rel_l2(gb, g32)
-        worst = max(worst, e_h / (2 * e_b + 1e-2))
-        assert e_h <= 2 * e_b + 1e-2, f"{name} {n}: rel-L2 hip {e_h:.3e} vs torch-bf16 {e_b:.3e}"
+        worst, worst_tight = max(worst, e_h / (2 * e_b + add)), max(worst_tight, e_h / (2 * e_b + 2e-3))
+        assert e_h <= 2 * e_b + add, f"{name} {n}: rel-L2 hip {e_h:.3e} vs torch-bf16 {e_b:.3e} (+{add:g})"
         checked += 1
-    return checked, worst
+    return checked, worst, worst_tight
 
 
 def test_training_step_hd128_against_the_reference_fixture(dev):
@@ -261,8 +358,8 @@ def test_training_step_hd128_against_the_reference_fixture(dev):
     l32 = float(T(z["loss"]))
     print(f"  loss: hip {float(loss):.5f} torch-bf16 {float(loss_b):.5f} reference fp32 {l32:.5f}")
     assert abs(float(loss) - l32) <= 2 * abs(float(loss_b) - l32) + 2e-2 * l32
-    n, worst = _compare("hd128", grads, ref, tbf)
-    print(f"  {n} non-zero LoRA gradients within tolerance (worst ratio to the bound {worst:.2f})")
+    n, worst, tight = _compare("hd128", grads, ref, tbf)
+    print(f"  {n} non-zero LoRA gradients within tolerance (worst ratio to the bound {worst:.2f}; to 2 x bf16 + 2e-3: {tight:.2f})")
     assert n == 44
     # bit-reproducible: the same step again
     loss2, grads2 = _product_step(pipe, batch, cfg)
@@ -271,15 +368,21 @@ def test_training_step_hd128_against_the_reference_fixture(dev):
         assert (v is None and grads2[k] is None) or torch.equal(v, grads2[k].cpu()), k
 
 
-def test_training_step_flux_width_blocks_vs_fp32_oracle(dev):
-    """One DoubleStream + one SingleStream block at FLUX.1-dev width (D = 3072, 24 heads, mlp 12288, LoRA r = 32), 512 text +
-    1024 image + 256 condition tokens: loss and LoRA gradients vs the fp32 oracle (run on the GPU), torch-bf16 as the yardstick."""
+@pytest.mark.parametrize("nd,ns,gh,gc,add", [(1, 1, 32, 16, 2e-3), (2, 2, 64, 32, 2e-3)], ids=["1+1_S1792", "2+2_S5632_cfg4_training_shape"])
+def test_training_step_flux_width_blocks_vs_fp32_oracle(dev, nd, ns, gh, gc, add):
+    """DoubleStream + SingleStream blocks at FLUX.1-dev width (D = 3072, 24 heads, mlp 12288, LoRA r = 32): loss and LoRA gradients vs
+    the fp32 oracle (run on the GPU), torch-bf16 as the yardstick.
+      1+1 blocks, 512 text + 1024 image + 256 condition tokens (S = 1792)
+      2+2 blocks, 512 text + 4096 image + 1024 condition = S = 5632: the sizes the reference trains at (config.yaml:39-40,
+          target_size 1024 / condition_size 512) -- at 24 x 5632 the attention backward runs the forms AUTO picks there
+          (test_attention_bwd_every_kernel_form prints them) and the GEMMs their 256^2 / stream-K schedules.
+    The additive term of the rule is the inference rule's 2e-3 here (round 4: 1e-2)."""
     torch.manual_seed(0)
-    om = O.FluxTransformer2DModel(num_layers=1, num_single_layers=1).float()
+    om = O.FluxTransformer2DModel(num_layers=nd, num_single_layers=ns).float()
     O.inject_lora(om, r=32, alpha=32.0)
     O.init_synthetic_(om, seed=3, std=0.02)
     TO.set_trainable(om.train())
-    St, gh, gc = 512, 32, 16
+    St = 512
     Si, Sc = gh * gh, gc * gc
     g = torch.Generator().manual_seed(5)
     x_0, cond = torch.randn(1, Si, 64, generator=g), torch.randn(1, Sc, 64, generator=g)
@@ -310,8 +413,11 @@ def test_training_step_flux_width_blocks_vs_fp32_oracle(dev):
     loss, grads = _product_step(pipe, batch, cfg)
     grads = {k: (None if v is None else v.cpu()) for k, v in grads.items()}
     l32 = float(loss32)
-    print(f"  FLUX-width 1+1: loss hip {float(loss):.5f} torch-bf16 {float(loss_b):.5f} fp32 {l32:.5f}")
+    print(f"  FLUX-width {nd}+{ns} S={St + Si + Sc}: loss hip {float(loss):.5f} torch-bf16 {float(loss_b):.5f} fp32 {l32:.5f}")
     assert abs(float(loss) - l32) <= 2 * abs(float(loss_b) - l32) + 2e-2 * l32
-    n, worst = _compare("flux-width", grads, ref, tbf)
-    print(f"  {n} non-zero LoRA gradients within tolerance (worst ratio to the bound {worst:.2f})")
-    assert n >= 20
+    n, worst, tight = _compare(f"flux-width {nd}+{ns}", grads, ref, tbf, add=add)
+    print(f"  {n} non-zero LoRA gradients within 2 x torch-bf16 + {add:g} (worst ratio to the bound {worst:.2f}; to 2 x bf16 + 2e-3: {tight:.2f})")
+    assert n >= 20 * nd
+    loss2, grads2 = _product_step(pipe, batch, cfg)                                   # bit-reproducible at the full shape too
+    assert torch.equal(loss, loss2)
+    assert all((v is None and grads2[k] is None) or torch.equal(v, grads2[k].cpu()) for k, v in grads.items())
