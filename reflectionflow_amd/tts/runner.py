@@ -245,6 +245,16 @@ def run_reflection_search(config: dict, prompts: Optional[List[str]], output_dir
                     os.remove(os.path.join(outpath, f))
         if shard.world_size > 1:
             torch.distributed.barrier()
+            # every rank writes its candidates' files under `outpath` and rank 0 copies the round's artefacts from there
+            # (samples_lastround / samples_path_bestround / samples_best): all ranks must see ONE output_dir -- one node, or a shared
+            # filesystem.  Checked before any work: a node-local output_dir would otherwise fail on rank 0 mid-round while the other
+            # ranks wait in the next collective.
+            seen = torch.tensor([1 if os.path.exists(os.path.join(outpath, "metadata.jsonl")) else 0], dtype=torch.int32,
+                                device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MIN)
+            if int(seen.item()) == 0:
+                raise RuntimeError(f"output_dir {output_dir!r} is not shared by all {shard.world_size} ranks (rank 0's metadata.jsonl is not visible "
+                                   "everywhere): run on one node or point --output_dir at a shared filesystem")
         log: List[dict] = []
         tree = search.ReflectionTree(kind)
         updated_prompt = [prompt] * N                                           # :579
@@ -320,7 +330,8 @@ def run_reflection_search(config: dict, prompts: Optional[List[str]], output_dir
             new_reflections = refined = None
             if use_reflection or use_refine:
                 if shard.rank == 0:
-                    ctx = dict(selected=[dict(e, **({"path": os.path.join(outpath, n) if not os.path.isabs(n) else n}),
+                    # (round-1 parents read from --imgpath are named relative to the CWD or absolutely, generated ones relative to outpath)
+                    ctx = dict(selected=[dict(e, **({"path": n if (pool_on_disk or os.path.isabs(n)) else os.path.join(outpath, n)}),
                                               latents=None if pool_on_disk else payload[j])
                                          for e, n, j in zip(evaluation, selected_names, sel)],
                                original_prompt=prompt, current_prompt=list(updated_prompt), reflections=reflections,
@@ -343,7 +354,10 @@ def run_reflection_search(config: dict, prompts: Optional[List[str]], output_dir
             parents = [selected_names[i] if i < len(sel) else None for i in range(N)]
             tree.record(rnd, names, scores, parents)                            # :358-395
             best_chain = tree.best_of_chains()
-            # ---- artefacts (:397-444), rank 0, after every rank's files exist (the score all-gather ordered them)
+            # ---- artefacts (:397-444), rank 0, after every rank's files exist (the score all-gather ordered the writes on one node; the
+            # barrier makes that explicit for a shared filesystem, whose visibility the collective does not order)
+            if shard.world_size > 1:
+                torch.distributed.barrier()
             if shard.rank == 0:
                 if rnd == R:
                     for i, n in enumerate(names):

@@ -87,6 +87,8 @@ class _Replay:
         L = self.logical
 
         def reflect(ctx):
+            for s in ctx["selected"]:                              # the hooks are handed files that exist (--imgpath pools)
+                assert os.path.exists(s["path"]), s["path"]
             if sc["reflection"] == "openai":
                 return ["fix(%s|was:%s)" % (L[s["image_name"]], prev) for s, prev in zip(ctx["selected"], ctx["reflections"])]
             return ["qwen(%s)" % L[s["image_name"]] for s in ctx["selected"]]
@@ -174,6 +176,22 @@ def test_reflection_search_equals_reference_fixture(name, tmp_path):
     out = str(tmp_path / "out")
     log = rp.run(search.Shard(0, 1), out)
     rp.check(log, out)
+
+
+def test_relative_imgpath_reaches_the_hooks_as_existing_files(tmp_path, monkeypatch):
+    """with `--imgpath img` (relative to the CWD) the round-1 parents' names are CWD-relative; the reflect / refine hooks
+    must receive them as they are, not re-rooted under the output directory (generated names ARE output-relative)."""
+    rp = _Replay(GOLD["nvila_reflect_openai_refine"], str(tmp_path))
+    monkeypatch.chdir(tmp_path)
+    rel = _Replay(GOLD["nvila_reflect_openai_refine"], str(tmp_path))
+    rel.imgpath = "img"
+    rel.logical.update({os.path.join("img", "00000", "samples", os.path.basename(k)): v for k, v in rp.logical.items() if k.endswith(".png")})
+    log = rel.run(search.Shard(0, 1), str(tmp_path / "out_rel"))          # (the reflect hook asserts every path it is handed exists)
+    ref = rp.run(search.Shard(0, 1), str(tmp_path / "out_abs"))
+    for a, b in zip(log[1:], ref[1:]):                                      # the same tree as with the absolute --imgpath
+        assert [rel.logical[n] for n in a["selected_names"]] == [rp.logical[n] for n in b["selected_names"]]
+        assert a["prompts"] == b["prompts"] and a["scores"] == b["scores"]
+    assert not os.path.isabs(log[1]["selected_names"][0])
 
 
 def test_reference_generate_kwargs_and_condition_geometry():
