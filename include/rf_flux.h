@@ -67,7 +67,8 @@ typedef enum rf_gemm_schedule {
   RF_SCHED_STREAMK = 3,     /* 256x256 stream-K whenever feasible (needs splitk_ws; else as TILE256)                        */
   RF_SCHED_PERSISTENT = 4,  /* one persistent workgroup per CU walking whole 256x256 tiles (needs splitk_ws)                */
   RF_SCHED_PLAIN256 = 5,    /* 256x256 tiles on the plain double-buffered loop: bit-exact reference of the ping-pong loops  */
-  RF_SCHED_W4 = 6           /* 256x256 tiles, ONE wave per SIMD (4 waves x 128x128 wave tiles): fewer LDS bytes per MFMA     */
+  RF_SCHED_W4 = 6,          /* 256x256 tiles, ONE wave per SIMD (4 waves x 128x128 wave tiles): fewer LDS bytes per MFMA     */
+  RF_SCHED_W4B = 7          /* ... with three half-stage barriers per K-tile: LDS-DMA spread over the whole tile (round 5)  */
 } rf_gemm_schedule;
 
 typedef struct rf_kseg {

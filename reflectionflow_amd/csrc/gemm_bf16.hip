@@ -161,7 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGro
             if (epi == RF_EPI_GELU) {
               v = gelu_tanh(v);
             } else if (epi == RF_EPI_GATE_RES) {
-              v = (G.residual != nullptr ? bf2f(G.residual[(int64_t)m * G.ldr + n]) : 0.f) + gate_v * v;
+              v = fmaf(gate_v, v, G.residual != nullptr ? bf2f(G.residual[(int64_t)m * G.ldr + n]) : 0.f);
             }
             orow[(int64_t)m * G.ldo] = f2bf(v);
           }
@@ -373,7 +373,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_v(const GemmParams& p, const G
             for (int e = 0; e < 8; ++e) rr[e] = 0.f;
             if (G.residual != nullptr) unpack8(resv[it], rr);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rr[e] + gate8[e] * v[e];
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(gate8[e], v[e], rr[e]);
           }
           bf16_t* dst;
           if (epi == RF_EPI_QKV) {
@@ -385,15 +385,15 @@ __device__ __forceinline__ void gemm_epilogue_lds_v(const GemmParams& p, const G
               const float sn[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
               float ss = 0.f;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+              for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
 #pragma unroll
               for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-              const float rs = rsqrtf(ss * (1.0f / 128.0f) + p.norm_eps);
+              const float rs = rsqrtf(fmaf(ss, 1.0f / 128.0f, p.norm_eps));
 #pragma unroll
               for (int e = 0; e < 8; e += 2) {
                 const float a = v[e] * rs * nw8[e], b = v[e + 1] * rs * nw8[e + 1];
-                v[e] = a * cs[e] - b * sn[e];
-                v[e + 1] = b * cs[e + 1] + a * sn[e + 1];
+                v[e] = fmaf(a, cs[e], -(b * sn[e]));      // explicit contraction: every epilogue of the library rounds the same way
+                v[e + 1] = fmaf(b, cs[e + 1], a * sn[e + 1]);
               }
             }
             if (which == 0) {
@@ -582,8 +582,13 @@ __device__ __forceinline__ void tile_coords(const int lt, const int tiles_m, con
 // per CU, or the same code compiled without packed-fp32 ops: bit-stable; waiting out every load before the arithmetic: no change).
 // The 256 x 256 kernels run one workgroup per CU with a barrier between K loop and epilogue and have never shown it (bit-stability
 // tests at cfg2 / cfg4 / cfg5 sizes).  Found by tests/test_fullsize_gpu.py::test_fast_denoise_is_bit_equal_... at 512 + 256 tokens.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define RF_NO_PACKED_FP32   // (the host pass does not know the feature)
+#endif
 template <int BM, int BN, int WM, int WN, bool VEC>
-__attribute__((target("no-packed-fp32-ops"))) __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
+RF_NO_PACKED_FP32 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmParams p) {
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 32, FN = TN / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1118,6 +1123,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p
 __global__ __launch_bounds__(512) void gemm_w8_pp16_kernel(const GemmParams p) { gemm_pp16_body<true>(p); }
 
 #include "gemm_w4.hpp"
+#include "gemm_w4b.hpp"
 
 
 // ---- stream-K variant ---------------------------------------------------------------------------------
@@ -1343,6 +1349,20 @@ static int launch_gemm_w4m16(GemmParams& p, hipStream_t stream) {
   return RF_OK;
 }
 
+static int launch_gemm_w4b(GemmParams& p, hipStream_t stream) {
+  constexpr int LDS = 2 * 2 * 32 * (1024 + 32);   // two stages x {A, W} images of 32 padded wave pieces (gemm_w4b.hpp)
+  static bool attr_set = false;
+  if (!attr_set) {
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  layout_tiles<256, 256>(p);
+  if (p.total_tiles == 0) return RF_OK;
+  hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3(p.total_tiles), dim3(256), LDS, stream, p);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
 static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * 4 * 128 * 128, LDS_EPI = 8 * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
@@ -1525,7 +1545,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
   memset(&p, 0, sizeof(p));
   p.w8 = w8 ? 1 : 0;
   p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
-  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_W4, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
+  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_W4B, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
   p.sched = d->schedule;
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
@@ -1628,6 +1648,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
       case RF_SCHED_TILE256: case RF_SCHED_STREAMK: case RF_SCHED_PERSISTENT: tile = 256; break;
       case RF_SCHED_PLAIN256: tile = 257; break;
       case RF_SCHED_W4: tile = 260; break;
+      case RF_SCHED_W4B: tile = 261; break;
       default: {
         // 256^2 tiles pay from ~half a round of the 256 CUs (plain or stream-K: 144-192 tiles measured 15-30 % ahead of 128^2,
         // tools/kb_gemm_midsize.py / profiles/r04_gemm_midsize.md); below that only as stream-K and only with a long K
@@ -1653,8 +1674,8 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
-  if (tile == 260)
-    RF_REQUIRE(p.vec_ok && !p.w8, RF_ERR_UNSUPPORTED, "rf_gemm: RF_SCHED_W4 needs bf16 operands and the 16-byte aligned epilogue path");
+  if (tile == 260 || tile == 261)
+    RF_REQUIRE(p.vec_ok && !p.w8, RF_ERR_UNSUPPORTED, "rf_gemm: RF_SCHED_W4 / W4B need bf16 operands and the 16-byte aligned epilogue path");
   if (tile >= 257 && (!p.vec_ok || p.w8)) tile = 256;
   if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
   if (tile == 256 && p.vec_ok && sk_mode(p) != 0) {   // (the plain reference loop / experimental kernels skip the stream-K paths)
@@ -1692,6 +1713,7 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   // wave tiles are (BM/WM) x 128: a wave always owns whole 128-wide head rows / 256-byte output runs
   if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (bit-exact reference)
   if (tile == 260) return launch_gemm_w4m16(p, stream);                   // one wave per SIMD, 128 x 128 wave tiles
+  if (tile == 261) return launch_gemm_w4b(p, stream);                     // ... with three half-stage barriers per K-tile
   if (tile == 256) return p.vec_ok ? launch_gemm_pp(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }

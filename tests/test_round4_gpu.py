@@ -21,12 +21,15 @@ def dev():
 
 
 def _both(fn):
+    """(8-wave result, W4 result) -- after checking that the round-5 form W4B (three half-stage barriers per K-tile, csrc/gemm_w4b.hpp)
+    gives the W4 result bit for bit too"""
     from reflectionflow_amd import _lib as L, ops
     outs = []
-    for sched in (L.RF_SCHED_TILE256, L.RF_SCHED_W4):
+    for sched in (L.RF_SCHED_TILE256, L.RF_SCHED_W4, L.RF_SCHED_W4B):
         with ops.gemm_schedule(sched):
             outs.append(fn())
-    return outs
+    assert torch.equal(outs[1], outs[2]), "W4B and W4 disagree"
+    return outs[:2]
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (700, 1032, 128), (1000, 768, 512), (4608, 3072, 3072), (130, 104, 192), (513, 3080, 64), (300, 512, 64), (64, 8, 128)])
