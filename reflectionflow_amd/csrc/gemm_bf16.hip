@@ -1714,6 +1714,10 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (bit-exact reference)
   if (tile == 260) return launch_gemm_w4m16(p, stream);                   // one wave per SIMD, 128 x 128 wave tiles
   if (tile == 261) return launch_gemm_w4b(p, stream);                     // ... with three half-stage barriers per K-tile
+  // (AUTO never picks RF_SCHED_W4B: with warm operands it is 0..4 % ahead of the 8-wave loop on plain-store launches and 8 % on the
+  //  K = 15360 single-block projection, but inside the 57-block sequence, where every weight panel arrives HBM-cold, the same
+  //  launches are 0.5..10 % SLOWER -- one wave per SIMD has nothing to run while a late LDS-DMA piece holds barrier 3;
+  //  profiles/r05_gemm_w4b.md)
   if (tile == 256) return p.vec_ok ? launch_gemm_pp(p, stream) : launch_gemm<256, 256, 4, 2, false>(p, stream);
   return p.vec_ok ? launch_gemm<128, 128, 4, 1, true>(p, stream) : launch_gemm<128, 128, 4, 1, false>(p, stream);
 }
