@@ -1,7 +1,7 @@
 // One wave per SIMD, second form (round 5): 256 x 256 x 64 block tile, 4 waves (2 x 2), 128 x 128 wave tiles on
 // v_mfma_f32_16x16x32_bf16, with
 //   (1) the K-tile SCHEDULE of the fastest 256 x 256 x 64 kernel this part has been seen to run (hipBLASLt's hand-written
-//       `Custom_Cijk_..._SK3_MT256x256x64_MI16x16x1`, disassembled: profiles/r05_gemm_loop_table.md), and
+//       `Custom_Cijk_..._SK3_MT256x256x64_MI16x16x1`, disassembled: profiles/r05_gemm_w4b.md), and
 //   (2) an LDS image whose LDS-DMA source pattern is LANE-LINEAR.
 // (included by gemm_bf16.hip after gemm_w4.hpp; namespace rf)
 //
@@ -16,7 +16,7 @@
 //     MFMA tile j (0..7) of a wave's 128-row strip is NOT 16 consecutive rows but the rows {8 r + j : r = 0..15} -- row j of 16
 //     consecutive pieces -- so lane (r, g) of a fragment read sits at (p0 + r) * 1056 + j * 128 + (4 s + g) * 16: one base register,
 //     immediates j * 128 + s * 64.  1056 / 16 = 66 = 2 (mod 16): the 16 lanes of every ds_read_b128 lane group land in 16 distinct
-//     16-byte bank slots (tests/test_lds_swizzle_cpu.py holds the lane groups; the bank algebra is in DESIGN K1).
+//     16-byte bank slots (tests/test_lds_layouts_cpu.py holds the lane groups and this image).
 //     Which rows form an MFMA tile is free: the accumulator of lane (l15, g), register e, tiles (it, jt) is element
 //         row 8 (4 g + e) + it,  column 8 l15 + jt
 //     of the wave tile -- a lane OWNS 8 CONSECUTIVE COLUMNS (jt = 0..7) of 32 rows, which is exactly what the LDS-staged epilogue
@@ -34,16 +34,6 @@
 //     publishes it (W4: 64).  In the accounting of DESIGN K1: window + flight <= 200 MFMAs of the 256 two stages allow (W4: 128).
 // Same MFMAs in the same order as RF_SCHED_W4 / the 8-wave loop (k-step 0 then 1, K-tiles in order): bit-identical results.
 #pragma once
-#ifndef RF_W4B_VM0
-#define RF_W4B_VM0 0
-#endif
-#ifndef RF_W4B_LATE
-#define RF_W4B_LATE 0
-#endif
-#ifndef RF_W4B_KO      // knock-outs of scratch builds (timing only, results wrong): 1 no LDS-DMA, 2 no barriers 1 / 2, 3 barrier 3 without its
-#define RF_W4B_KO 0    // vmcnt, 4 no fragment reads, 5 MFMAs only
-#endif
-
 // what happens in front of MFMA m of a K-tile (m = 0..127; MFMA m multiplies A[(m / 8) % 8] with W[m % 8] of k-step m / 64)
 struct W4bPlan {
   signed char read[128];   // -1, or fragment to read: 0..7 W k-step 1, 8..15 A k-step 1 (this tile); 16..23 W k-step 0, 24..31 A k-step 0 (next tile)
@@ -57,13 +47,8 @@ constexpr W4bPlan w4b_plan() {
   p.bar[20] = 1;                                                             // W image of this tile is free
   for (int i = 0; i < 8; ++i) p.read[26 + 3 * i] = (signed char)(8 + i);     // A k-step 1: MFMAs 26..47 (A1[i] is needed at MFMA 64 + 8 i)
   p.bar[52] = 1;                                                             // A image of this tile is free
-#if RF_W4B_LATE
-  const int wp[8] = {54, 58, 62, 66, 70, 74, 78, 82};
-  const int ap[8] = {86, 90, 96, 100, 104, 108, 114, 122};
-#else
   const int wp[8] = {22, 28, 34, 40, 46, 54, 60, 66};                        // W pieces (22..46 before barrier 2 interleave with the A reads)
   const int ap[8] = {72, 78, 84, 90, 98, 106, 114, 122};                     // A pieces
-#endif
   for (int i = 0; i < 8; ++i) p.dma[wp[i]] = (signed char)i;
   for (int i = 0; i < 8; ++i) p.dma[ap[i]] = (signed char)(8 + i);
   p.bar[93] = 2;                                                             // the next tile has landed for every wave (12 pieces of this tile in flight)
@@ -154,21 +139,19 @@ __device__ __forceinline__ void gemm_mainloop_w4b(const GemmGroupDev& G, const i
 #define RF_W4B_SLOT(m)                                                                                       \
   {                                                                                                          \
     constexpr int r_ = P.read[(m)], d_ = P.dma[(m)], b_ = P.bar[(m)];                                        \
-    if constexpr (b_ == 1 && RF_W4B_KO != 2 && RF_W4B_KO != 5) {                                             \
+    if constexpr (b_ == 1) {                                             \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
       __builtin_amdgcn_s_barrier();                                                                          \
-    } else if constexpr (b_ == 2 && NEXT && RF_W4B_KO != 5) {                                                \
-      if constexpr (RF_W4B_KO == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       \
-      else if constexpr (DMA && !RF_W4B_VM0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BEFORE3) : "memory"); \
+    } else if constexpr (b_ == 2 && NEXT) {                                                \
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BEFORE3) : "memory"); \
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
       __builtin_amdgcn_s_barrier();                                                                          \
     }                                                                                                        \
-    if constexpr (RF_W4B_KO >= 4) {                                                                          \
-    } else if constexpr (r_ >= 0 && r_ < 8) B1[r_ & 7] = *(const bf16x8*)(cur + fb1 + (r_ & 7) * 128);             \
+    if constexpr (r_ >= 0 && r_ < 8) B1[r_ & 7] = *(const bf16x8*)(cur + fb1 + (r_ & 7) * 128);             \
     else if constexpr (r_ >= 8 && r_ < 16) A1[r_ & 7] = *(const bf16x8*)(cur + fa1 + (r_ & 7) * 128);       \
     else if constexpr (r_ >= 16 && r_ < 24 && NEXT) B0[r_ & 7] = *(const bf16x8*)(oth + fb0 + (r_ & 7) * 128); \
     else if constexpr (r_ >= 24 && NEXT) A0[r_ & 7] = *(const bf16x8*)(oth + fa0 + (r_ & 7) * 128);         \
-    if constexpr (DMA && d_ >= 0 && RF_W4B_KO != 1 && RF_W4B_KO != 5) piece(c, dstage, d_ & 15);                                                 \
+    if constexpr (DMA && d_ >= 0) piece(c, dstage, d_ & 15);                                                 \
     if constexpr ((m) < 64) RF_W4B_MFMA(acc[((m) >> 3) & 7][(m) & 7], A0[((m) >> 3) & 7], B0[(m) & 7]);      \
     else RF_W4B_MFMA(acc[((m) >> 3) & 7][(m) & 7], A1[((m) >> 3) & 7], B1[(m) & 7]);                         \
     __builtin_amdgcn_sched_barrier(0);                                                                       \

@@ -53,3 +53,35 @@ def test_dma_side_of_the_transposed_tiles_is_the_inverse_of_the_read_side():
         row, pos = lane >> 2, lane & 3
         chunk = pos ^ SWZ[(lane >> 4) & 3]
         assert chunk ^ SWZ[(row & 15) >> 2] == pos
+
+
+def test_w4b_lane_linear_image_is_conflict_free_without_a_source_swizzle():
+    """gemm_w4b.hpp (round 5): an operand's K-tile as 32 lane-linear wave pieces (8 rows x 128 B, one LDS-DMA instruction each, lane l ->
+    row l / 8, chunk l % 8) at byte p * 1056; MFMA tile j of a 128-row strip = rows {8 r + j}; lane (r = l15, g) of a fragment read
+    of tile j, k-step s at (p0 + r) * 1056 + j * 128 + (4 s + g) * 16.  The 32 B of padding per piece (66 slots = 2 mod 16) is what
+    makes it conflict-free: the same strided tiles on un-padded pieces are 8-way, contiguous 16-row tiles conflict at any padding."""
+    def frag(piece, tiles):
+        return lambda j, s: (lambda l: tiles(l & 15, j, piece) + (4 * s + (l >> 4)) * 16)
+    strided = lambda r, j, piece: r * piece + j * 128                              # noqa: E731
+    contiguous = lambda r, j, piece: ((16 * j + r) >> 3) * piece + ((16 * j + r) & 7) * 128   # noqa: E731
+    for p0 in (0, 16):
+        for j in range(8):
+            for s in range(2):
+                assert ways(lambda l: p0 * 1056 + frag(1056, strided)(j, s)(l)) == 1
+    assert max(ways(frag(1024, strided)(j, s)) for j in range(8) for s in range(2)) == 8
+    for pad in range(0, 256, 16):
+        assert max(ways(frag(1024 + pad, contiguous)(j, s)) for j in range(8) for s in range(2)) >= 2
+    # the DMA side: a wave piece is written lane-linearly -- 64 lanes x 16 B, contiguous, each lane at its own 16-byte slot
+    assert sorted((l >> 3) * 128 + (l & 7) * 16 for l in range(64)) == [16 * i for i in range(64)]
+    # every (row, chunk) of the 128-row strip is read by exactly one (tile, lane, k-step)
+    seen = set()
+    for j in range(8):
+        for s in range(2):
+            for l in range(64):
+                r, g = l & 15, l >> 4
+                seen.add((8 * r + j, 4 * s + g))
+    assert len(seen) == 128 * 8
+    # accumulator ownership of the register-direct epilogue: lane (l15, g), register e, tiles (it, jt) <-> (row 8 (4 g + e) + it,
+    # column 8 l15 + jt): a bijection onto the 128 x 128 wave tile with 8 consecutive columns per lane and row
+    cover = {(8 * (4 * g + e) + it, 8 * l15 + jt) for g in range(4) for e in range(4) for it in range(8) for l15 in range(16) for jt in range(8)}
+    assert len(cover) == 128 * 128
