@@ -305,7 +305,7 @@ def pmc_traffic(S_txt, S_img, D, mlp):
     FETCH_SIZE doubled per the gfx950 correction), forward-weighted like `achieved`.  Newest round wins."""
     if (S_txt, S_img, D, mlp) != (512, 4096, 3072, 12288):
         return None, None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_kernels.json")
         if os.path.exists(pmc):
             pj = json.load(open(pmc))["_summary"]

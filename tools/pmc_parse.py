@@ -49,7 +49,8 @@ for n, e in rows.items():
     ab, fl, cnt = alg[n]
     cyc = e['GRBM_GUI_ACTIVE'] / 8
     util = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) * 100
-    assert abs(e['SQ_VALU_MFMA_BUSY_CYCLES'] / (32 * fl / 32768) - 1) < 0.03, n   # v4 attention: +1.4 % (one stale score tile, one zero PV)
+    dev_ = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (32 * fl / 32768) - 1
+    assert abs(dev_) < (0.10 if n.startswith('attn') else 0.03), (n, dev_)   # attention: the mixed-size launch multiplies padded query rows (+4..6 %)
     clk = cyc / e['ns_p4']
     ldsc = e['SQ_LDS_BANK_CONFLICT'] / max(e['SQ_LDS_IDX_ACTIVE'], 1) * 100
     out[n] = dict(kernel=e['kernel'], launches_per_forward=cnt, us_profiled=round(us, 1), fabric_read_bytes=fetch, write_bytes=write,
