@@ -3,7 +3,21 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reflectionflow_amd import _lib as L, ops
-from tools.kbench import timeit
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
 dev = torch.device("cuda:0"); lib = L.load()
 for S, cands in ((4608, (0, 4, 8, 12, 16, 20, 24)), (5632, (0, 8, 16, 20, 24, 28))):
     H = 24
