@@ -243,3 +243,98 @@ def test_lora_prodigy_kernels_against_the_oracle(dev):
     p16, t16 = run(BF, False)
     assert abs(t16[-1] - t32[-1]) <= 0.05 * t32[-1]
     assert float((p16.float() - p32.float()).norm() / p32.float().norm()) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------- co-residency stress (hardening)
+def _stable(fn, n=10):
+    outs = []
+    for _ in range(n):
+        o = fn()
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (o if isinstance(o, (list, tuple)) else [o])])
+    return [i for i in range(1, n) if not all(torch.equal(a, b) for a, b in zip(outs[i], outs[0]))]
+
+
+def test_kernels_that_share_a_cu_are_bit_stable(dev):
+    """The round-5 defect needed TWO workgroups on one CU (one in its K loop, one in its epilogue).  Every other MFMA kernel of the
+    library whose workgroups can share a CU is launched here 10 times at a size with more workgroups than CUs and must give one
+    result: the 128 x 128 GEMM on every epilogue (STORE / GELU / gated residual / QKV without and with the fused RoPE / QKV + GELU /
+    split-K), the online-softmax attention kernels (masked, biased and ragged launches), the T5 attention + GEMMs through a
+    2-layer encoder, the VAE's one-head attention through a decode, the token-axis skinny GEMM, and the attention backward's
+    two-per-CU dK / dV form."""
+    from reflectionflow_amd import _lib as L, ops
+    from reflectionflow_amd.train import kernels as K
+    g = torch.Generator(device=dev).manual_seed(0)
+    bad = {}
+    # --- 128 x 128 GEMM, 576 tiles
+    M, N, Kd = 1536, 3072, 1024
+    x, W, b = _rnd(dev, g, M, Kd), _rnd(dev, g, N, Kd, sc=0.03), _rnd(dev, g, N)
+    gate, res = _rnd(dev, g, N), _rnd(dev, g, M, N)
+    with ops.gemm_schedule(L.RF_SCHED_TILE128):
+        bad["gemm128 store"] = _stable(lambda: ops.linear(x, W, b, splitk_ws=False))
+        bad["gemm128 gelu"] = _stable(lambda: ops.linear(x, W, b, epilogue=L.RF_EPI_GELU, splitk_ws=False))
+
+        def gr():
+            y = res.clone()
+            ops.gemm([ops.Group([ops.Seg(x, W)], bias=b, out=y, residual=y, gate=gate)], N, L.RF_EPI_GATE_RES, splitk_ws=False)
+            return y
+        bad["gemm128 gate_res"] = _stable(gr)
+        H, S = 8, 1536
+        D = H * 128
+        xq, Wq, bq = _rnd(dev, g, S, D), _rnd(dev, g, 3 * D + 2048, D, sc=0.03), _rnd(dev, g, 3 * D + 2048)
+        nw = (1 + 0.05 * torch.randn(128, device=dev, generator=g)).to(BF)
+        ids = torch.stack([torch.zeros(S), torch.arange(S) // 32, torch.arange(S) % 32], 1).to(dev)
+        cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
+
+        def qkv(rope, gelu):
+            q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+            hid = torch.empty(S, 2048, dtype=BF, device=dev)
+            n_ = 3 * D + (2048 if gelu else 0)
+            ops.gemm([ops.Group([ops.Seg(xq, Wq[:n_])], bias=bq[:n_], out=hid if gelu else None, norm_q=nw, norm_k=nw)], n_,
+                     L.RF_EPI_QKV_GELU if gelu else L.RF_EPI_QKV, n_split=3 * D if gelu else 0, q=q, k=k, vt=vt, heads=H, s_pad=s_pad,
+                     rope=(cos, sin) if rope else None, q_scale=ops.QK_PRESCALE, splitk_ws=False)
+            return [q, k, vt] + ([hid] if gelu else [])
+        bad["gemm128 qkv"] = _stable(lambda: qkv(False, False))
+        bad["gemm128 qkv+rope"] = _stable(lambda: qkv(True, False))
+        bad["gemm128 qkv+rope+gelu"] = _stable(lambda: qkv(True, True))
+    xs, As = _rnd(dev, g, 1024, 12288), _rnd(dev, g, 64, 12288, sc=0.03)
+    bad["gemm128 split-K (LoRA down)"] = _stable(lambda: ops.lora_down(xs, As))
+    # --- attention: online-softmax kernels (48 KiB / 80 KiB of LDS: several workgroups per CU), masked / biased / ragged
+    for H, S, mode, nm in ((24, 1500, 0, None), (24, 2048, 1, 1024), (16, 2304, 2, 1280)):
+        q, k, vt, s_pad = ops.alloc_attn_operands(H, S, dev)
+        q.normal_(generator=g), k.normal_(generator=g), vt.normal_(generator=g)
+        for kern in (L.RF_ATTN_ONLINE128, L.RF_ATTN_ONLINE256):
+            try:
+                bad[f"attention kernel {kern} H={H} S={S} mode={mode}"] = _stable(
+                    lambda: ops.attention(q, k, vt, S, n_main=nm, mode=mode, cross_bias=0.3 if mode else 0.0, kernel=kern))
+            except ops.RFError:
+                pass
+    # --- token-axis skinny GEMM and the attention backward's two-per-CU form
+    big, sk = _rnd(dev, g, 5632, 12288), _rnd(dev, g, 5632, 64)
+    bad["gemm_tn_skinny"] = _stable(lambda: K.gemm_tn(big, sk))
+    H, S = 24, 2560
+    raw = _rnd(dev, g, S, 3 * H * 128, sc=1.5)
+    w1 = torch.ones(128, device=dev).to(BF)
+    ids = torch.stack([torch.zeros(S), torch.arange(S) // 64, torch.arange(S) % 64], 1).to(dev)
+    cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
+    a = K.qkv_train_fwd(raw, H, 0, (w1, w1, None, None), cos, sin)
+    out = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True)
+    dout = _rnd(dev, g, S, H * 128)
+    bad["attention_bwd dq128 + dkv128x2"] = _stable(lambda: list(K.attention_bwd(a, out, dout, kernel=L.RF_ATTN_BWD_DQ_128 | L.RF_ATTN_BWD_DKV_128X2)))
+    # --- T5 (attn64 + small GEMMs) and the VAE (one-head attention + conv GEMMs) through their encoders
+    from oracle import text_oracle as TXO
+    from reflectionflow_amd.flux.text_hip import HipT5Encoder
+    sd = {k_: v.to(BF).float() for k_, v in TXO.synthetic_t5_state(300, 512, 64, 8, 1024, 2, 6).items()}
+    enc = HipT5Encoder(sd, 8, dev)
+    ids_t = torch.randint(0, 300, (8, 512), generator=torch.Generator().manual_seed(1)).to(dev)
+    with torch.no_grad():
+        bad["t5 encoder (8 x 512 tokens)"] = _stable(lambda: enc.encode(ids_t), n=6)
+        from reflectionflow_amd.flux import vae as V
+        from reflectionflow_amd.flux.vae_hip import HipVAE
+        vae = V.init_synthetic_vae_(V.AutoencoderKL(block_out_channels=(64, 128, 512), norm_num_groups=32, mid_block_add_attention=True), seed=1).eval()
+        hv = HipVAE(vae.to(dev).to(BF))
+        z = torch.randn(2, 16, 32, 32, generator=torch.Generator().manual_seed(2)).to(dev).to(BF)
+        bad["vae decode (2 x 32 x 32 latents)"] = _stable(lambda: hv.decode(z).sample, n=6)
+    failed = {k_: v for k_, v in bad.items() if v}
+    print(f"  {len(bad)} kernel configurations x 6-10 launches: all bit-stable" if not failed else f"  NOT bit-stable: {failed}")
+    assert not failed, failed
