@@ -727,11 +727,14 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
     F_, B_ = gemm_f + att_f, gemm_f + 2.5 * att_f
     cl = pr.classes
     state_bytes = opt.exp_avg.element_size()
+    # (Prodigy starts at d0 = 1e-6: over the handful of steps timed here the loss does not move yet; d and the step count are reported)
+    prodigy_state = {k: (round(v, 12) if isinstance(v, float) else v) for k, v in opt.d_state().items() if k in ("d", "d_hat", "k")} \
+        if optimizer == "Prodigy" else None
     return {"what": f"ONE LoRA training step (train_flux/train/model.py:164-238 + optimizer), {nd} double + {ns} single blocks, S = {St} text + {Si} image "
                     f"({target}^2) + {Sc} condition ({cond}^2) = {S} tokens (config.yaml:39-40), LoRA r = {rank} on the condition rows, batch 1",
             "ms_per_step": round(ms, 2), "steps": steps, "warmup": warmup,
             "optimizer": {"type": optimizer, "params": ocfg["params"], "kernel": "rf_lora_prodigy (3 launches, d on the device)" if optimizer == "Prodigy" else "rf_lora_adamw (1 launch)",
-                          "ms": round(opt_ms, 3), "lora_parameters": n_lora, "state": "bf16" if state_bytes == 2 else "fp32",
+                          "ms": round(opt_ms, 3), "lora_parameters": n_lora, "prodigy_distance_estimate": prodigy_state, "state": "bf16" if state_bytes == 2 else "fp32",
                           "parity": "unpinned (prodigyopt not available offline; oracle/optim_oracle.py restates the published algorithm)" if optimizer == "Prodigy"
                                     else "within 1 bf16 ulp of torch.optim.AdamW (tests/test_round5_gpu.py)"},
             "tflop": {"forward": round(F_ / 1e12, 2), "backward": round(B_ / 1e12, 2), "executed_with_recompute": round((2 * F_ + B_) / 1e12, 2),
