@@ -644,7 +644,7 @@ class Telemetry:
 # ------------------------------------------------------------------------------------------------------
 # training step: the other caller of the hot functions, in front of the driver
 # ------------------------------------------------------------------------------------------------------
-def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2, optimizer="Prodigy"):
+def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2, optimizer="Prodigy", batch_size=1):
     """One LoRA training step of the 57-block model at the sizes the reference trains at (config.yaml:39-40: target_size 1024,
     condition_size 512 -> 512 text + 4096 image + 1024 condition = 5632 tokens; LoRA r = 32 on the FLUX-Corrector target list,
     config.yaml:50-53; optimizer = the shipped Prodigy config :55-61), batch 1: zero_grad, forward, per-block recompute + backward,
@@ -677,9 +677,10 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
         return torch.stack([torch.zeros(n * n), torch.arange(n).repeat_interleave(n).float(), torch.arange(n).repeat(n).float()], 1).to(dev)
     cond_ids = ids(gc)
     cond_ids[:, 2] -= gc
-    batch = dict(x_0=r(1, Si, 64), img_ids=ids(gh), prompt_embeds=r(1, St, tr.config.joint_attention_dim), pooled_prompt_embeds=r(1, tr.config.pooled_projection_dim),
-                 text_ids=torch.zeros(St, 3, device=dev), condition_latents=r(1, Sc, 64), condition_ids=cond_ids, t=torch.tensor([0.5], device=dev),
-                 x_1=r(1, Si, 64))
+    Bn = int(batch_size)      # the reference trains at batch 8 per GPU (config.yaml:11); the samples of a batch run one after the other here
+    batch = dict(x_0=r(Bn, Si, 64), img_ids=ids(gh), prompt_embeds=r(Bn, St, tr.config.joint_attention_dim), pooled_prompt_embeds=r(Bn, tr.config.pooled_projection_dim),
+                 text_ids=torch.zeros(St, 3, device=dev), condition_latents=r(Bn, Sc, 64), condition_ids=cond_ids, t=torch.full((Bn,), 0.5, device=dev),
+                 x_1=r(Bn, Si, 64))
     cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
     trainer = FluxTrainer(tr, cfg)
     ocfg = {"Prodigy": {"type": "Prodigy", "params": {"lr": 1, "use_bias_correction": True, "safeguard_warmup": True, "weight_decay": 0.01}},
@@ -691,7 +692,7 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
         x_t = (0.5 * batch["x_0"].float() + 0.5 * batch["x_1"].float()).to(BF)
         pred_inf = tranformer_forward(tr, batch["condition_latents"], cond_ids, None, model_config=cfg, hidden_states=x_t,
                                       encoder_hidden_states=batch["prompt_embeds"], pooled_projections=batch["pooled_prompt_embeds"],
-                                      timestep=batch["t"], guidance=torch.ones(1, device=dev), img_ids=batch["img_ids"], txt_ids=batch["text_ids"],
+                                      timestep=batch["t"], guidance=torch.ones(Bn, device=dev), img_ids=batch["img_ids"], txt_ids=batch["text_ids"],
                                       return_dict=False)[0]
         loss_inf = float(torch.nn.functional.mse_loss(pred_inf, (batch["x_1"] - batch["x_0"]).to(pred_inf.dtype)))
     opt.zero_grad()
@@ -719,19 +720,22 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
     o1.record()
     torch.cuda.synchronize()
     opt_ms = o0.elapsed_time(o1) / 4
-    with ops.profile(max_launches=24000) as pr:
+    with ops.profile(max_launches=4000 * Bn + 4000) as pr:
         trainer.training_step(batch)
         torch.cuda.synchronize()
     gemm_f = nd * S * (2 * D * 3 * D + 2 * D * D + 2 * 2 * D * mlp) + ns * S * (2 * D * (3 * D + mlp) + 2 * (D + mlp) * D)
     att_f = (nd + ns) * 4 * S * S * D
-    F_, B_ = gemm_f + att_f, gemm_f + 2.5 * att_f
+    F_, B_ = Bn * (gemm_f + att_f), Bn * (gemm_f + 2.5 * att_f)
     cl = pr.classes
     state_bytes = opt.exp_avg.element_size()
     # (Prodigy starts at d0 = 1e-6: over the handful of steps timed here the loss does not move yet; d and the step count are reported)
     prodigy_state = {k: (round(v, 12) if isinstance(v, float) else v) for k, v in opt.d_state().items() if k in ("d", "d_hat", "k")} \
         if optimizer == "Prodigy" else None
     return {"what": f"ONE LoRA training step (train_flux/train/model.py:164-238 + optimizer), {nd} double + {ns} single blocks, S = {St} text + {Si} image "
-                    f"({target}^2) + {Sc} condition ({cond}^2) = {S} tokens (config.yaml:39-40), LoRA r = {rank} on the condition rows, batch 1",
+                    f"({target}^2) + {Sc} condition ({cond}^2) = {S} tokens (config.yaml:39-40), LoRA r = {rank} on the condition rows, batch {Bn}"
+                    + (" (the reference's config.yaml:11 trains at batch 8; samples of a batch run sequentially, one optimizer update per batch)" if Bn == 1 else
+                       " (samples run sequentially; one optimizer update per batch)"),
+            "batch_size": Bn, "ms_per_sample": round(ms / Bn, 2),
             "ms_per_step": round(ms, 2), "steps": steps, "warmup": warmup,
             "optimizer": {"type": optimizer, "params": ocfg["params"], "kernel": "rf_lora_prodigy (3 launches, d on the device)" if optimizer == "Prodigy" else "rf_lora_adamw (1 launch)",
                           "ms": round(opt_ms, 3), "lora_parameters": n_lora, "prodigy_distance_estimate": prodigy_state, "state": "bf16" if state_bytes == 2 else "fp32",
@@ -821,6 +825,7 @@ def main():
     ap.add_argument("--train-optimizer", choices=["Prodigy", "AdamW"], default="Prodigy")
     ap.add_argument("--train-target", type=int, default=1024)
     ap.add_argument("--train-cond", type=int, default=512)
+    ap.add_argument("--train-batch", type=int, default=1, help="samples per training step (the reference's config trains at 8; default 1 keeps the default run short)")
     ap.add_argument("--n1-value", type=float, default=None,
                     help="the N = 1 value of this metric: with --gpus N > 1 the line then also carries scaling_efficiency = value / (N * n1_value)")
     args = ap.parse_args()
@@ -857,7 +862,8 @@ def main():
     pipe = build_model(dev, cfg, seed=0)
     tr = pipe.transformer
     if args.train_only:
-        out = training_table(dev, pipe, args.train_target, args.train_cond, optimizer=args.train_optimizer)
+        out = training_table(dev, pipe, args.train_target, args.train_cond, optimizer=args.train_optimizer, batch_size=args.train_batch,
+                             steps=4 if args.train_batch == 1 else 2, warmup=2 if args.train_batch == 1 else 1)
         if args.small:
             out["INVALID"] = "debug model (--small)"
         print(json.dumps({"training": out}), flush=True)
@@ -1036,7 +1042,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(S_txt, S_img, T, D, heads, nd, ns)
             if not args.no_train and not args.small and not args.lean:
                 # last: it loads a LoRA into the model and re-homes its factors (the inference measurements above ran without one)
-                res["training"] = training_table(dev, pipe, args.train_target, args.train_cond, optimizer=args.train_optimizer)
+                res["training"] = training_table(dev, pipe, args.train_target, args.train_cond, optimizer=args.train_optimizer, batch_size=args.train_batch)
         if args.n1_value and shard.world_size > 1:
             res["scaling_efficiency"] = round(value / (shard.world_size * args.n1_value), 4)
             res["n1_value"] = args.n1_value
