@@ -338,3 +338,45 @@ def test_kernels_that_share_a_cu_are_bit_stable(dev):
     failed = {k_: v for k_, v in bad.items() if v}
     print(f"  {len(bad)} kernel configurations x 6-10 launches: all bit-stable" if not failed else f"  NOT bit-stable: {failed}")
     assert not failed, failed
+
+
+@torch.no_grad()
+def test_search_pipeline_folds_its_static_lora_by_default(dev, tmp_path):
+    """runner.build_pipeline (what the tts entry points call): a `lora_path` is loaded AND folded into per-token-group weight copies by
+    default (the search never changes its one LoRA; +11 GB at FLUX.1-dev size on a 288 GB part) -- `"merged_lora": false` keeps the
+    K-segment form.  Both give the same conditioned latents to bf16 rounding of the merged sum, and image-only generation (no condition
+    rows: LoRA gated off) is BIT-equal between them: the reference's enable_lora gating survives the fold."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from reflectionflow_amd.flux.condition import Condition
+    from reflectionflow_amd.flux.generate import generate
+    from reflectionflow_amd.flux.pipeline import synthetic_lora_state_dict
+    from reflectionflow_amd.tts import runner
+    cfg = json.load(open(os.path.join(os.path.dirname(runner.__file__), "configs", "flux1_dev_mi355x.json")))
+    probe = runner.build_pipeline(cfg, dev, synthetic=True, small=True)
+    lora_file = str(tmp_path / "corrector.safetensors")
+    save_file({k: v.contiguous() for k, v in synthetic_lora_state_dict(probe.transformer, r=8, seed=3).items()}, lora_file)
+    outs = {}
+    for merged in (True, False):
+        c = json.loads(json.dumps(cfg))
+        c["pipeline_args"]["lora_path"] = lora_file
+        if not merged:
+            c["pipeline_args"]["merged_lora"] = False
+        pipe = runner.build_pipeline(c, dev, synthetic=True, small=True)
+        assert bool(getattr(pipe.transformer, "_rf_merged_lora", False)) == merged
+        g = torch.Generator().manual_seed(4)
+        tr = pipe.transformer
+        pe = torch.randn(1, 64, tr.config.joint_attention_dim, generator=g).to(dev).to(BF)
+        pooled = torch.randn(1, tr.config.pooled_projection_dim, generator=g).to(dev).to(BF)
+        lat = torch.randn(1, 256, 64, generator=g).to(dev).to(BF)
+        cond = torch.randn(1, 64, 64, generator=g).to(dev).to(BF)
+        mc = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+        kw = dict(model_config=mc, default_lora=True, height=256, width=256, num_inference_steps=3, guidance_scale=3.5, prompt_embeds=pe,
+                  pooled_prompt_embeds=pooled, output_type="latent")
+        conds = [Condition("cot", tokens=cond, ids=O.condition_ids_for(128).to(dev))]
+        outs[merged] = (generate(pipe, conditions=conds, latents=lat.clone(), **kw).images, generate(pipe, conditions=None, latents=lat.clone(), **kw).images)
+    rel = float((outs[True][0].float() - outs[False][0].float()).norm() / outs[False][0].float().norm())
+    print(f"  merged vs K-segment LoRA through build_pipeline: rel-L2 {rel:.2e} (conditioned), image-only bit-equal {bool(torch.equal(outs[True][1], outs[False][1]))}")
+    assert 0 < rel < 2e-2
+    assert torch.equal(outs[True][1], outs[False][1])
