@@ -111,14 +111,13 @@ __global__ __launch_bounds__(OPT_THREADS) void prodigy_moments_kernel(const bf16
                                                                       void* __restrict__ exp_avg, void* __restrict__ exp_avg_sq, void* __restrict__ s_,
                                                                       const bf16_t* __restrict__ p0, int64_t n, const double* __restrict__ dstate,
                                                                       ProdigyCfg c, float* __restrict__ partials) {
-  __shared__ float sc[4];
+  __shared__ float sc[3];
   __shared__ float red[2][OPT_THREADS / WAVE];
   if (threadIdx.x == 0) {
     const double d = dstate[0], d0 = dstate[7], dlr = prodigy_dlr(dstate, c);
     sc[0] = (float)(d * (1.0 - (double)c.beta1));
     sc[1] = (float)(d * d * (1.0 - (double)c.beta2));
     sc[2] = (float)((d / d0) * (c.safeguard_warmup ? d : dlr));
-    sc[3] = 0.f;
   }
   __syncthreads();
   const float a_m = sc[0], a_v = sc[1], a_s = sc[2];
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(OPT_THREADS) void prodigy_apply_kernel(bf16_t* __re
                                                                     const void* __restrict__ exp_avg_sq, int64_t n, const double* __restrict__ dstate,
                                                                     ProdigyCfg c) {
   const float dlr = (float)dstate[6];
-  if (dlr == 0.f && dstate[3] == 0.0) return;       // the skipped step (see finalize)
+  if (dlr == 0.f) return;       // the skipped step (finalize left dlr = 0), or lr = 0: the update is the identity either way
   const float d_eps = (float)(dstate[0] * (double)c.eps);
   const float decay_mul = (c.decay != 0.f && c.decouple) ? -c.decay * dlr : 0.f;
   const int64_t base = (int64_t)blockIdx.x * OPT_BLOCK_ELEMS + threadIdx.x * OPT_VEC;

@@ -161,9 +161,40 @@ __global__ __launch_bounds__(256) void qkv_train_bwd_kernel(const bf16_t* __rest
   *(u32x4*)(drow + 2 * D + 8) = *(const u32x4*)(dv + hrow + 8);
 }
 
+// The four waves of a block add their per-lane column sums through LDS in wave order -- ((w0 + w1) + w2) + w3, bit-reproducible --
+// and wave 3 stores the block's sums to dst[0 .. D).  sm: NCH * 512 floats.
+template <int NCH>
+__device__ __forceinline__ void block_colsum(float (&acc)[NCH][8], float* sm, float* __restrict__ dst, int D, int lane, int w) {
+#pragma unroll
+  for (int turn = 0; turn < 4; ++turn) {
+    if (w == turn) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < D) {
+          if (turn > 0) {
+            const f32x4 a = *(const f32x4*)(sm + col), b = *(const f32x4*)(sm + col + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[c][j] = a[j] + acc[c][j], acc[c][4 + j] = b[j] + acc[c][4 + j];
+          }
+          f32x4 a, b;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = acc[c][j], b[j] = acc[c][4 + j];
+          float* o = turn < 3 ? sm + col : dst + col;
+          *(f32x4*)o = a, *(f32x4*)(o + 4) = b;
+        }
+      }
+    }
+    if (turn < 3) __syncthreads();
+  }
+}
+
 // ---- LayerNorm + modulate, backward --------------------------------------------------------------------------------------------
-// One wave per row, grid-stride over the rows; a lane keeps the column sums of ITS columns over ITS rows and writes them to
-// partials[wave][2][D] (d shift | d scale); colsum_reduce_kernel adds the waves in index order.
+// One wave per row, grid-stride over the rows; a lane keeps the column sums of ITS columns over ITS rows, the block adds its four
+// waves (block_colsum) and writes partials[block][2][D] (d shift | d scale); colsum_reduce_kernel adds the blocks in index order.
+// At D = 3072 the column sums alone are 96 registers per lane, so a SIMD holds ONE wave: the loads of a wave's next row (x, dy, dres
+// as packed 16-byte registers) are issued before the arithmetic of the current one, and the grid covers every CU (round 4 ran 128
+// blocks, each row's loads exposed: 90 us for 4096 x 3072 where the traffic is worth 25).
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
                                                          int64_t lddy, const bf16_t* __restrict__ dres, int64_t lddres,
@@ -182,24 +213,34 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) a_shift[c][j] = 0.f, a_scale[c][j] = 0.f, sc1[c][j] = 1.0f + t[j];
   }
-  for (int row = wave; row < rows; row += nwaves) {
-    const bf16_t* xr = x + (int64_t)row * ldx;
-    const bf16_t* gr = dy + (int64_t)row * lddy;
-    float v[NCH][8], gy[NCH][8];
-    float s = 0.f;
+  u32x4 xq[NCH], gq[NCH], rq[NCH];      // the row in flight, packed (columns >= D stay zero)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) xq[c] = gq[c] = rq[c] = u32x4{0u, 0u, 0u, 0u};
+  auto fetch = [&](int row) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = (c * 64 + lane) * 8;
       if (col < D) {
-        unpack8(*(const u32x4*)(xr + col), v[c]);
-        unpack8(*(const u32x4*)(gr + col), gy[c]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[c][j] = 0.f, gy[c][j] = 0.f;
+        xq[c] = *(const u32x4*)(x + (int64_t)row * ldx + col);
+        gq[c] = *(const u32x4*)(dy + (int64_t)row * lddy + col);
+        if (dres != nullptr) rq[c] = *(const u32x4*)(dres + (int64_t)row * lddres + col);
       }
+    }
+  };
+  if (wave < rows) fetch(wave);
+  for (int row = wave; row < rows; row += nwaves) {
+    float v[NCH][8], gy[NCH][8];
+    u32x4 rcur[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      unpack8(xq[c], v[c]);
+      unpack8(gq[c], gy[c]);
+      rcur[c] = rq[c];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[c][j];
     }
+    if (row + nwaves < rows) fetch(row + nwaves);
     const float mean = wave_sum_t(s) / (float)D;
     float qv = 0.f;
 #pragma unroll
@@ -240,24 +281,18 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restric
       const int col = (c * 64 + lane) * 8;
       if (col < D) {
         float r8[8], o8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r8[j] = 0.f;
-        if (dres != nullptr) unpack8(*(const u32x4*)(dres + (int64_t)row * lddres + col), r8);
+        unpack8(rcur[c], r8);                 // zero without a residual gradient
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = r8[j] + rstd * (gy[c][j] - m1 - v[c][j] * m2);
         *(u32x4*)(orow + col) = pack8(o8);
       }
     }
   }
-  float* pw = partials + (int64_t)wave * 2 * D;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 64 + lane) * 8;
-    if (col < D) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pw[col + j] = a_shift[c][j], pw[D + col + j] = a_scale[c][j];
-    }
-  }
+  __shared__ float sm[NCH * 512];
+  float* pw = partials + (int64_t)blockIdx.x * 2 * D;
+  block_colsum<NCH>(a_shift, sm, pw, D, lane, threadIdx.x >> 6);
+  __syncthreads();                            // (wave 3 has read the last LDS image before the next one is written)
+  block_colsum<NCH>(a_scale, sm, pw + D, D, lane, threadIdx.x >> 6);
 }
 
 // out[c] = sum_w partials[w][c] in a FIXED order: a block owns 64 columns; thread (c, j) adds the partial rows j, j + 4, j + 8, ... with
@@ -321,15 +356,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* __restrict_
       }
     }
   }
-  float* pw = partials + (int64_t)wave * D;
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 64 + lane) * 8;
-    if (col < D) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pw[col + j] = acc[c][j];
-    }
-  }
+  __shared__ float sm[NCH * 512];
+  block_colsum<NCH>(acc, sm, partials + (int64_t)blockIdx.x * D, D, lane, threadIdx.x >> 6);
 }
 
 // y = res + gate o f (the training path keeps f = the projection's bf16 output for the gate gradient, so the gated residual is its
@@ -399,9 +427,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
-static int row_blocks(int rows) {
+// blocks of four row-waves; one fp32 partial row per BLOCK, so rf_train_partials_bytes' 512 rows bound the grid
+static int row_blocks(int rows, int cap) {
   const int b = cdiv(rows, 4);
-  return b < 128 ? b : 128;      // <= 512 waves: 512 x 2 x D fp32 partials
+  return b < cap ? b : cap;
 }
 
 
@@ -622,12 +651,12 @@ extern "C" int rf_layernorm_modulate_bwd(const void* x, int64_t ldx, const void*
              RF_ERR_SHAPE, "rf_layernorm_modulate_bwd: rows=%d D=%d (D %% 8 == 0, D <= 3072)", rows, D);
   RF_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(scale) && (dres == nullptr || aligned16(dres)), RF_ERR_ALIGN,
              "rf_layernorm_modulate_bwd: 16-byte alignment");
-  const int blocks = row_blocks(rows), nw = blocks * 4;
+  const int nch = cdiv(D, 512);
+  const int blocks = row_blocks(rows, nch > 4 ? 256 : 512), nw = blocks;   // nch > 4: one wave per SIMD, one block per CU
   RF_REQUIRE(partials_bytes >= (int64_t)nw * 2 * D * 4, RF_ERR_WORKSPACE, "rf_layernorm_modulate_bwd: partials need %lld bytes",
              (long long)nw * 2 * D * 4);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(RF_KC_ROWOP, (double)rows * D * 2.0 * (dres ? 4.0 : 3.0), st);
-  const int nch = cdiv(D, 512);
 #define RF_LNB(N)                                                                                                                    \
   hipLaunchKernelGGL(ln_mod_bwd_kernel<N>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy,           \
                      (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, rows, D, (const bf16_t*)scale, eps, partials)
@@ -650,7 +679,7 @@ extern "C" int rf_gate_bwd(const void* dy, int64_t lddy, const void* f, int64_t 
   RF_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 6 * 512 && lddy % 8 == 0 && ldf % 8 == 0 && lddf % 8 == 0, RF_ERR_SHAPE,
              "rf_gate_bwd: rows=%d D=%d", rows, D);
   RF_REQUIRE(aligned16(dy) && aligned16(f) && aligned16(gate) && aligned16(df), RF_ERR_ALIGN, "rf_gate_bwd: 16-byte alignment");
-  const int blocks = row_blocks(rows), nw = blocks * 4;
+  const int blocks = row_blocks(rows, 512), nw = blocks;
   RF_REQUIRE(partials_bytes >= (int64_t)nw * D * 4, RF_ERR_WORKSPACE, "rf_gate_bwd: partials need %lld bytes", (long long)nw * D * 4);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(RF_KC_ROWOP, (double)rows * D * 2.0 * 3.0, st);
