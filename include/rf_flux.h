@@ -502,7 +502,9 @@ int rf_clip_text_encode(const rf_clip_weights* w, const int32_t* ids, int32_t B,
  *   vt      : rf_attention's V^T tiles,
  *   qt, kt  : [heads][s_pad/32][128][32] TRANSPOSED TILES for rf_attention_bwd: element (d, slot(n)) of block n/32 holds
  *             x[n][d], slot(n) = 8 ((n%16)/4) + 4 ((n%32)/16) + n%4 -- the order in which a 16x16x32 MFMA consumes the
- *             rows of two 16x16 score tiles. */
+ *             rows of two 16x16 score tiles.
+ * v, qt, kt are the backward's operands: all three NULL = a forward nobody differentiates (the no-grad pass of a checkpointed
+ * block, train_flux/flux/transformer.py:139-157) writes q, k, vt only.  Giving some but not all is RF_ERR_NULL. */
 int rf_qkv_train_fwd(const void* raw, int64_t ld_raw, int32_t heads, int32_t S, int32_t s_pad, int32_t n_added,
                      const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k,
                      const float* cos_tab, const float* sin_tab, float eps, float q_scale,

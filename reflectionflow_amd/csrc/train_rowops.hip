@@ -83,11 +83,12 @@ __global__ __launch_bounds__(256) void qkv_train_fwd_kernel(const bf16_t* __rest
     load16(row + 2 * D, o[2]);
   }
   const int64_t hrow = ((int64_t)head * s_pad + tok) * 128 + c * 16;
+  const bool bwd_ops = qt != nullptr;     // (v, qt, kt are given or omitted together: a forward that nobody differentiates writes half the bytes)
   store16(q + hrow, o[0]);
   store16(k + hrow, o[1]);
-  store16(v + hrow, o[2]);
+  if (bwd_ops) store16(v + hrow, o[2]);
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = bwd_ops ? 0 : 2; a < 3; ++a)
 #pragma unroll
     for (int e = 0; e < 16; ++e) tl[a][i][c * 16 + e] = f2bf(o[a][e]);
   __syncthreads();
@@ -100,16 +101,21 @@ __global__ __launch_bounds__(256) void qkv_train_fwd_kernel(const bf16_t* __rest
     float a8[8], b8[8], v8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int n = e < 4 ? 4 * g + e : 16 + 4 * g + e - 4;              // token of slot 8 g + e (attention_bwd.hip slot32)
-      a8[e] = bf2f(tl[0][n][d]);
-      b8[e] = bf2f(tl[1][n][d]);
       // forward kernels' V^T: position = token with bits 2 and 3 swapped; positions 8 g .. 8 g + 7 of this half tile
       const int nv = 16 * (g >> 1) + 8 * (e >> 2) + 4 * (g & 1) + (e & 3);
       v8[e] = bf2f(tl[2][nv][d]);
     }
-    *(u32x4*)(qt + tbase + d * 32 + g * 8) = pack8(a8);
-    *(u32x4*)(kt + tbase + d * 32 + g * 8) = pack8(b8);
     *(u32x4*)(vtile + d * 64 + g * 8) = pack8(v8);
+    if (bwd_ops) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = e < 4 ? 4 * g + e : 16 + 4 * g + e - 4;            // token of slot 8 g + e (attention_bwd.hip slot32)
+        a8[e] = bf2f(tl[0][n][d]);
+        b8[e] = bf2f(tl[1][n][d]);
+      }
+      *(u32x4*)(qt + tbase + d * 32 + g * 8) = pack8(a8);
+      *(u32x4*)(kt + tbase + d * 32 + g * 8) = pack8(b8);
+    }
   }
 }
 
@@ -427,6 +433,33 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   }
 }
 
+// The same map with 16-byte accesses on both sides (pointers 16-byte aligned, pitches / cols / rows_pad multiples of 8: every LoRA
+// operand of the training step).  The 64 x 64 tile sits in LDS at a 144-byte row pitch; a thread gathers the 8 rows of one output run.
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __restrict__ src, int64_t lds_, int rows, int cols,
+                                                            bf16_t* __restrict__ dst, int64_t ldd, int rows_pad) {
+  __shared__ __attribute__((aligned(16))) bf16_t t[64][72];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int idx = tid + 256 * p, r = idx >> 3, c = (idx & 7) * 8;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (r0 + r < rows && c0 + c < cols) v = *(const u32x4*)(src + (int64_t)(r0 + r) * lds_ + c0 + c);
+    *(u32x4*)&t[r][c] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int idx = tid + 256 * p, c = idx >> 3, r = (idx & 7) * 8;
+    if (c0 + c < cols && r0 + r < rows_pad) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = (uint32_t)*(const uint16_t*)&t[r + 2 * e][c] | ((uint32_t)*(const uint16_t*)&t[r + 2 * e + 1][c] << 16);
+      *(u32x4*)(dst + (int64_t)(c0 + c) * ldd + r0 + r) = u32x4{w[0], w[1], w[2], w[3]};
+    }
+  }
+}
+
 // blocks of four row-waves; one fp32 partial row per BLOCK, so rf_train_partials_bytes' 512 rows bound the grid
 static int row_blocks(int rows, int cap) {
   const int b = cdiv(rows, 4);
@@ -454,7 +487,9 @@ __device__ __forceinline__ f32x4 mfma16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
   return c;
 #endif
 }
-template <int RT>   // RT = R / 16 (1, 2, 4 or 8) column tiles of the skinny operand
+// TR: the output is wanted transposed ([R][N]: dA) -- the MFMA operands swap roles, so a lane holds 4 rows j of ONE column n and the
+// partial tiles are written (and later summed) as [chunk][R][N] with n along the lanes: coalesced on both sides.
+template <int RT, bool TR>   // RT = R / 16 (1, 2, 4 or 8) column tiles of the skinny operand
 __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict__ big, int64_t ld_big, const bf16_t* __restrict__ sk,
                                                         int64_t ld_sk, float* __restrict__ ws, int S, int N) {
   constexpr int R = 16 * RT;
@@ -528,36 +563,50 @@ __global__ __launch_bounds__(256) void tn_skinny_kernel(const bf16_t* __restrict
       const int n = 16 * (2 * w + a) + l15;                    // this wave's column tiles 2 w, 2 w + 1
       const bf16x8 af = *(const bf16x8*)(bigT[buf] + n * 64 + ((g ^ tn_swz((n >> 2) & 3)) << 4));
 #pragma unroll
-      for (int b = 0; b < RT; ++b) acc[a][b] = mfma16x16x32(af, bf[b], acc[a][b]);
+      for (int b = 0; b < RT; ++b) acc[a][b] = TR ? mfma16x16x32(bf[b], af, acc[a][b]) : mfma16x16x32(af, bf[b], acc[a][b]);
     }
     if (st + 1 < nsteps) commit(buf ^ 1);
     __syncthreads();
   }
-  // partial tile: lane (g, j = l15) holds out[n = 16 (2 w + a) + 4 g + r][16 b + j]
-  float* dst = ws + ((int64_t)blockIdx.y * N + n0) * R;
+  if constexpr (TR) {
+    // partial tile: lane (g, l15) holds out^T[j = 16 b + 4 g + r][n = 16 (2 w + a) + l15]
+    float* dst = ws + (int64_t)blockIdx.y * R * N + n0;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = 16 * (2 * w + a) + 4 * g + r;
+    for (int a = 0; a < 2; ++a) {
+      const int n = 16 * (2 * w + a) + l15;
       if (n0 + n < N) {
 #pragma unroll
-        for (int b = 0; b < RT; ++b) dst[(int64_t)n * R + 16 * b + l15] = acc[a][b][r];
+        for (int b = 0; b < RT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(int64_t)(16 * b + 4 * g + r) * N + n] = acc[a][b][r];
       }
     }
+  } else {
+    // partial tile: lane (g, j = l15) holds out[n = 16 (2 w + a) + 4 g + r][16 b + j]
+    float* dst = ws + ((int64_t)blockIdx.y * N + n0) * R;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = 16 * (2 * w + a) + 4 * g + r;
+        if (n0 + n < N) {
+#pragma unroll
+          for (int b = 0; b < RT; ++b) dst[(int64_t)n * R + 16 * b + l15] = acc[a][b][r];
+        }
+      }
+  }
 }
 
-// out[n][j] (or out[j][n] when transposed) = bf16(sum over chunks, in chunk order)
+// out[n][j] (or out[j][n] when transposed) = bf16(sum over chunks, in chunk order).  The partials are [chunk][N][R], or [chunk][R][N] for a
+// transposed output: either way thread idx reads element idx of every chunk and writes element idx of a contiguous output row.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, int chunks, int N, int R, bf16_t* __restrict__ out,
                                                         int64_t ld_out, int transposed) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)N * R) return;
-  // transposed output: consecutive threads walk n (the contiguous axis of out[j][:]); plain: consecutive threads walk j
-  const int n = transposed ? (int)(idx % N) : (int)(idx / R), j = transposed ? (int)(idx / N) : (int)(idx % R);
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)N * R;
+  if (idx >= total) return;
   float v = 0.f;
-  for (int c = 0; c < chunks; ++c) v += ws[((int64_t)c * N + n) * R + j];
-  if (transposed) out[(int64_t)j * ld_out + n] = f2bf(v);
-  else out[(int64_t)n * ld_out + j] = f2bf(v);
+  for (int c = 0; c < chunks; ++c) v += ws[(int64_t)c * total + idx];
+  const int inner = transposed ? N : R;
+  out[(idx / inner) * ld_out + idx % inner] = f2bf(v);
 }
 
 }  // namespace rf
@@ -568,14 +617,16 @@ extern "C" int rf_qkv_train_fwd(const void* raw, int64_t ld_raw, int32_t heads, 
                                 const void* w_q, const void* w_k, const void* w_added_q, const void* w_added_k, const float* cos_tab,
                                 const float* sin_tab, float eps, float q_scale, void* q, void* k, void* v, void* vt, void* qt, void* kt,
                                 void* stream) {
-  RF_REQUIRE(raw && w_q && w_k && cos_tab && sin_tab && q && k && v && vt && qt && kt, RF_ERR_NULL, "rf_qkv_train_fwd: NULL operand");
+  RF_REQUIRE(raw && w_q && w_k && cos_tab && sin_tab && q && k && vt, RF_ERR_NULL, "rf_qkv_train_fwd: NULL operand");
+  RF_REQUIRE((v != nullptr) == (qt != nullptr) && (qt != nullptr) == (kt != nullptr), RF_ERR_NULL,
+             "rf_qkv_train_fwd: v, qt, kt (the backward's operands) are given or omitted together");
   RF_REQUIRE(n_added == 0 || (w_added_q && w_added_k), RF_ERR_NULL, "rf_qkv_train_fwd: text rows need norm_added_q / norm_added_k");
   RF_REQUIRE(heads > 0 && S > 0 && s_pad >= S && s_pad % 64 == 0 && ld_raw % 8 == 0 && ld_raw >= 3 * heads * 128, RF_ERR_SHAPE,
              "rf_qkv_train_fwd: heads=%d S=%d s_pad=%d ld=%lld", heads, S, s_pad, (long long)ld_raw);
   RF_REQUIRE(aligned16(raw) && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(vt) && aligned16(qt) && aligned16(kt),
              RF_ERR_ALIGN, "rf_qkv_train_fwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
-  ProfScope prof(RF_KC_ROWOP, (double)S * heads * 128.0 * 2.0 * (3.0 + 6.0), st);
+  ProfScope prof(RF_KC_ROWOP, (double)S * heads * 128.0 * 2.0 * (3.0 + (qt ? 6.0 : 3.0)), st);
   hipLaunchKernelGGL(qkv_train_fwd_kernel, dim3(s_pad / 32, heads), dim3(256), 0, st, (const bf16_t*)raw, ld_raw, heads, S, s_pad, n_added,
                      (const bf16_t*)w_q, (const bf16_t*)w_k, (const bf16_t*)w_added_q, (const bf16_t*)w_added_k, cos_tab, sin_tab, eps,
                      q_scale == 0.f ? 1.0f : q_scale, (bf16_t*)q, (bf16_t*)k, (bf16_t*)v, (bf16_t*)vt, (bf16_t*)qt, (bf16_t*)kt);
@@ -624,7 +675,11 @@ extern "C" int rf_gemm_tn_skinny(const void* big, int64_t ld_big, const void* sk
   for (int j0 = 0; j0 < R;) {
     const int rem = R - j0, Rs = rem >= 128 ? 128 : rem >= 64 ? 64 : rem >= 32 ? 32 : 16;
     const bf16_t* sks = (const bf16_t*)skinny + j0;
-#define RF_TN(RT_) hipLaunchKernelGGL(tn_skinny_kernel<RT_>, grid, dim3(256), 0, st, (const bf16_t*)big, ld_big, sks, ld_sk, ws, S, N)
+#define RF_TN(RT_)                                                                                                                \
+  do {                                                                                                                            \
+    if (transposed) hipLaunchKernelGGL((tn_skinny_kernel<RT_, true>), grid, dim3(256), 0, st, (const bf16_t*)big, ld_big, sks, ld_sk, ws, S, N);  \
+    else hipLaunchKernelGGL((tn_skinny_kernel<RT_, false>), grid, dim3(256), 0, st, (const bf16_t*)big, ld_big, sks, ld_sk, ws, S, N);            \
+  } while (0)
     if (Rs == 128) RF_TN(8);
     else if (Rs == 64) RF_TN(4);
     else if (Rs == 32) RF_TN(2);
@@ -749,8 +804,11 @@ extern "C" int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, 
              "rf_transpose_bf16: rows=%d cols=%d rows_pad=%d", rows, cols, rows_pad);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(RF_KC_ROWOP, (double)rows * cols * 4.0, st);
-  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(rows_pad, 64), cdiv(cols, 64)), dim3(256), 0, st, (const bf16_t*)src, ld_src, rows, cols,
-                     (bf16_t*)dst, ld_dst, rows_pad);
+  const dim3 grid(cdiv(rows_pad, 64), cdiv(cols, 64));
+  if (aligned16(src) && aligned16(dst) && ld_src % 8 == 0 && ld_dst % 8 == 0 && cols % 8 == 0 && rows_pad % 8 == 0)
+    hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, st, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
+  else
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }

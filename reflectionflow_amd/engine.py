@@ -25,6 +25,10 @@ from . import ops
 from .flux import modules as M
 
 
+# (the packed copies below are inference operands: made under no_grad -- a copy that carried a grad_fn would keep the factors' gradient
+#  accumulators alive on the stream it was made on, and a later backward under hipGraph capture would then synchronise with that
+#  stream from inside the capture)
+@torch.no_grad()
 def _pad_lora(A: torch.Tensor, B: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, int]:
     r = A.shape[0]
     r_pad = (r + 63) // 64 * 64
@@ -41,6 +45,7 @@ def _base(lin):
     return lin.base_layer if isinstance(lin, M.LoraLinear) else lin
 
 
+@torch.no_grad()
 def _fused_lora(linears) -> Optional[Tuple[torch.Tensor, torch.Tensor, int]]:
     """Stack the LoRA factors of sibling linears that were concatenated along N:
     A = rows stacked, B = block diagonal (scaling folded in)."""

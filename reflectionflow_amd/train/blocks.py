@@ -23,7 +23,7 @@ on the image rows iff model_config["latent_lora"] (lora_controller.py:5-42).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -209,7 +209,7 @@ def double_train_forward(tw: TrainWeights, x_txt, x_img, x_cond, mod_txt, mod_im
         ops.layernorm_modulate(s.x, s.mod[1], s.mod[0], out=XN[s.sl])
     _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D, RAW, lora.get("qkv"), keep, "qkv", tc)
     norms = (tw.w("norm_q"), tw.w("norm_k"), tw.w("norm_added_q"), tw.w("norm_added_k"))
-    a = K.qkv_train_fwd(RAW, H, st[0].rows, norms, cos, sin)
+    a = K.qkv_train_fwd(RAW, H, st[0].rows, norms, cos, sin, backward_operands=keep is not None)
     # (recompute inside the backward: the forward kernel also emits the row statistics its backward needs)
     LSE = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev) if keep is not None else None
     ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0, lse=LSE)
@@ -293,15 +293,31 @@ def double_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
     return dxs, [torch.cat(m).to(BF) if nd[i] else None for i, m in enumerate(dmod)], dlora
 
 
+class BlockOpts(NamedTuple):
+    """Second argument of the block Functions (a plain bool is read as latent_lora, recompute=True).
+    recompute=True is the reference's `gradient_checkpointing: true` (train_flux/flux/transformer.py:139-157): a block keeps its inputs
+    and runs its forward again inside the backward.  recompute=False keeps the forward's intermediates instead (~0.8 GB per block at
+    5632 tokens, ~45 GB per sample of the 57-block model -- what 288 GB of HBM are for): the same kernels on the same operands in the
+    backward, so the gradients are bit-identical, with one forward less per block and step."""
+    latent_lora: bool = False
+    recompute: bool = True
+
+
+def _opts(o) -> BlockOpts:
+    return o if isinstance(o, BlockOpts) else BlockOpts(bool(o), True)
+
+
 class DoubleBlockFn(torch.autograd.Function):
-    """y_txt, y_img, y_cond = DoubleBlockFn.apply(tw, latent_lora, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin,
+    """y_txt, y_img, y_cond = DoubleBlockFn.apply(tw, BlockOpts(latent_lora, recompute), x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin,
     A_qkv, B_qkv, A_out, B_out, A_ff2, B_ff2)    (x_cond / mod_cond / any LoRA pair may be None)"""
 
     @staticmethod
-    def forward(ctx, tw, latent_lora, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo):
+    def forward(ctx, tw, opts, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo):
+        latent_lora, recompute = _opts(opts)
         lora = {"qkv": (lo[0], lo[1]), "out": (lo[2], lo[3]), "ff2": (lo[4], lo[5])}
         ctx.tc = {}
-        ys = double_train_forward(tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, latent_lora, tc=ctx.tc)
+        ctx.kp = None if recompute else {}
+        ys = double_train_forward(tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, latent_lora, keep=ctx.kp, tc=ctx.tc)
         ctx.tw, ctx.latent_lora, ctx.has_cond = tw, latent_lora, x_cond is not None
         ctx.save_for_backward(x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo)
         return (ys[0], ys[1], ys[2] if x_cond is not None else None)
@@ -310,8 +326,11 @@ class DoubleBlockFn(torch.autograd.Function):
     def backward(ctx, dy_txt, dy_img, dy_cond):
         x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, *lo = ctx.saved_tensors
         lora = {"qkv": (lo[0], lo[1]), "out": (lo[2], lo[3]), "ff2": (lo[4], lo[5])}
-        kp: dict = {}
-        double_train_forward(ctx.tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp, tc=ctx.tc)   # recompute
+        kp = ctx.kp
+        ctx.kp = None                                            # (the intermediates die with this call)
+        if kp is None:
+            kp = {}
+            double_train_forward(ctx.tw, x_txt, x_img, x_cond, mod_txt, mod_img, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp, tc=ctx.tc)   # recompute
         zeros = lambda x: torch.zeros_like(x)   # noqa: E731
         dys = [dy_txt if dy_txt is not None else zeros(x_txt), dy_img if dy_img is not None else zeros(x_img)]
         if ctx.has_cond:
@@ -341,7 +360,7 @@ def single_train_forward(tw: TrainWeights, x_main, x_cond, mod_main, mod_cond, c
         ops.layernorm_modulate(s.x, s.mod[1], s.mod[0], out=XN[s.sl])
     _grouped(st, XN, [(tw,) + s.qkv for s in st], 3 * D + mlp, Z, lora.get("qkv_mlp"), keep, "qkv_mlp", tc)
     norms = (tw.w("norm_q"), tw.w("norm_k"), None, None)
-    a = K.qkv_train_fwd(Z, H, 0, norms, cos, sin)
+    a = K.qkv_train_fwd(Z, H, 0, norms, cos, sin, backward_operands=keep is not None)
     # (recompute inside the backward: the forward kernel also emits the row statistics its backward needs)
     LSE = torch.empty(H, a.s_pad, dtype=torch.float32, device=dev) if keep is not None else None
     ATT = ops.attention(a.q, a.k, a.vt, S, q_prescaled=True, score_bound=0.0, lse=LSE)
@@ -419,13 +438,15 @@ def single_train_backward(tw: TrainWeights, kp: dict, dys: Sequence[torch.Tensor
 
 
 class SingleBlockFn(torch.autograd.Function):
-    """y_main, y_cond = SingleBlockFn.apply(tw, latent_lora, x_main, x_cond, mod_main, mod_cond, cos, sin, A_qkv_mlp, B_qkv_mlp, A_out, B_out)"""
+    """y_main, y_cond = SingleBlockFn.apply(tw, BlockOpts(latent_lora, recompute), x_main, x_cond, mod_main, mod_cond, cos, sin, A_qkv_mlp, B_qkv_mlp, A_out, B_out)"""
 
     @staticmethod
-    def forward(ctx, tw, latent_lora, x_main, x_cond, mod_main, mod_cond, cos, sin, *lo):
+    def forward(ctx, tw, opts, x_main, x_cond, mod_main, mod_cond, cos, sin, *lo):
+        latent_lora, recompute = _opts(opts)
         lora = {"qkv_mlp": (lo[0], lo[1]), "out": (lo[2], lo[3])}
         ctx.tc = {}
-        ys = single_train_forward(tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, latent_lora, tc=ctx.tc)
+        ctx.kp = None if recompute else {}
+        ys = single_train_forward(tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, latent_lora, keep=ctx.kp, tc=ctx.tc)
         ctx.tw, ctx.latent_lora, ctx.has_cond = tw, latent_lora, x_cond is not None
         ctx.save_for_backward(x_main, x_cond, mod_main, mod_cond, cos, sin, *lo)
         return (ys[0], ys[1] if x_cond is not None else None)
@@ -434,8 +455,11 @@ class SingleBlockFn(torch.autograd.Function):
     def backward(ctx, dy_main, dy_cond):
         x_main, x_cond, mod_main, mod_cond, cos, sin, *lo = ctx.saved_tensors
         lora = {"qkv_mlp": (lo[0], lo[1]), "out": (lo[2], lo[3])}
-        kp: dict = {}
-        single_train_forward(ctx.tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp, tc=ctx.tc)    # recompute
+        kp = ctx.kp
+        ctx.kp = None
+        if kp is None:
+            kp = {}
+            single_train_forward(ctx.tw, x_main, x_cond, mod_main, mod_cond, cos, sin, lora, ctx.latent_lora, keep=kp, tc=ctx.tc)    # recompute
         dys = [dy_main if dy_main is not None else torch.zeros_like(x_main)]
         if ctx.has_cond:
             dys.append(dy_cond if dy_cond is not None else torch.zeros_like(x_cond))

@@ -42,9 +42,10 @@ def _norm_ptrs(norms):
 
 
 def qkv_train_fwd(raw: torch.Tensor, heads: int, n_added: int, norms, cos: torch.Tensor, sin: torch.Tensor, eps: float = 1e-6,
-                  q_scale: float = ops.QK_PRESCALE) -> AttnOperands:
+                  q_scale: float = ops.QK_PRESCALE, backward_operands: bool = True) -> AttnOperands:
     """raw [S, >= 3 * heads * 128] (columns q | k | v; a wider row pitch is fine: the single block's [q | k | v | mlp] buffer).
-    norms = (norm_q.weight, norm_k.weight, norm_added_q.weight or None, norm_added_k.weight or None)."""
+    norms = (norm_q.weight, norm_k.weight, norm_added_q.weight or None, norm_added_k.weight or None).
+    backward_operands=False: the no-grad forward of a checkpointed block -- v / qt / kt are not written (None in the result)."""
     raw = _rows2d(raw, "raw")
     S, dev = raw.shape[0], raw.device
     _chk(cos, "cos", torch.float32), _chk(sin, "sin", torch.float32)
@@ -52,14 +53,17 @@ def qkv_train_fwd(raw: torch.Tensor, heads: int, n_added: int, norms, cos: torch
         raise RFError(f"rope tables must be contiguous fp32 [{S}, 128]")
     s_pad = (S + 63) // 64 * 64
     q = torch.empty(heads, s_pad, 128, dtype=BF, device=dev)
-    k, v = torch.empty_like(q), torch.empty_like(q)
+    k = torch.empty_like(q)
     vt = torch.empty(heads, s_pad // 64, 128, 64, dtype=BF, device=dev)
-    qt = torch.empty(heads, s_pad // 32, 128, 32, dtype=BF, device=dev)
-    kt = torch.empty_like(qt)
+    v = qt = kt = None
+    if backward_operands:
+        v = torch.empty_like(q)
+        qt = torch.empty(heads, s_pad // 32, 128, 32, dtype=BF, device=dev)
+        kt = torch.empty_like(qt)
     wq, wk, waq, wak = _norm_ptrs(norms)
     L.check(L.load().rf_qkv_train_fwd(raw.data_ptr(), raw.stride(0), heads, S, s_pad, n_added, wq, wk, waq, wak, cos.data_ptr(),
-                                      sin.data_ptr(), eps, q_scale, q.data_ptr(), k.data_ptr(), v.data_ptr(), vt.data_ptr(),
-                                      qt.data_ptr(), kt.data_ptr(), stream_ptr()), "rf_qkv_train_fwd")
+                                      sin.data_ptr(), eps, q_scale, q.data_ptr(), k.data_ptr(), ptr(v), vt.data_ptr(),
+                                      ptr(qt), ptr(kt), stream_ptr()), "rf_qkv_train_fwd")
     return AttnOperands(q, k, v, vt, qt, kt, S, s_pad)
 
 

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import engine as E
 from .. import ops
 from ..flux.modules import LoraLinear
-from .blocks import DoubleBlockFn, SingleBlockFn, double_weights, fused_lora, single_weights
+from .blocks import BlockOpts, DoubleBlockFn, SingleBlockFn, double_weights, fused_lora, single_weights
 
 BF = torch.bfloat16
 
@@ -43,10 +43,36 @@ def _lora_term(lin, s: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
+class _RowLoraTerms(torch.autograd.Function):
+    """out[i] = scaling * B_i (A_i s) for n sibling LoRA pairs and ONE input row s -- matrix-VECTOR products, written as broadcast
+    multiplies and fp32 row sums with the intermediate t = A s rounded to the factors' dtype (as F.linear(s, A) rounds it).  As torch.bmm / `@` they
+    went to hipBLASLt, whose batched K = 1 / N = 1 launches in the BACKWARD (dB = dout t^T, dt = B^T dout) held the host 8-11 ms each,
+    twice a step, at the one point of a step where it has no lead over the GPU (the end of the backward: profiles/r05_train_step_gaps.md)."""
+
+    @staticmethod
+    def forward(ctx, A, B, s, scaling):                     # A [n, r, K], B [n, N, r], s [K] (no gradient: silu(temb) is an input here)
+        t = (A.float() * s.float()).sum(-1).to(A.dtype)     # [n, r]
+        out = ((B.float() * t.float()[:, None, :]).sum(-1) * scaling).to(B.dtype)    # [n, N]
+        ctx.save_for_backward(A, B, s, t)
+        ctx.scaling = scaling
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        A, B, s, t = ctx.saved_tensors
+        g = dout.float() * ctx.scaling                      # [n, N]
+        dB = (g[:, :, None] * t.float()[:, None, :]).to(B.dtype) if ctx.needs_input_grad[1] else None
+        dA = None
+        if ctx.needs_input_grad[0]:
+            dt = (B.float() * g[:, :, None]).sum(1).to(A.dtype)  # [n, r]: the gradient of the rounded t, as autograd would carry it
+            dA = (dt.float()[:, :, None] * s.float()).to(A.dtype)
+        return dA, dB, None, None
+
+
 def _lora_terms_batched(lins, s: torch.Tensor):
     """[_lora_term(l, s)[0] for l in lins] for sibling linears of ONE shape fed the same row s [1, K] -- the AdaLN linears of all
-    blocks see the same silu(temb): one [n r, K] x [K, 1] product and one batched [N, r] x [r, 1] product instead of two tiny GEMMs
-    per block (and four more in their backward).  Falls back to the per-linear form for mixed shapes / several adapters."""
+    blocks see the same silu(temb): one [n r, K] x [K] and one batched [N, r] x [r] matrix-vector product (_RowLoraTerms) instead of two
+    tiny GEMMs per block (and four more in their backward).  Falls back to the per-linear form for mixed shapes / several adapters."""
     if not lins:
         return []
     ok = all(isinstance(l, LoraLinear) and len(l.active_adapters) == 1 for l in lins)
@@ -60,17 +86,24 @@ def _lora_terms_batched(lins, s: torch.Tensor):
     n, (r, K_) = len(lins), wa.shape
     A = torch.stack([l.lora_A[a0].weight for l in lins])                    # [n, r, K]
     B = torch.stack([l.lora_B[a0].weight for l in lins])                    # [n, N, r]
-    t = (A.reshape(n * r, K_) @ s.reshape(K_, 1)).reshape(n, r, 1)           # bf16, as F.linear(s, A) rounds it
-    out = torch.bmm(B, t).squeeze(-1) * lins[0].scaling[a0]                 # [n, N]
+    out = _RowLoraTerms.apply(A, B, s.reshape(K_), float(lins[0].scaling[a0]))   # [n, N]
     return list(out.unbind(0))
 
 
 class FluxTrainer:
     """Forward with a backward through the HIP blocks for ONE transformer; `model_config` as in config.yaml:5-8."""
 
-    def __init__(self, transformer, model_config: Optional[dict] = None):
+    def __init__(self, transformer, model_config: Optional[dict] = None, gradient_checkpointing="auto"):
+        """gradient_checkpointing: True = the reference's training config (config.yaml `gradient_checkpointing: true`,
+        transformer.py:139-157: every block re-runs its forward inside the backward); False = every block keeps its intermediates;
+        "auto" (default) = keep them for as many blocks as fit the free HBM (~0.8 GB per block at 5632 tokens: all 57 blocks of one
+        sample are ~45 GB of 288) and re-compute the rest.  The gradients are bit-identical in all three."""
         self.tr = transformer
         self.cfg = dict(model_config or {})
+        if gradient_checkpointing not in (True, False, "auto"):
+            raise ops.RFError(f"gradient_checkpointing must be True, False or 'auto', got {gradient_checkpointing!r}")
+        self.gradient_checkpointing = gradient_checkpointing
+        self.kept_blocks = 0                                # blocks of the last forward that kept their intermediates (telemetry)
         if self.cfg.get("add_cond_attn", False) or not self.cfg.get("union_cond_attn", True):
             raise ops.RFError("the training path covers the shipped training config (union_cond_attn: true, add_cond_attn: false)")
         E.check_lora_placement(transformer)
@@ -168,6 +201,26 @@ class FluxTrainer:
                 img_ids = img_ids[0]
             cos, sin = eng.rope_tables(txt_ids, img_ids, condition_ids if use_cond else None)
         outs = []
+        # activation budget of this forward ("auto"): what the device and torch's allocator have free now, minus a reserve for the
+        # backward's own temporaries; a block's intermediates are ~24 [S, D] tensors + 2 [S, mlp] (double) / ~20 + 3 (single)
+        S_all = hidden_states.shape[1] + encoder_hidden_states.shape[1] + (condition_latents.shape[1] if use_cond else 0)
+        mlp = eng.mlp
+        cost_d = 2 * S_all * (24 * D + 2 * mlp)
+        cost_s = 2 * S_all * (20 * D + 3 * mlp)
+        budget = 0
+        if self.gradient_checkpointing == "auto" and torch.is_grad_enabled():
+            free = torch.cuda.mem_get_info(hidden_states.device)[0] + torch.cuda.memory_reserved(hidden_states.device) \
+                - torch.cuda.memory_allocated(hidden_states.device)
+            budget = int(0.85 * free) - (16 << 30)
+        self.kept_blocks = 0
+
+        def opts(cost):
+            nonlocal budget
+            keep = torch.is_grad_enabled() and (self.gradient_checkpointing is False or (self.gradient_checkpointing == "auto" and budget >= cost))
+            if keep:
+                budget -= cost
+                self.kept_blocks += 1
+            return BlockOpts(self.latent_lora, not keep)
         for b in range(hidden_states.shape[0]):
             m_img, m_txt, m_sgl, m_out = self._mods(temb[b:b + 1], self.latent_lora)
             if use_cond:
@@ -180,13 +233,13 @@ class FluxTrainer:
             for i, blk in enumerate(tr.transformer_blocks):
                 a = blk.attn
                 lo = (*fused_lora([a.to_q, a.to_k, a.to_v]), *fused_lora([a.to_out[0]]), *fused_lora([blk.ff.net[2]]))
-                x_txt, x_img, x_cond = DoubleBlockFn.apply(double_weights(blk), self.latent_lora, x_txt, x_img, x_cond, m_txt[i], m_img[i],
+                x_txt, x_img, x_cond = DoubleBlockFn.apply(double_weights(blk), opts(cost_d), x_txt, x_img, x_cond, m_txt[i], m_img[i],
                                                            c_img[i] if use_cond else None, cos, sin, *lo)
             x_main = torch.cat([x_txt, x_img], 0)
             for j, blk in enumerate(tr.single_transformer_blocks):
                 a = blk.attn
                 lo = (*fused_lora([a.to_q, a.to_k, a.to_v, blk.proj_mlp]), *fused_lora([blk.proj_out]))
-                x_main, x_cond = SingleBlockFn.apply(single_weights(blk), self.latent_lora, x_main, x_cond, m_sgl[j],
+                x_main, x_cond = SingleBlockFn.apply(single_weights(blk), opts(cost_s), x_main, x_cond, m_sgl[j],
                                                      c_sgl[j] if use_cond else None, cos, sin, *lo)
             x_img = x_main[St:]
             # norm_out (AdaLayerNormContinuous: scale FIRST) + proj_out, transformer.py:243-244 -- torch ops, autograd

@@ -99,6 +99,10 @@ def test_qkv_train_fwd_bwd(dev, H, S, n_added, extra):
     ids = torch.stack([torch.zeros(S), torch.arange(S) // 8, torch.arange(S) % 8], 1).to(dev)
     cos, sin = (t.contiguous() for t in O.FluxPosEmbed(10000, (16, 56, 56))(ids))
     a = K.qkv_train_fwd(raw, H, n_added, norms if n_added else (norms[0], norms[1], None, None), cos, sin)
+    # the no-grad pass of a checkpointed block writes the forward's operands only -- the same bits
+    a0 = K.qkv_train_fwd(raw, H, n_added, norms if n_added else (norms[0], norms[1], None, None), cos, sin, backward_operands=False)
+    assert a0.v is None and a0.qt is None and a0.kt is None
+    assert torch.equal(a0.q, a.q) and torch.equal(a0.k, a.k) and torch.equal(a0.vt, a.vt)
     rf = raw.float().requires_grad_(True)
     tok = torch.arange(S, device=dev)[:, None, None]
     wq = torch.where(tok < n_added, norms[2].float(), norms[0].float())
@@ -366,6 +370,38 @@ def test_training_step_hd128_against_the_reference_fixture(dev):
     assert torch.equal(loss, loss2)
     for k, v in grads.items():
         assert (v is None and grads2[k] is None) or torch.equal(v, grads2[k].cpu()), k
+
+
+def test_kept_activations_give_the_gradients_of_gradient_checkpointing(dev):
+    """FluxTrainer(gradient_checkpointing=True | False | "auto"): True is the reference's flag (every block re-runs its forward in the
+    backward, transformer.py:139-157), False keeps every block's intermediates, "auto" keeps what fits the free HBM.  The backward runs
+    the same kernels on the same operands in all three: loss and every LoRA gradient bit-equal."""
+    from reflectionflow_amd.train.step import FluxTrainer, lora_parameters
+    z = load("train_step_hd128")
+    om = TO.set_trainable(build("hd128", lora=True).train())
+    cfg = {"union_cond_attn": True, "add_cond_attn": False, "latent_lora": False}
+    tb = lambda k: T(z[k]).to(dev)   # noqa: E731
+    pipe = to_product(om, dev)
+    batch = dict(x_0=tb("x_0").to(BF), img_ids=tb("img_ids"), prompt_embeds=tb("pe").to(BF), pooled_prompt_embeds=tb("pooled").to(BF),
+                 text_ids=tb("txt_ids"), condition_latents=tb("cond").to(BF), condition_ids=tb("cond_ids"), t=tb("t"), x_1=tb("x_1").to(BF))
+    ps = lora_parameters(pipe.transformer)
+    res = {}
+    for mode, want_kept in ((True, 0), (False, 8), ("auto", 8)):      # 2 + 2 blocks x batch of 2
+        tr = FluxTrainer(pipe.transformer, cfg, gradient_checkpointing=mode)
+        for p in ps:
+            p.grad = None
+        loss = tr.step(batch)
+        assert tr.kept_blocks == want_kept, (mode, tr.kept_blocks)
+        loss.backward()
+        res[mode] = (loss.detach().clone(), [None if p.grad is None else p.grad.clone() for p in ps])
+        del loss
+    assert sum(g is not None and float(g.float().abs().max()) > 0 for g in res[True][1]) >= 44
+    for mode in (False, "auto"):
+        assert torch.equal(res[mode][0], res[True][0])
+        for a, b in zip(res[mode][1], res[True][1]):
+            assert (a is None and b is None) or torch.equal(a, b), mode
+    with pytest.raises(Exception):
+        FluxTrainer(pipe.transformer, cfg, gradient_checkpointing="sometimes")
 
 
 @pytest.mark.parametrize("nd,ns,gh,gc,add", [(1, 1, 32, 16, 2e-3), (2, 2, 64, 32, 2e-3)], ids=["1+1_S1792", "2+2_S5632_cfg4_training_shape"])
