@@ -729,7 +729,7 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
     # (2) "auto": blocks keep their intermediates while they fit the free HBM -- the same backward kernels on the same operands
     trainer.gradient_checkpointing = "auto"
     ms, host_ms, loss = timed()
-    kept = trainer.kept_blocks
+    kept = trainer.kept_blocks * (Bn if Bn > 1 else 1)      # (a batch runs sample by sample in this mode: kept_blocks counts the last sample's)
     # both modes at the SAME parameters (no optimizer step in between): the flat gradient bucket, bit for bit
     g_auto = grads_now()
     trainer.gradient_checkpointing = True
@@ -766,6 +766,8 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
                                     "(~0.8 GB per block at 5632 tokens) instead of re-running its forward inside the backward; ms_per_step, the "
                                     "class table and tflops_model are this mode",
                             "blocks_keeping_their_intermediates": kept, "of": (nd + ns) * Bn,
+                            "batch": "one sample at a time, each with 1 / B of the loss (FluxTrainer.training_step(sample_by_sample=True), the default "
+                                     "for B > 1 here): one sample's activations alive at a time" if Bn > 1 else "1 sample",
                             "gradients_bit_equal_to_gradient_checkpointing": keep_equal},
             "gradient_checkpointing_true": {"what": "the reference's training flag (config.yaml gradient_checkpointing: true, transformer.py:139-157): "
                                                     "every block re-computed in its backward, executed FLOPs 2 F + B",

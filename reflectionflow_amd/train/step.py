@@ -134,15 +134,43 @@ class FluxTrainer:
         self.eng = E.engine_for(self.tr)
         return self.optimizer
 
-    def training_step(self, batch: Dict[str, torch.Tensor], world_size: int = 1, group=None, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    _PER_SAMPLE = ("x_0", "x_1", "t", "prompt_embeds", "pooled_prompt_embeds", "condition_latents")
+
+    def training_step(self, batch: Dict[str, torch.Tensor], world_size: int = 1, group=None, generator: Optional[torch.Generator] = None,
+                      sample_by_sample: Optional[bool] = None) -> torch.Tensor:
         """One optimisation step as the reference's Lightning loop runs it (zero_grad -> step() -> backward -> DDP all-reduce ->
-        optimizer.step): returns the detached loss.  Needs configure_optimizers() first."""
+        optimizer.step): returns the detached loss.  Needs configure_optimizers() first.
+        sample_by_sample (default: on for a batch of several samples unless gradient_checkpointing is True): forward + backward of one
+        sample at a time, each with 1 / B of the loss -- the mean over the batch is the mean of the per-sample means, so the summed
+        gradients are those of the batched loss up to the order of the bf16 accumulation, while only ONE sample's activations are alive
+        (a sample of the 57-block model keeps ~45 GB; the reference's batch of 8, config.yaml:11, would not fit 288 GB at once).  The
+        draws of t and x_1 are made for the whole batch first, exactly as step() makes them."""
         if self.optimizer is None:
             raise ops.RFError("FluxTrainer.training_step: call configure_optimizers() first")
         opt = self.optimizer
         opt.zero_grad()
-        loss = self.step(batch, generator=generator)
-        loss.backward()
+        Bn = batch["x_0"].shape[0]
+        if sample_by_sample is None:
+            sample_by_sample = Bn > 1 and self.gradient_checkpointing is not True
+        if sample_by_sample and Bn > 1:
+            batch = dict(batch)
+            with torch.no_grad():                                                            # the draws of step(), for the whole batch
+                if batch.get("t") is None:
+                    batch["t"] = torch.sigmoid(torch.randn((Bn,), device=batch["x_0"].device, generator=generator))
+                if batch.get("x_1") is None:
+                    batch["x_1"] = torch.randn(batch["x_0"].shape, device=batch["x_0"].device, dtype=batch["x_0"].dtype, generator=generator)
+            loss = None
+            for b in range(Bn):
+                one = {k: (v[b:b + 1] if k in self._PER_SAMPLE and isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+                part = self.step(one) / Bn
+                part.backward()
+                loss = part.detach().float() if loss is None else loss + part.detach().float()
+                dt = part.dtype
+                del part
+            loss = loss.to(dt)
+        else:
+            loss = self.step(batch, generator=generator)
+            loss.backward()
         if world_size > 1:
             opt.bucket.all_reduce(world_size, group)
             opt.grad_scale = 1.0 / world_size

@@ -402,6 +402,17 @@ def test_kept_activations_give_the_gradients_of_gradient_checkpointing(dev):
             assert (a is None and b is None) or torch.equal(a, b), mode
     with pytest.raises(Exception):
         FluxTrainer(pipe.transformer, cfg, gradient_checkpointing="sometimes")
+    # training_step over the batch of 2: one sample at a time with half the loss each == the batched step up to the accumulation order
+    tr = FluxTrainer(pipe.transformer, cfg)
+    opt = tr.configure_optimizers({"type": "AdamW", "params": {"lr": 0.0, "weight_decay": 0.0}})
+    l_b = tr.training_step(batch, sample_by_sample=False).clone()
+    g_b = opt.bucket.grad.float().clone()
+    l_s = tr.training_step(batch).clone()                    # default for B > 1 with kept activations
+    g_s = opt.bucket.grad.float()
+    assert tr.kept_blocks == 4                               # the blocks of ONE sample
+    assert abs(float(l_s) - float(l_b)) <= 1.2e-2 * abs(float(l_b)), (float(l_s), float(l_b))      # bf16 losses: three ulps
+    assert rel_l2(g_s, g_b) < 5e-3, rel_l2(g_s, g_b)
+    print(f"  sample-by-sample vs batched: loss {float(l_s):.5f} / {float(l_b):.5f}, gradient rel-L2 {rel_l2(g_s, g_b):.2e}")
 
 
 @pytest.mark.parametrize("nd,ns,gh,gc,add", [(1, 1, 32, 16, 2e-3), (2, 2, 64, 32, 2e-3)], ids=["1+1_S1792", "2+2_S5632_cfg4_training_shape"])
