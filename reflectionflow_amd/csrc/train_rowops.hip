@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256) void qkv_train_fwd_kernel(const bf16_t* __rest
   store16(k + hrow, o[1]);
   if (bwd_ops) store16(v + hrow, o[2]);
 #pragma unroll
-  for (int a = bwd_ops ? 0 : 2; a < 3; ++a)
+  for (int a = 0; a < 3; ++a) {          // (a compile-time trip count: o[][] stays in registers)
+    if (a == 2 || bwd_ops) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) tl[a][i][c * 16 + e] = f2bf(o[a][e]);
+      for (int e = 0; e < 16; ++e) tl[a][i][c * 16 + e] = f2bf(o[a][e]);
+    }
+  }
   __syncthreads();
   const int blk = blockIdx.x;
   const int64_t tbase = ((int64_t)head * (s_pad >> 5) + blk) * (128 * 32);
