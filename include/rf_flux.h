@@ -35,7 +35,8 @@ typedef enum rf_status {
 } rf_status;
 
 const char* rf_last_error(void);
-/* ABI version: bump on any struct/signature change (v13: rf_attn_bwd_desc.kernel, rf_lora_adamw / rf_lora_prodigy). */
+/* ABI version: bump on any struct/signature change (v13: rf_attn_bwd_desc.kernel, rf_lora_adamw / rf_lora_prodigy; v14: rf_lora_fuse /
+ * rf_lora_unfuse_grads, rf_qkv_train_fwd's forward-only form). */
 int rf_abi_version(void);
 /* Returns 950 when the library was compiled for gfx950. */
 int rf_target_arch(void);
@@ -569,6 +570,32 @@ int rf_gemm_tn_skinny(const void* big, int64_t ld_big, const void* skinny, int64
 /* dst[c][r] = src[r][c], r < rows; zero for rows <= r < rows_pad (the K % 64 padding of a token-axis contraction) */
 int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, int32_t cols, void* dst, int64_t ld_dst,
                       int32_t rows_pad, void* stream);
+
+/* The fused LoRA operands of sibling linears and the way back (ABI v14; reference: peft's per-linear lora_A / lora_B applied one by one
+ * inside F.linear calls, train_flux/flux/lora_controller.py + block.py:23-30,146-155).  The training path applies the LoRA of linears
+ * that share an input as ONE K-segment (A [r_pad][K]) and one block-diagonal up-projection (Bs [N][r_pad]):
+ *   rf_lora_fuse          A rows r0 .. r0+r <- lora_A of entry i ([r][K]), Bs block (n0 .. n0+n, r0 .. r0+r) <- scaling * lora_B
+ *                         ([n][r], rounded to bf16), everything else zero -- one launch instead of two fills + a copy and a scaled
+ *                         copy per linear;
+ *   rf_lora_unfuse_grads  its backward: dA_i (+)= dA rows, dB_i (+)= bf16(scaling * dBs block) -- the product is rounded to bf16 first
+ *                         and the sum once more, exactly what `grad += dBs_block * scaling` on bf16 tensors does -- one launch
+ *                         instead of a scaled copy and two accumulations per linear.  accumulate = 0 overwrites.
+ * Up to RF_LORA_FUSE_MAX entries, K % 8 == 0, r_pad % 8 == 0, 16-byte aligned A / dA pointers. */
+#define RF_LORA_FUSE_MAX 8
+typedef struct rf_lora_fuse_entry {
+  const void* A;      /* lora_A.weight [r][K] bf16 (fuse: read) */
+  const void* B;      /* lora_B.weight [n][r] bf16 (fuse: read) */
+  void* dA;           /* gradient of A [r][K] bf16 (unfuse: written / accumulated; may be NULL = not wanted) */
+  void* dB;           /* gradient of B [n][r] bf16 (same) */
+  int32_t n0, n;      /* rows of Bs this linear owns */
+  int32_t r0, r;      /* rows of A / columns of Bs this (linear, adapter) owns */
+  float scaling;      /* lora_alpha / r */
+  int32_t _pad;
+} rf_lora_fuse_entry;
+int rf_lora_fuse(const rf_lora_fuse_entry* entries, int32_t n_entries, int32_t K, int32_t N, int32_t r_pad, void* A_out, void* Bs_out,
+                 void* stream);
+int rf_lora_unfuse_grads(const rf_lora_fuse_entry* entries, int32_t n_entries, int32_t K, int32_t N, int32_t r_pad, const void* dA,
+                         const void* dBs, int32_t accumulate, void* stream);
 
 /* Optimizer update of the LoRA factors (train_flux/train/model.py:105-117: torch.optim.AdamW or prodigyopt.Prodigy over the LoRA
  * parameters; config.yaml:55-61 ships Prodigy lr 1, use_bias_correction, safeguard_warmup, weight_decay 0.01) over ONE flat bucket:

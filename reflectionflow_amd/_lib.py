@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -61,6 +61,14 @@ class rf_attn_bwd_desc(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("q", "k", "v", "qt", "kt", "o", "dout")] + [("ldo", C.c_int64), ("lddo", C.c_int64)] + [
         (n, C.c_void_p) for n in ("dq", "dk", "dv", "dot", "lse", "dsum")] + [
         ("heads", C.c_int32), ("S", C.c_int32), ("s_pad", C.c_int32), ("mode", C.c_int32), ("lse_given", C.c_int32), ("kernel", C.c_int32)]
+
+
+class rf_lora_fuse_entry(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("dA", C.c_void_p), ("dB", C.c_void_p), ("n0", C.c_int32), ("n", C.c_int32),
+                ("r0", C.c_int32), ("r", C.c_int32), ("scaling", C.c_float), ("_pad", C.c_int32)]
+
+
+RF_LORA_FUSE_MAX = 8
 
 
 class rf_w8(C.Structure):
@@ -209,6 +217,8 @@ _SIGS = {
     "rf_gelu": (C.c_int, [_P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "rf_gelu_bwd": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "rf_transpose_bf16": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, C.c_int64, C.c_int32, _P]),
+    "rf_lora_fuse": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "rf_lora_unfuse_grads": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, _P]),
     "rf_gemm_tn_skinny_ws_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "rf_gemm_tn_skinny": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "rf_lora_adamw": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),

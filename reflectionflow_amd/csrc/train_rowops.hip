@@ -463,6 +463,90 @@ __global__ __launch_bounds__(256) void transpose_vec_kernel(const bf16_t* __rest
   }
 }
 
+// ---- fused LoRA operands of sibling linears, and their gradients back to the factors -------------------------------------------------
+struct LoraFuseTab {
+  rf_lora_fuse_entry e[RF_LORA_FUSE_MAX];
+  int n;
+};
+// thread = 8 consecutive elements of A_out [r_pad][K] (first r_pad * K / 8 threads) or of Bs_out [N][r_pad] (the rest)
+__global__ __launch_bounds__(256) void lora_fuse_kernel(LoraFuseTab t, int K, int N, int r_pad, bf16_t* __restrict__ A_out,
+                                                        bf16_t* __restrict__ B_out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, nA = (int64_t)r_pad * (K >> 3), nB = (int64_t)N * (r_pad >> 3);
+  if (idx < nA) {
+    const int row = (int)(idx / (K >> 3)), k = (int)(idx % (K >> 3)) * 8;
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < t.n; ++i)
+      if (row >= t.e[i].r0 && row < t.e[i].r0 + t.e[i].r) v = *(const u32x4*)((const bf16_t*)t.e[i].A + (int64_t)(row - t.e[i].r0) * K + k);
+    *(u32x4*)(A_out + (int64_t)row * K + k) = v;
+  } else if (idx < nA + nB) {
+    const int64_t j = idx - nA;
+    const int nrow = (int)(j / (r_pad >> 3)), c0 = (int)(j % (r_pad >> 3)) * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    for (int i = 0; i < t.n; ++i) {
+      const rf_lora_fuse_entry& E = t.e[i];
+      if (nrow < E.n0 || nrow >= E.n0 + E.n || c0 + 8 <= E.r0 || c0 >= E.r0 + E.r) continue;
+      const bf16_t* src = (const bf16_t*)E.B + (int64_t)(nrow - E.n0) * E.r;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e - E.r0;
+        if (c >= 0 && c < E.r) o[e] = bf2f(src[c]) * E.scaling;
+      }
+    }
+    *(u32x4*)(B_out + (int64_t)nrow * r_pad + c0) = pack8(o);
+  }
+}
+// thread = 8 consecutive elements of some dA_i row (first threads: r_total * K / 8 of them, rows in entry order) or ONE row segment of a
+// dB_i (n_total rows x entries: the r columns of entry i in row n)
+__global__ __launch_bounds__(256) void lora_unfuse_kernel(LoraFuseTab t, int K, int N, int r_pad, const bf16_t* __restrict__ dA,
+                                                          const bf16_t* __restrict__ dB, int accumulate, int r_total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, nA = (int64_t)r_total * (K >> 3);
+  if (idx < nA) {
+    int row = (int)(idx / (K >> 3));
+    const int k = (int)(idx % (K >> 3)) * 8;
+    for (int i = 0; i < t.n; ++i) {
+      const rf_lora_fuse_entry& E = t.e[i];
+      if (row < E.r) {
+        if (E.dA != nullptr) {
+          bf16_t* dst = (bf16_t*)E.dA + (int64_t)row * K + k;
+          const u32x4 g = *(const u32x4*)(dA + (int64_t)(E.r0 + row) * K + k);
+          if (accumulate) {
+            float a[8], b[8];
+            unpack8(*(const u32x4*)dst, a);
+            unpack8(g, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];
+            *(u32x4*)dst = pack8(a);
+          } else {
+            *(u32x4*)dst = g;
+          }
+        }
+        return;
+      }
+      row -= E.r;
+    }
+    return;
+  }
+  // dB: item = (entry i, row n of its n rows); the r columns are contiguous in both tensors
+  int64_t j = idx - nA;
+  for (int i = 0; i < t.n; ++i) {
+    const rf_lora_fuse_entry& E = t.e[i];
+    if (j < E.n) {
+      if (E.dB != nullptr) {
+        bf16_t* dst = (bf16_t*)E.dB + j * E.r;
+        const bf16_t* src = dB + (int64_t)(E.n0 + j) * r_pad + E.r0;
+        for (int c = 0; c < E.r; ++c) {
+          const float g = bf2f(f2bf(bf2f(src[c]) * E.scaling));          // the product rounded to bf16, as `dBs_block * scaling` is
+          dst[c] = f2bf(accumulate ? bf2f(dst[c]) + g : g);
+        }
+      }
+      return;
+    }
+    j -= E.n;
+  }
+}
+
 // blocks of four row-waves; one fp32 partial row per BLOCK, so rf_train_partials_bytes' 512 rows bound the grid
 static int row_blocks(int rows, int cap) {
   const int b = cdiv(rows, 4);
@@ -812,6 +896,61 @@ extern "C" int rf_transpose_bf16(const void* src, int64_t ld_src, int32_t rows, 
     hipLaunchKernelGGL(transpose_vec_kernel, grid, dim3(256), 0, st, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
   else
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, st, (const bf16_t*)src, ld_src, rows, cols, (bf16_t*)dst, ld_dst, rows_pad);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+static int lora_fuse_tab(const char* who, const rf_lora_fuse_entry* entries, int32_t n_entries, int32_t K, int32_t N, int32_t r_pad,
+                         rf::LoraFuseTab& t, bool grads) {
+  RF_REQUIRE(entries != nullptr, RF_ERR_NULL, "%s: NULL entries", who);
+  RF_REQUIRE(n_entries >= 1 && n_entries <= RF_LORA_FUSE_MAX && K > 0 && K % 8 == 0 && N > 0 && r_pad > 0 && r_pad % 8 == 0, RF_ERR_SHAPE,
+             "%s: n_entries=%d K=%d N=%d r_pad=%d (1..%d entries, K %% 8 == 0, r_pad %% 8 == 0)", who, n_entries, K, N, r_pad, RF_LORA_FUSE_MAX);
+  t.n = n_entries;
+  for (int i = 0; i < n_entries; ++i) {
+    const rf_lora_fuse_entry& E = entries[i];
+    RF_REQUIRE(E.r > 0 && E.n > 0 && E.r0 >= 0 && E.n0 >= 0 && E.r0 + E.r <= r_pad && E.n0 + E.n <= N, RF_ERR_SHAPE,
+               "%s: entry %d (n0=%d n=%d r0=%d r=%d) outside [N=%d][r_pad=%d]", who, i, E.n0, E.n, E.r0, E.r, N, r_pad);
+    for (int j = 0; j < i; ++j)
+      RF_REQUIRE(E.r0 >= entries[j].r0 + entries[j].r || entries[j].r0 >= E.r0 + E.r, RF_ERR_SHAPE, "%s: entries %d and %d share rank columns", who, j, i);
+    if (grads) {
+      RF_REQUIRE(E.dA == nullptr || rf::aligned16(E.dA), RF_ERR_ALIGN, "%s: entry %d: dA must be 16-byte aligned", who, i);
+    } else {
+      RF_REQUIRE(E.A != nullptr && E.B != nullptr, RF_ERR_NULL, "%s: entry %d: NULL factor", who, i);
+      RF_REQUIRE(rf::aligned16(E.A), RF_ERR_ALIGN, "%s: entry %d: A must be 16-byte aligned", who, i);
+    }
+    t.e[i] = E;
+  }
+  return RF_OK;
+}
+
+extern "C" int rf_lora_fuse(const rf_lora_fuse_entry* entries, int32_t n_entries, int32_t K, int32_t N, int32_t r_pad, void* A_out,
+                            void* Bs_out, void* stream) {
+  rf::LoraFuseTab t;
+  if (int rc = lora_fuse_tab("rf_lora_fuse", entries, n_entries, K, N, r_pad, t, false)) return rc;
+  RF_REQUIRE(A_out && Bs_out, RF_ERR_NULL, "rf_lora_fuse: NULL output");
+  RF_REQUIRE(aligned16(A_out) && aligned16(Bs_out), RF_ERR_ALIGN, "rf_lora_fuse: 16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t items = (int64_t)r_pad * (K >> 3) + (int64_t)N * (r_pad >> 3);
+  ProfScope prof(RF_KC_ROWOP, 2.0 * 2.0 * ((double)r_pad * K + (double)N * r_pad), st);
+  hipLaunchKernelGGL(lora_fuse_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, t, K, N, r_pad, (bf16_t*)A_out, (bf16_t*)Bs_out);
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
+extern "C" int rf_lora_unfuse_grads(const rf_lora_fuse_entry* entries, int32_t n_entries, int32_t K, int32_t N, int32_t r_pad, const void* dA,
+                                    const void* dBs, int32_t accumulate, void* stream) {
+  rf::LoraFuseTab t;
+  if (int rc = lora_fuse_tab("rf_lora_unfuse_grads", entries, n_entries, K, N, r_pad, t, true)) return rc;
+  RF_REQUIRE(dA && dBs, RF_ERR_NULL, "rf_lora_unfuse_grads: NULL gradient");
+  RF_REQUIRE(aligned16(dA), RF_ERR_ALIGN, "rf_lora_unfuse_grads: 16-byte alignment");
+  int r_total = 0;
+  int64_t n_total = 0;
+  for (int i = 0; i < n_entries; ++i) r_total += entries[i].r, n_total += entries[i].n;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t items = (int64_t)r_total * (K >> 3) + n_total;
+  ProfScope prof(RF_KC_ROWOP, 2.0 * 3.0 * ((double)r_total * K + (double)n_total * 8), st);
+  hipLaunchKernelGGL(lora_unfuse_kernel, dim3((unsigned)cdiv64(items, 256)), dim3(256), 0, st, t, K, N, r_pad, (const bf16_t*)dA,
+                     (const bf16_t*)dBs, accumulate, r_total);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }

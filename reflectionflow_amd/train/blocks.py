@@ -27,6 +27,7 @@ from typing import Dict, List, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
+from .. import _lib as L
 from .. import engine as E
 from .. import ops
 from ..ops import RF_EPI_STORE, Group, Seg
@@ -77,31 +78,50 @@ def single_weights(block) -> TrainWeights:
 
 class _FuseLora(torch.autograd.Function):
     """(A_pad [r_pad, K], Bs_pad [N, r_pad]) from the LoRA parameters of sibling linears: A = the lora_A weights stacked along r,
-    Bs = block-diagonal of scaling * lora_B (one block per linear along N, one column range per (linear, adapter) along r).  As
-    torch ops (cat / mul / block_diag / pad, and their autograd) this was ~25 small launches per LoRA site and step forward plus as
-    many backward -- 10 % of a training step; here it is two zero-fills plus one copy and one scaled copy per (linear, adapter), and
-    the backward hands back VIEWS of dA and one scaled copy of each dB block."""
+    Bs = block-diagonal of scaling * lora_B (one block per linear along N, one column range per (linear, adapter) along r).  ONE launch
+    each way (rf_lora_fuse / rf_lora_unfuse_grads, ABI v14).  The backward ADDS the factors' gradients into their `.grad` itself (into
+    the views of the flat bucket when an optimizer of train/optim.py owns them) and hands autograd None for them: a scaled copy plus
+    two AccumulateGrad launches per linear and site were ~720 launches of a step; the arithmetic is that of `grad += dBs_block * scaling`
+    on bf16 tensors, rounding for rounding."""
+
+    @staticmethod
+    def _table(entries, params, grads: bool):
+        tab = (L.rf_lora_fuse_entry * len(entries))()
+        for i, (n0, n, r0, r, sc) in enumerate(entries):
+            wa, wb = params[2 * i], params[2 * i + 1]
+            e = tab[i]
+            e.A, e.B, e.n0, e.n, e.r0, e.r, e.scaling = wa.data_ptr(), wb.data_ptr(), n0, n, r0, r, sc
+            if grads:
+                for p_ in (wa, wb):
+                    if p_.requires_grad and p_.grad is None:
+                        p_.grad = torch.zeros_like(p_)
+                e.dA = wa.grad.data_ptr() if wa.requires_grad else None
+                e.dB = wb.grad.data_ptr() if wb.requires_grad else None
+        return tab
 
     @staticmethod
     def forward(ctx, layout, *params):
         # layout: (K, N, r_pad, [(n0, n, r0, r, scaling) per (linear, adapter), in parameter order]); params = A_0, B_0, A_1, B_1, ...
         K_, N, r_pad, entries = layout
         ref = params[0]
-        A = torch.zeros(r_pad, K_, dtype=ref.dtype, device=ref.device)
-        B = torch.zeros(N, r_pad, dtype=ref.dtype, device=ref.device)
-        for i, (n0, n, r0, r, sc) in enumerate(entries):
-            A[r0:r0 + r].copy_(params[2 * i])
-            torch.mul(params[2 * i + 1], sc, out=B[n0:n0 + n, r0:r0 + r])
-        ctx.entries = entries
+        if len(entries) > L.RF_LORA_FUSE_MAX or any(p_.dtype != BF or not p_.is_contiguous() for p_ in params):
+            raise ops.RFError(f"fused LoRA: up to {L.RF_LORA_FUSE_MAX} contiguous bf16 (linear, adapter) pairs per site, got {len(entries)}")
+        A = torch.empty(r_pad, K_, dtype=BF, device=ref.device)
+        B = torch.empty(N, r_pad, dtype=BF, device=ref.device)
+        tab = _FuseLora._table(entries, params, False)
+        L.check(L.load().rf_lora_fuse(tab, len(entries), K_, N, r_pad, A.data_ptr(), B.data_ptr(), ops.stream_ptr()), "rf_lora_fuse")
+        ctx.layout, ctx.params = layout, params
         return A, B
 
     @staticmethod
     def backward(ctx, dA, dB):
-        grads = [None]
-        for i, (n0, n, r0, r, sc) in enumerate(ctx.entries):
-            grads.append(dA[r0:r0 + r] if ctx.needs_input_grad[1 + 2 * i] else None)
-            grads.append(dB[n0:n0 + n, r0:r0 + r] * sc if ctx.needs_input_grad[2 + 2 * i] else None)
-        return tuple(grads)
+        K_, N, r_pad, entries = ctx.layout
+        dA, dB = dA.contiguous(), dB.contiguous()
+        with torch.no_grad():
+            tab = _FuseLora._table(entries, ctx.params, True)
+            L.check(L.load().rf_lora_unfuse_grads(tab, len(entries), K_, N, r_pad, dA.data_ptr(), dB.data_ptr(), 1, ops.stream_ptr()),
+                    "rf_lora_unfuse_grads")
+        return (None,) * (1 + len(ctx.params))
 
 
 def fused_lora(linears, device=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:

@@ -91,49 +91,6 @@ def test_lora_gradient_allreduce_two_ranks():
     assert torch.allclose(got[0][1][2], torch.full((3,), 0.5))
 
 
-def test_fused_lora_node_equals_the_torch_op_construction():
-    """train.blocks.fused_lora builds (A_pad, Bs_pad) of sibling linears in ONE autograd node; values and the gradients that reach
-    every lora_A / lora_B must equal the cat / scaling / block_diag / pad construction it replaced (a plain linear among the siblings
-    contributes output rows and no rank)."""
-    import torch.nn as nn
-    from reflectionflow_amd.flux import modules as M
-    from reflectionflow_amd.train.blocks import fused_lora
-
-    def lin(i, o, r=None):
-        base = nn.Linear(i, o)
-        if r is None:
-            return base
-        l = M.LoraLinear(base, r, 2 * r)
-        for p in (l.lora_A["default"].weight, l.lora_B["default"].weight):
-            nn.init.normal_(p)
-        return l
-
-    def reference(linears):
-        As, Bs = [], []
-        for l in linears:
-            if isinstance(l, M.LoraLinear):
-                As.append(torch.cat([l.lora_A[a].weight for a in l.active_adapters], 0))
-                Bs.append(torch.cat([l.lora_B[a].weight * l.scaling[a] for a in l.active_adapters], 1))
-            else:
-                As.append(torch.zeros(0, l.in_features))
-                Bs.append(torch.zeros(l.out_features, 0))
-        A, B = torch.cat(As, 0), torch.block_diag(*Bs)
-        r = A.shape[0]
-        rp = (r + 63) // 64 * 64
-        return torch.nn.functional.pad(A, (0, 0, 0, rp - r)), torch.nn.functional.pad(B, (0, rp - r))
-
-    torch.manual_seed(0)
-    for linears in ([lin(48, 32, 8), lin(48, 16), lin(48, 40, 4)], [lin(64, 24, 32)], [lin(32, 8, 40), lin(32, 8, 40)]):
-        A, B = fused_lora(linears)
-        A0, B0 = reference(linears)
-        assert torch.equal(A, A0) and torch.equal(B, B0)
-        ps = [p for l in linears if isinstance(l, M.LoraLinear) for p in (l.lora_A["default"].weight, l.lora_B["default"].weight)]
-        gA, gB = torch.randn_like(A), torch.randn_like(B)
-        for x, y in zip(torch.autograd.grad([A, B], ps, [gA, gB]), torch.autograd.grad([A0, B0], ps, [gA, gB])):
-            assert torch.allclose(x, y)
-    assert fused_lora([lin(8, 8)]) == (None, None)
-
-
 def test_batched_adaln_lora_terms_equal_the_per_block_form():
     """train.step._lora_terms_batched: the LoRA terms of all blocks' AdaLN linears from ONE stacked product must equal the per-linear
     F.linear(F.linear(s, A), B) * scaling, values and parameter gradients; mixed shapes fall back to the per-linear form."""

@@ -300,6 +300,58 @@ def test_attention_bwd_every_kernel_form(dev, H, S):
         K.attention_bwd(a, out, dout, kernel=7)
 
 
+def test_fused_lora_node_equals_the_torch_op_construction(dev):
+    """train.blocks.fused_lora builds (A_pad, Bs_pad) of sibling linears with ONE launch (rf_lora_fuse) and its backward adds the
+    gradients into every lora_A / lora_B `.grad` with one more (rf_lora_unfuse_grads): values and gradients bit-equal to the cat /
+    scaling / block_diag / pad construction in torch ops on the same bf16 tensors (a plain linear among the siblings contributes output
+    rows and no rank; ranks that are not multiples of 8; a second backward accumulates)."""
+    import torch.nn as nn
+    from reflectionflow_amd.flux import modules as M
+    from reflectionflow_amd.train.blocks import fused_lora
+
+    def lin(i, o, r=None):
+        base = nn.Linear(i, o)
+        if r is None:
+            return base.to(dev, BF)
+        l = M.LoraLinear(base, r, 2 * r)
+        for p in (l.lora_A["default"].weight, l.lora_B["default"].weight):
+            nn.init.normal_(p)
+        return l.to(dev, BF)
+
+    def reference(linears):
+        As, Bs = [], []
+        for l in linears:
+            if isinstance(l, M.LoraLinear):
+                As.append(torch.cat([l.lora_A[a].weight for a in l.active_adapters], 0))
+                Bs.append(torch.cat([l.lora_B[a].weight * l.scaling[a] for a in l.active_adapters], 1))
+            else:
+                As.append(torch.zeros(0, l.in_features, device=dev, dtype=BF))
+                Bs.append(torch.zeros(l.out_features, 0, device=dev, dtype=BF))
+        A, B = torch.cat(As, 0), torch.block_diag(*Bs)
+        r = A.shape[0]
+        rp = (r + 63) // 64 * 64
+        return torch.nn.functional.pad(A, (0, 0, 0, rp - r)), torch.nn.functional.pad(B, (0, rp - r))
+
+    torch.manual_seed(0)
+    for linears in ([lin(48, 32, 8), lin(48, 16), lin(48, 40, 4)], [lin(64, 24, 32)], [lin(32, 8, 40), lin(32, 8, 40)],
+                    [lin(3072, 3072, 32), lin(3072, 3072, 32), lin(3072, 3072, 32), lin(3072, 12288, 32)]):
+        A, B = fused_lora(linears)
+        A0, B0 = reference(linears)
+        assert torch.equal(A, A0) and torch.equal(B, B0)
+        ps = [p for l in linears if isinstance(l, M.LoraLinear) for p in (l.lora_A["default"].weight, l.lora_B["default"].weight)]
+        gA, gB = torch.randn_like(A), torch.randn_like(B)
+        want = torch.autograd.grad([A0, B0], ps, [gA, gB])
+        for p in ps:
+            p.grad = None
+        torch.autograd.backward([A, B], [gA, gB], retain_graph=True)
+        for p, y in zip(ps, want):
+            assert torch.equal(p.grad, y)
+        torch.autograd.backward([A, B], [gA, gB])                      # accumulates: bf16(g + g) = 2 g exactly
+        for p, y in zip(ps, want):
+            assert torch.equal(p.grad, 2 * y)
+    assert fused_lora([lin(8, 8)]) == (None, None)
+
+
 # ------------------------------------------------------------------------------------------------- the whole step
 def _product_step(pipe, batch, cfg):
     from reflectionflow_amd.train.step import FluxTrainer, lora_parameters
