@@ -2,7 +2,7 @@
 # Round-5 second closing session on the GPU box (one gpurun call), after the training-step work: the GPU suite on the final tree, smoke(),
 # the default bench line, the training step at the reference's batch size, and the rocprofv3 kernel trace of a training step
 # (per-kernel table + the idle-time analysis of tools/trace_gaps.py).  Everything lands in gpurun_out/final5/.
-OUT=gpurun_out/final5
+OUT=gpurun_out/final6
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -q -m gpu -x > $OUT/gpu_suite.log 2>&1; tail -3 $OUT/gpu_suite.log
