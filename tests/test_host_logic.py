@@ -233,3 +233,25 @@ def test_rope_table_cache_works_under_inference_mode():
         assert c3.shape[0] == 9 + 16
     img.add_(1)                                                                   # an in-place edit must miss
     assert not torch.equal(eng.rope_tables(txt, img)[0], cos)
+
+
+def test_trace_gaps_tool_on_a_synthetic_kernel_trace(tmp_path):
+    """tools/trace_gaps.py (profiles/r05_train_step_gaps*.md): a step = the kernels between two optimizer launches; busy time, idle
+    time and the idle time booked on the kernel in front of each gap."""
+    import os
+    import subprocess
+    import sys
+    rows = [("rf::prodigy_apply_kernel<false>", 0, 10_000),
+            ("rf::gemm_bf16_pp16e_kernel(rf::GemmParams)", 20_000, 320_000),          # 10 us gap behind the optimizer (outside the step)
+            ("void rf::ln_mod_kernel<6>(x)", 326_000, 336_000),                       # 6 us gap behind the GEMM
+            ("void at::native::vectorized_elementwise_kernel<8, Foo>(int)", 1_336_000, 1_340_000),   # 1 ms gap behind ln_mod
+            ("rf::prodigy_apply_kernel<false>", 1_342_000, 1_350_000)]
+    f = tmp_path / "t_kernel_trace.csv"
+    f.write_text('"Kernel_Name","Start_Timestamp","End_Timestamp"\n' + "".join(f'"{n}",{a},{b}\n' for n, a, b in rows))
+    out = tmp_path / "gaps.md"
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "trace_gaps.py")
+    r = subprocess.run([sys.executable, tool, str(f), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = out.read_text()
+    assert "4 kernels" in text and "busy 0.32 ms" in text and "idle 1.01 ms" in text
+    assert "`ln_mod_kernel<6>` | 1 | 1.00" in text and "1.00 ms at kernel 2 / 4" in text
