@@ -121,11 +121,25 @@ def _save(path: str, latents: torch.Tensor, pipe: FluxPipeline, height: int, wid
 
 
 def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: FluxPipeline, shard: search.Shard,
-                      start_index: int = 0, metadatas: Optional[List[dict]] = None) -> List[dict]:
-    """tts_t2i_noise_scaling.py:126-159.  The output directory has the layout the reflection driver's `--imgpath` reads
-    (`<index>/metadata.jsonl` + `<index>/samples/<round>_round@<seed>.png`), as in the reference."""
+                      start_index: int = 0, metadatas: Optional[List[dict]] = None, seeds_fn=None) -> List[dict]:
+    """The plain t2i candidate loop, tts_t2i_noise_scaling.py:126-159 (`main`'s prompt x round loop) + :16-77 (`sample`),
+    sharded over ranks; BASELINE cfg1 / cfg3 are quoted on it.  Pinned by `tests/golden/noise_scaling.json`, recorded
+    from the reference's own main(): per prompt `<index + start_index:05>/metadata.jsonl` (`json.dump` of the meta line,
+    :136-137) and `<index>/samples/` (:132-133); per round `search_branch` seeded noises (:141-148), one stock `pipe(...)`
+    call per candidate with prompt / latents / guidance_scale / num_inference_steps / height / width and nothing else
+    (:60), the candidate written as `samples/<round>_round@<seed>.png` (:47-49, :70), and the datapoint
+    {prompt, search_round, num_noises} (:72-77) -- the tree the reflection driver's `--imgpath` reads.
+
+    Deviations, deliberate: candidate i of a round runs on rank i % world_size (the reference: a serial loop on one GPU);
+    its seed is `seeds_fn(prompt index, round, N)[i]` -- by default `candidate_seeds`, a pure function of the indices, where
+    the reference draws `torch.randint` from the global RNG (:141, utils.py:141) -- so the tree does not depend on the world
+    size; `batch_size_for_img_gen` > 1 (:37-58: b candidates in one pipe call) still means one call per candidate here
+    (the engine runs batch 1; same prompts, noises and files); the pipe is asked for latents and `_save` decodes them (PNG
+    with a VAE on the pipeline, the packed latents as `.pt` without one); `use_low_gpu_vram` (:51-52, :62-63: the pipeline
+    hops between CPU and GPU around every batch) is ignored: 24 GB of weights stay resident in 288 GB."""
     pa, sa = config["pipeline_args"], config["search_args"]
     dev, dtype = pipe.device, pipe.dtype
+    seeds_fn = seeds_fn or candidate_seeds
     out = []
     for index, prompt in enumerate(prompts):
         outpath = os.path.join(output_dir, f"{index + start_index:0>5}")
@@ -134,8 +148,12 @@ def run_noise_scaling(config: dict, prompts: List[str], output_dir: str, pipe: F
             os.makedirs(sample_dir, exist_ok=True)
             with open(os.path.join(outpath, "metadata.jsonl"), "w") as fp:       # tts_t2i_noise_scaling.py:136-137
                 json.dump(metadatas[index] if metadatas is not None else {"prompt": prompt}, fp)
+        if shard.world_size > 1:
+            torch.distributed.barrier()                                         # rank 0 made the directories every rank writes into
         for rnd in range(1, sa["search_rounds"] + 1):
-            seeds = candidate_seeds(index + start_index, rnd, sa["search_branch"])
+            seeds = [int(s) for s in seeds_fn(index + start_index, rnd, sa["search_branch"])]
+            if len(set(seeds)) != len(seeds):                                   # utils.py:153 (`assert len(noises) == len(seeds)`)
+                raise ValueError(f"prompt {index + start_index} round {rnd}: duplicate candidate seeds {seeds}")
             for i in shard.mine(len(seeds)):
                 noise = get_noises(MAX_SEED, 1, pa["height"], pa["width"], device=dev, dtype=dtype, seeds=[seeds[i]])[seeds[i]]
                 lat = pipe(prompt=[prompt], latents=noise, guidance_scale=pa["guidance_scale"],
