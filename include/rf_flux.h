@@ -36,7 +36,7 @@ typedef enum rf_status {
 
 const char* rf_last_error(void);
 /* ABI version: bump on any struct/signature change (v13: rf_attn_bwd_desc.kernel, rf_lora_adamw / rf_lora_prodigy; v14: rf_lora_fuse /
- * rf_lora_unfuse_grads, rf_qkv_train_fwd's forward-only form). */
+ * rf_lora_unfuse_grads, rf_qkv_train_fwd's forward-only form; v15: rf_lora_clip_grad_norm). */
 int rf_abi_version(void);
 /* Returns 950 when the library was compiled for gfx950. */
 int rf_target_arch(void);
@@ -616,6 +616,14 @@ int rf_lora_prodigy(void* param, const void* grad, void* exp_avg, void* exp_avg_
                     int32_t state_fp32, double* dstate, float lr, float beta1, float beta2, float beta3, float eps,
                     float weight_decay, int32_t decouple, int32_t use_bias_correction, int32_t safeguard_warmup, float d_coef,
                     float growth_rate, float grad_scale, float* partials, int64_t partials_bytes, void* stream);
+
+/* Gradient clipping by global L2 norm over the flat gradient bucket (ABI v15): the reference's Lightning Trainer runs with
+ * gradient_clip_val = 0.5 (train_flux/train/train.py:165), i.e. torch.nn.utils.clip_grad_norm_(params, 0.5) between the DDP all-reduce and
+ * optimizer.step:  total_norm = || grad_scale * grad ||_2,  coef = min(1, max_norm / (total_norm + 1e-6)),  grad *= coef  (in place, bf16).
+ * `out` = 2 floats ON THE DEVICE {total_norm, coef}: nothing crosses to the host.  `partials`: >= 4 bytes per 8192 elements
+ * (rf_lora_prodigy_partials_bytes(n) is enough).  Fixed-order sums: bit-reproducible.  Three launches. */
+int rf_lora_clip_grad_norm(void* grad, int64_t n, float max_norm, float grad_scale, float* partials, int64_t partials_bytes, float* out,
+                           void* stream);
 
 /* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
  * shape with hipEvents on `stream`; returns average microseconds in *us. */

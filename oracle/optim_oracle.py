@@ -63,9 +63,11 @@ def prodigy_step(p: torch.Tensor, g: torch.Tensor, st: Dict, lr: float = 1.0, be
         st["m"].mul_(beta1).add_(g, alpha=d * (1 - beta1))
         st["v"].mul_(beta2).addcmul_(g, g, value=d * d * (1 - beta2))
         st["s"].mul_(beta3).add_(g, alpha=(d / d0) * (d if safeguard_warmup else dlr))
-    d_denom = float(st["s"].abs().double().sum())
+        d_denom = float(st["s"].abs().double().sum())                # the package accumulates d_denom INSIDE the lr > 0 gate ...
+    else:
+        d_denom = 0.0
     if d_denom == 0:
-        return                                                       # no gradient seen yet: nothing moves, k stays
+        return                                                       # ... so lr == 0, or no gradient seen yet: nothing moves, k stays
     d_hat = d
     d_max = st["d_max"]
     if lr > 0.0:

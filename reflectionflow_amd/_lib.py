@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librf_flux.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
@@ -223,6 +223,7 @@ _SIGS = {
     "rf_gemm_tn_skinny": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "rf_lora_adamw": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "rf_lora_prodigy_partials_bytes": (C.c_int64, [C.c_int64]),
+    "rf_lora_clip_grad_norm": (C.c_int, [_P, C.c_int64, C.c_float, C.c_float, _P, C.c_int64, _P, _P]),
     "rf_lora_prodigy": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P] + [C.c_float] * 6 + [C.c_int32] * 3 + [C.c_float] * 3 +
                         [_P, C.c_int64, _P]),
     "rf_profile_begin": (C.c_int, [C.c_int32]),

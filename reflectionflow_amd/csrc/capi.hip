@@ -108,5 +108,5 @@ extern "C" int rf_profile_end(double* us_sum, int64_t* launches, double* work_su
 }
 
 extern "C" const char* rf_last_error(void) { return rf::g_err; }
-extern "C" int rf_abi_version(void) { return 14; }
+extern "C" int rf_abi_version(void) { return 15; }
 extern "C" int rf_target_arch(void) { return 950; }

@@ -220,6 +220,67 @@ __global__ __launch_bounds__(OPT_THREADS) void prodigy_apply_kernel(bf16_t* __re
   }
 }
 
+// ---- gradient clipping by global L2 norm -------------------------------------------------------------------------------------------
+// The reference's Lightning Trainer is built with gradient_clip_val = 0.5 (train_flux/train/train.py:165; config.yaml does not override
+// it), i.e. torch.nn.utils.clip_grad_norm_(params, 0.5) between the DDP all-reduce and optimizer.step:
+//   total_norm = || grad_scale * grad ||_2;  coef = min(1, max_norm / (total_norm + 1e-6));  grad *= coef
+// Three launches over the flat gradient bucket: block partial sums of squares (fp32 per lane, fixed butterfly / wave order), one
+// workgroup adding the partials in block order in fp64 and forming {total_norm, coef} ON THE DEVICE (`out`, 2 floats: no host sync
+// in a step), and the in-place scale (skipped per workgroup when coef == 1: a multiply by 1 is the identity in bf16 as well).
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_kernel(const bf16_t* __restrict__ grad, int64_t n, float* __restrict__ partials) {
+  __shared__ float red[OPT_THREADS / WAVE];
+  float acc = 0.f;
+  const int64_t base = (int64_t)blockIdx.x * OPT_BLOCK_ELEMS + threadIdx.x * OPT_VEC;
+#pragma unroll
+  for (int it = 0; it < OPT_ITEMS; ++it) {
+    const int64_t i = base + (int64_t)it * OPT_THREADS * OPT_VEC;
+    if (i >= n) break;
+    float g[8];
+    load_bf8(grad, i, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += g[j] * g[j];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void clip_coef_kernel(const float* __restrict__ partials, int nblocks, float max_norm, float grad_scale,
+                                                                float* __restrict__ out) {
+  __shared__ double red[OPT_THREADS];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += OPT_THREADS) s += (double)partials[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = OPT_THREADS / 2; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double norm = sqrt(red[0]) * fabs((double)grad_scale);
+  const double coef = (double)max_norm / (norm + 1e-6);
+  out[0] = (float)norm;
+  out[1] = (coef < 1.0 || coef != coef) ? (float)coef : 1.0f;   // torch.clamp(coef, max=1) keeps a NaN coefficient (non-finite norm, error_if_nonfinite=False)
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void scale_grad_kernel(bf16_t* __restrict__ grad, int64_t n, const float* __restrict__ out) {
+  const float coef = out[1];
+  if (coef == 1.0f) return;
+  const int64_t base = (int64_t)blockIdx.x * OPT_BLOCK_ELEMS + threadIdx.x * OPT_VEC;
+#pragma unroll
+  for (int it = 0; it < OPT_ITEMS; ++it) {
+    const int64_t i = base + (int64_t)it * OPT_THREADS * OPT_VEC;
+    if (i >= n) break;
+    float g[8];
+    load_bf8(grad, i, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= coef;
+    store_bf8(grad, i, g);
+  }
+}
+
 static int opt_check(const char* who, const void* param, const void* grad, const void* m, const void* v, int64_t n) {
   RF_REQUIRE(param && grad && m && v, RF_ERR_NULL, "%s: NULL pointer", who);
   RF_REQUIRE(n > 0 && n % OPT_VEC == 0 && n / OPT_BLOCK_ELEMS < (1ll << 30), RF_ERR_SHAPE, "%s: n=%lld (need n > 0, n %% 8 == 0)", who, (long long)n);
@@ -274,6 +335,7 @@ extern "C" int rf_lora_prodigy(void* param, const void* grad, void* exp_avg, voi
              (long long)partials_bytes, (long long)rf_lora_prodigy_partials_bytes(n));
   RF_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && lr >= 0.f, RF_ERR_SHAPE, "rf_lora_prodigy: lr=%g betas=(%g, %g)", lr,
              beta1, beta2);
+  if (lr == 0.f) return RF_OK;   // prodigyopt gates the moment / s / numerator updates on group_lr > 0 and then returns on d_denom == 0: nothing moves, k stays
   ProdigyCfg c;
   c.lr = lr, c.beta1 = beta1, c.beta2 = beta2, c.beta3 = beta3 > 0.f ? beta3 : sqrtf(beta2), c.eps = eps, c.decay = weight_decay;
   c.d_coef = d_coef, c.growth_rate = growth_rate, c.grad_scale = grad_scale;
@@ -304,6 +366,36 @@ extern "C" int rf_lora_prodigy(void* param, const void* grad, void* exp_avg, voi
     else
       hipLaunchKernelGGL(prodigy_apply_kernel<false>, dim3(blocks), dim3(OPT_THREADS), 0, st, (bf16_t*)param, (const void*)exp_avg,
                          (const void*)exp_avg_sq, n, (const double*)dstate, c);
+    RF_LAUNCH_CHECK();
+  }
+  return RF_OK;
+}
+
+extern "C" int rf_lora_clip_grad_norm(void* grad, int64_t n, float max_norm, float grad_scale, float* partials, int64_t partials_bytes,
+                                      float* out, void* stream) {
+  using namespace rf;
+  RF_REQUIRE(grad && partials && out, RF_ERR_NULL, "rf_lora_clip_grad_norm: NULL pointer");
+  RF_REQUIRE(n > 0 && n % OPT_VEC == 0 && n / OPT_BLOCK_ELEMS < (1ll << 30), RF_ERR_SHAPE, "rf_lora_clip_grad_norm: n=%lld (need n > 0, n %% 8 == 0)",
+             (long long)n);
+  RF_REQUIRE(aligned16(grad), RF_ERR_ALIGN, "rf_lora_clip_grad_norm: grad must be 16-byte aligned");
+  RF_REQUIRE(max_norm > 0.f, RF_ERR_SHAPE, "rf_lora_clip_grad_norm: max_norm=%g", max_norm);
+  const unsigned blocks = (unsigned)((n + OPT_BLOCK_ELEMS - 1) / OPT_BLOCK_ELEMS);
+  RF_REQUIRE(partials_bytes >= (int64_t)blocks * 4, RF_ERR_WORKSPACE, "rf_lora_clip_grad_norm: partials %lld B < %lld B", (long long)partials_bytes,
+             (long long)blocks * 4);
+  hipStream_t st = (hipStream_t)stream;
+  {
+    ProfScope prof(RF_KC_ROWOP, (double)n * 2.0, st);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(OPT_THREADS), 0, st, (const bf16_t*)grad, n, partials);
+    RF_LAUNCH_CHECK();
+  }
+  {
+    ProfScope prof(RF_KC_ROWOP, (double)blocks * 4.0, st);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(OPT_THREADS), 0, st, (const float*)partials, (int)blocks, max_norm, grad_scale, out);
+    RF_LAUNCH_CHECK();
+  }
+  {
+    ProfScope prof(RF_KC_ROWOP, (double)n * 4.0, st);
+    hipLaunchKernelGGL(scale_grad_kernel, dim3(blocks), dim3(OPT_THREADS), 0, st, (bf16_t*)grad, n, (const float*)out);
     RF_LAUNCH_CHECK();
   }
   return RF_OK;

@@ -82,6 +82,7 @@ class _FlatOptimizer:
         self.exp_avg_sq = torch.zeros(n, dtype=state_dtype, device=dev)
         self.grad_scale = 1.0                                     # set to 1 / world_size behind bucket.all_reduce()
         self.lib = L.load()
+        self._clip_ws = self._clip_out = None
 
     @property
     def param_groups(self):
@@ -89,6 +90,35 @@ class _FlatOptimizer:
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.bucket.zero_grad()
+
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_(params, max_norm) over the flat gradient bucket -- what Lightning's `gradient_clip_val` runs
+        between the DDP all-reduce and optimizer.step (the reference trains with 0.5, train_flux/train/train.py:165): the L2 norm of
+        `grad_scale * grad` (the AVERAGED gradient when the bucket holds a SUM), coef = min(1, max_norm / (norm + 1e-6)), gradients
+        scaled in place.  Norm and coefficient stay on the device: returns the 2-float tensor {total_norm, coef} without a sync."""
+        b = self.bucket
+        if self._clip_ws is None:
+            self._clip_ws = torch.empty(int(self.lib.rf_lora_prodigy_partials_bytes(b.numel)) // 4, dtype=torch.float32, device=b.param.device)
+            self._clip_out = torch.zeros(2, dtype=torch.float32, device=b.param.device)
+        L.check(self.lib.rf_lora_clip_grad_norm(b.grad.data_ptr(), b.numel, float(max_norm), float(self.grad_scale), self._clip_ws.data_ptr(),
+                                                self._clip_ws.numel() * 4, self._clip_out.data_ptr(), stream_ptr()), "rf_lora_clip_grad_norm")
+        return self._clip_out
+
+    _STATE_TENSORS: tuple = ()
+
+    def load_state_dict(self, sd: Dict) -> None:
+        """Resume from `state_dict()` (Lightning's checkpoint of the optimizer): state tensors are copied INTO the flat buffers (the
+        kernels hold their addresses), hyper-parameters replace the defaults."""
+        for k in self._STATE_TENSORS:
+            t, dst = sd[k], getattr(self, k)
+            if tuple(t.shape) != tuple(dst.shape):
+                raise RFError(f"load_state_dict: {k} has shape {tuple(t.shape)}, the bucket needs {tuple(dst.shape)}")
+            with torch.no_grad():
+                dst.copy_(t.to(dst.device))
+        for k in self.defaults:
+            if k in sd:
+                self.defaults[k] = tuple(sd[k]) if k == "betas" else sd[k]
 
 
 class LoraAdamW(_FlatOptimizer):
@@ -108,8 +138,14 @@ class LoraAdamW(_FlatOptimizer):
                                        int(self.state_fp32), self.step_count, d["lr"], d["betas"][0], d["betas"][1], d["eps"], d["weight_decay"],
                                        self.grad_scale, stream_ptr()), "rf_lora_adamw")
 
+    _STATE_TENSORS = ("exp_avg", "exp_avg_sq")
+
     def state_dict(self) -> Dict:
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, **self.defaults)
+
+    def load_state_dict(self, sd: Dict) -> None:
+        super().load_state_dict(sd)
+        self.step_count = int(sd["step"])
 
 
 class LoraProdigy(_FlatOptimizer):
@@ -145,6 +181,8 @@ class LoraProdigy(_FlatOptimizer):
         """the distance estimate, read back (a host sync: for logging / tests, never inside the step)"""
         v = self.dstate.tolist()
         return dict(d=v[0], d_max=v[1], d_numerator=v[2], d_denom=v[3], d_hat=v[4], k=int(v[5]), dlr=v[6], d0=v[7])
+
+    _STATE_TENSORS = ("exp_avg", "exp_avg_sq", "s", "p0", "dstate")       # d, d_max, the numerator and k travel in dstate
 
     def state_dict(self) -> Dict:
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, s=self.s, p0=self.p0, dstate=self.dstate, **self.defaults)

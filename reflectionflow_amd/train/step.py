@@ -93,8 +93,11 @@ def _lora_terms_batched(lins, s: torch.Tensor):
 class FluxTrainer:
     """Forward with a backward through the HIP blocks for ONE transformer; `model_config` as in config.yaml:5-8."""
 
-    def __init__(self, transformer, model_config: Optional[dict] = None, gradient_checkpointing="auto"):
-        """gradient_checkpointing: True = the reference's training config (config.yaml `gradient_checkpointing: true`,
+    def __init__(self, transformer, model_config: Optional[dict] = None, gradient_checkpointing="auto", gradient_clip_val: Optional[float] = 0.5):
+        """gradient_clip_val: the global L2 norm the gradients are clipped to before every optimizer update -- the reference's Trainer is
+        built with `gradient_clip_val=training_config.get("gradient_clip_val", 0.5)` (train_flux/train/train.py:165; config.yaml does not
+        override it), so 0.5 is the default here too; None or 0 = no clipping.
+        gradient_checkpointing: True = the reference's training config (config.yaml `gradient_checkpointing: true`,
         transformer.py:139-157: every block re-runs its forward inside the backward); False = every block keeps its intermediates;
         "auto" (default) = keep them for as many blocks as fit the free HBM (~0.8 GB per block at 5632 tokens: all 57 blocks of one
         sample are ~45 GB of 288) and re-compute the rest.  The gradients are bit-identical in all three."""
@@ -103,6 +106,9 @@ class FluxTrainer:
         if gradient_checkpointing not in (True, False, "auto"):
             raise ops.RFError(f"gradient_checkpointing must be True, False or 'auto', got {gradient_checkpointing!r}")
         self.gradient_checkpointing = gradient_checkpointing
+        if gradient_clip_val is not None and gradient_clip_val < 0:
+            raise ops.RFError(f"gradient_clip_val must be >= 0 or None, got {gradient_clip_val!r}")
+        self.gradient_clip_val = gradient_clip_val or None
         self.kept_blocks = 0                                # blocks of the last forward that kept their intermediates (telemetry)
         if self.cfg.get("add_cond_attn", False) or not self.cfg.get("union_cond_attn", True):
             raise ops.RFError("the training path covers the shipped training config (union_cond_attn: true, add_cond_attn: false)")
@@ -139,7 +145,7 @@ class FluxTrainer:
     def training_step(self, batch: Dict[str, torch.Tensor], world_size: int = 1, group=None, generator: Optional[torch.Generator] = None,
                       sample_by_sample: Optional[bool] = None) -> torch.Tensor:
         """One optimisation step as the reference's Lightning loop runs it (zero_grad -> step() -> backward -> DDP all-reduce ->
-        optimizer.step): returns the detached loss.  Needs configure_optimizers() first.
+        clip_grad_norm_(gradient_clip_val) -> optimizer.step): returns the detached loss.  Needs configure_optimizers() first.
         sample_by_sample (default: on for a batch of several samples unless gradient_checkpointing is True): forward + backward of one
         sample at a time, each with 1 / B of the loss -- the mean over the batch is the mean of the per-sample means, so the summed
         gradients are those of the batched loss up to the order of the bf16 accumulation, while only ONE sample's activations are alive
@@ -174,8 +180,37 @@ class FluxTrainer:
         if world_size > 1:
             opt.bucket.all_reduce(world_size, group)
             opt.grad_scale = 1.0 / world_size
+        if self.gradient_clip_val:
+            opt.clip_grad_norm_(self.gradient_clip_val)      # norm of the averaged gradient, on the device; opt.last_clip() reads it back
         opt.step()
         return loss.detach()
+
+    # -------------------------------------------------------------------------------------------------- checkpoints
+    def save_lora(self, path: str, adapter_name: Optional[str] = None) -> str:
+        """train/model.py:87-92 (`OminiModel.save_lora`, called every `save_interval` steps by callbacks.py:68-74):
+        `FluxPipeline.save_lora_weights(path, transformer_lora_layers=get_peft_model_state_dict(transformer), safe_serialization=True)`
+        -> `<path>/pytorch_lora_weights.safetensors` with keys `transformer.<module>.lora_{A,B}.weight` (peft drops the adapter name
+        from the key) -- the file `pipe.load_lora_weights(path)` and the search drivers' `lora_path` read.  Every factor is CLONED out
+        of the flat bucket first: after configure_optimizers() all of them are views of one storage, which safetensors refuses (or, by
+        version, splits) and which torch.save would serialise whole.  Returns the file name."""
+        import os
+        from safetensors.torch import save_file
+        names = sorted({a for _n, m in self.tr.named_modules() if isinstance(m, LoraLinear) for a in m.lora_A})
+        if adapter_name is None:
+            if len(names) != 1:
+                raise ops.RFError(f"save_lora: adapters {names} on the model: name the one to save")
+            adapter_name = names[0]
+        sd = {}
+        for n, m in self.tr.named_modules():
+            if isinstance(m, LoraLinear) and adapter_name in m.lora_A:
+                sd[f"transformer.{n}.lora_A.weight"] = m.lora_A[adapter_name].weight.detach().clone().contiguous()
+                sd[f"transformer.{n}.lora_B.weight"] = m.lora_B[adapter_name].weight.detach().clone().contiguous()
+        if not sd:
+            raise ops.RFError(f"save_lora: no LoRA factors of adapter {adapter_name!r} on the model")
+        os.makedirs(path, exist_ok=True)
+        fn = os.path.join(path, "pytorch_lora_weights.safetensors")
+        save_file(sd, fn, metadata={"format": "pt"})
+        return fn
 
     # -------------------------------------------------------------------------------------------------- pieces
     def _mods(self, temb: torch.Tensor, lora_on: bool):
