@@ -625,34 +625,6 @@ int rf_lora_prodigy(void* param, const void* grad, void* exp_avg, void* exp_avg_
 int rf_lora_clip_grad_norm(void* grad, int64_t n, float max_norm, float grad_scale, float* partials, int64_t partials_bytes, float* out,
                            void* stream);
 
-/* Kernel-level timing hook used by bench.py: time `iters` launches of the dominant GEMM
- * shape with hipEvents on `stream`; returns average microseconds in *us. */
-int rf_time_gemm(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
-int rf_time_gemm_w8a8(const rf_gemm_desc* d, int32_t iters, float* us, void* stream);
-
-/* In-sequence timing hook (bench.py's `roofline`): between rf_profile_begin and rf_profile_end every launch site of
- * the library records ONE hipEvent on ITS launch stream in front of its kernel(s); rf_profile_end records a closing
- * event.  A launch's duration is the distance to the next event (kernel + the gap behind it), so the durations are
- * those of the kernels inside the real 57-block sequence (cold operands, real neighbours), not of isolated
- * re-launches, and the per-class sums add up exactly to the wall time between the first and the closing event.
- * rf_profile_end synchronises, then fills, per rf_kernel_class: summed duration (us), launch count and summed
- * algorithmic work (FLOPs: 2MNK per GEMM over all groups and K-segments, 4*S^2*128*heads per attention launch;
- * BYTES read+written for the row kernels).  `dropped` = launches beyond max_launches (not timed).
- * Not thread-safe, single stream, not for use during hipGraph capture; costs one event record per launch while open. */
-typedef enum rf_kernel_class {
-  RF_KC_GEMM_MAIN = 0,   /* 256x256-tile MFMA GEMM launches (tile-per-block ping-pong loop and stream-K) */
-  RF_KC_GEMM_SMALL = 1,  /* 128x128-tile launches (embedders, LoRA down-projections incl. split-K + reduce) */
-  RF_KC_ATTN = 2,        /* rf_attention / rf_attention_fwd */
-  RF_KC_ROWOP = 3,       /* LayerNorm+modulate, RMSNorm+RoPE, Euler, SiLU, add */
-  RF_KC_GEMM_W8 = 4,     /* fp8-weight GEMM launches (rf_gemm_w8a8) */
-  RF_KC_QUANT = 5,       /* activation quantisation row kernels of the fp8 path */
-  RF_KC_ATTN_BWD = 6,    /* rf_attention_bwd (work = 5 products x 2 S^2 128 per head = 2.5 x the forward's) */
-  RF_KC_COUNT = 7
-} rf_kernel_class;
-int rf_profile_begin(int32_t max_launches);
-int rf_profile_end(double* us_sum /*[RF_KC_COUNT]*/, int64_t* launches /*[RF_KC_COUNT]*/,
-                   double* work_sum /*[RF_KC_COUNT]*/, int32_t* dropped /* may be NULL */);
-
 #ifdef __cplusplus
 }
 #endif

@@ -163,7 +163,7 @@ class rf_clip_weights(C.Structure):
                 ("final_ln_scale", C.c_void_p), ("final_ln_shift", C.c_void_p), ("layer", C.POINTER(rf_clip_layer))]
 
 
-# every symbol include/rf_flux.h declares: (restype, argtypes)
+# every symbol include/rf_flux.h (the product ABI) declares: (restype, argtypes)
 _SIGS = {
     "rf_last_error": (C.c_char_p, []),
     "rf_abi_version": (C.c_int, []),
@@ -172,7 +172,6 @@ _SIGS = {
     "rf_gemm_w8a8": (C.c_int, [C.POINTER(rf_gemm_desc), _P]),
     "rf_layernorm_modulate_fp8": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P, C.c_float, _P]),
     "rf_quant_rows_fp8": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P]),
-    "rf_time_gemm_w8a8": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
     "rf_qk_rmsnorm_rope": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
                                      C.c_float, _P]),
     "rf_attention_fwd": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
@@ -195,7 +194,6 @@ _SIGS = {
                                   C.POINTER(rf_workspace), _P]),
     "rf_flux_denoise": (C.c_int, [C.POINTER(rf_flux_dims), C.POINTER(rf_flux_model), _P, _P, _P, _P, C.c_int64, _P,
                                   _P, _P, C.POINTER(C.c_float), C.c_int32, _P, C.POINTER(rf_workspace), _P]),
-    "rf_time_gemm": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
     "rf_vae_workspace_bytes": (C.c_int64, [C.POINTER(rf_vae_weights), C.c_int32, C.c_int32, C.c_int32]),
     "rf_vae_decode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
     "rf_vae_encode": (C.c_int, [C.POINTER(rf_vae_weights), _P, C.c_int32, C.c_int32, _P, C.POINTER(rf_workspace), _P]),
@@ -226,14 +224,16 @@ _SIGS = {
     "rf_lora_clip_grad_norm": (C.c_int, [_P, C.c_int64, C.c_float, C.c_float, _P, C.c_int64, _P, _P]),
     "rf_lora_prodigy": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, _P] + [C.c_float] * 6 + [C.c_int32] * 3 + [C.c_float] * 3 +
                         [_P, C.c_int64, _P]),
-    "rf_profile_begin": (C.c_int, [C.c_int32]),
-    "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
-                                 C.POINTER(C.c_int32)]),
 }
 RF_KC_NAMES = ("gemm_main", "gemm_small", "attention", "rowop", "gemm_w8", "quant", "attention_bwd")
-# read-only introspection (tests, bench); not part of the declared drop-in surface.  librf_flux.so exports NO kernel-selecting
-# switch: tests pin a kernel per launch through rf_gemm_desc.schedule / rf_attn_desc.kernel.
-_EXTRA_SIGS = {"rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_attn_bwd_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),
+# include/rf_flux_debug.h: timing hooks and read-only introspection (tests, bench, tools); not part of the drop-in surface.
+# librf_flux.so exports NO kernel-selecting switch: tests pin a kernel per launch through rf_gemm_desc.schedule / rf_attn_desc.kernel.
+_EXTRA_SIGS = {
+    "rf_time_gemm_w8a8": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
+    "rf_time_gemm": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_float), _P]),
+    "rf_profile_begin": (C.c_int, [C.c_int32]),
+    "rf_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "rf_debug_last_attn_path": (C.c_int, []), "rf_debug_last_attn_bwd_path": (C.c_int, []), "rf_debug_last_gemm_path": (C.c_int, []),
                "rf_debug_clock_probe": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
                "rf_debug_sk_plan": (C.c_int, [C.POINTER(rf_gemm_desc), C.c_int32, C.POINTER(C.c_int32)]),
                "rf_debug_attn_mix_plan": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)])}
@@ -268,7 +268,13 @@ def load():
 
 
 def declared_symbols():
+    """the product ABI (include/rf_flux.h)"""
     return sorted(_SIGS)
+
+
+def debug_symbols():
+    """measurement / introspection entry points (include/rf_flux_debug.h)"""
+    return sorted(_EXTRA_SIGS)
 
 
 def check(rc: int, what: str = ""):

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "rf_flux.h"
+#include "rf_flux_debug.h"   // includes rf_flux.h (the product ABI); the profiling classes live in the debug header
 
 namespace rf {
 

@@ -11,10 +11,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "rf_flux.h")
+HDR_DEBUG = os.path.join(ROOT, "include", "rf_flux_debug.h")
 
 
-def header_functions():
-    txt = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+def header_functions(path=HDR):
+    txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
     return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -35,6 +36,12 @@ def test_library_exports_every_declared_symbol(lib):
     for n in names:
         assert hasattr(raw, n), f"librf_flux.so does not export {n} (declared in include/rf_flux.h)"
     assert set(names) == set(_lib.declared_symbols()), "ctypes binding and header disagree"
+    # the product ABI carries no timing / debug entry point: those live in rf_flux_debug.h
+    assert not [n for n in names if n.startswith(("rf_debug_", "rf_time_", "rf_profile_"))]
+    dbg = header_functions(HDR_DEBUG)
+    assert set(dbg) == set(_lib.debug_symbols()) and len(dbg) == 10
+    for n in dbg:
+        assert hasattr(raw, n), f"librf_flux.so does not export {n} (declared in include/rf_flux_debug.h)"
     assert lib.rf_abi_version() == _lib.ABI_VERSION and lib.rf_target_arch() == 950
 
 
@@ -43,7 +50,7 @@ def test_header_is_plain_c_and_struct_layout_matches_binding(lib):
     structs = ["rf_kseg", "rf_gemm_group", "rf_gemm_desc", "rf_attn_desc", "rf_attn_bwd_desc", "rf_lora_seg", "rf_double_block_weights",
                "rf_single_block_weights", "rf_flux_dims", "rf_workspace", "rf_flux_model"] + \
         ["rf_vae_conv", "rf_vae_norm", "rf_vae_resnet", "rf_vae_attn", "rf_vae_weights", "rf_t5_layer", "rf_t5_weights", "rf_clip_layer", "rf_clip_weights"]
-    src = '#include "rf_flux.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){\n' + "".join(
+    src = '#include "rf_flux_debug.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){\n' + "".join(
         f'printf("{s} %zu\\n", sizeof({s}));\n' for s in structs) + \
         'printf("off_g %zu\\n", offsetof(rf_gemm_desc, g));\nprintf("off_out %zu\\n", offsetof(rf_gemm_group, out));\n' \
         'printf("off_sched %zu\\n", offsetof(rf_gemm_desc, schedule));\nprintf("off_kernel %zu\\n", offsetof(rf_attn_desc, kernel));\n' \
