@@ -69,9 +69,7 @@ typedef enum rf_gemm_schedule {
   RF_SCHED_PERSISTENT = 4,  /* one persistent workgroup per CU walking whole 256x256 tiles (needs splitk_ws)                */
   RF_SCHED_PLAIN256 = 5,    /* 256x256 tiles on the plain double-buffered loop: bit-exact reference of the ping-pong loops  */
   RF_SCHED_W4 = 6,          /* 256x256 tiles, ONE wave per SIMD (4 waves x 128x128 wave tiles): fewer LDS bytes per MFMA     */
-  RF_SCHED_W4B = 7,         /* ... with three half-stage barriers per K-tile: LDS-DMA spread over the whole tile (round 5)  */
-  RF_SCHED_TILE256_PF = 8,  /* TILE256 + weight-panel touches: every wave pulls its W rows of K-tile t+5 into the L2 (round 6) */
-  RF_SCHED_W4B_PF = 9       /* W4B + the same touches                                                                       */
+  RF_SCHED_W4B = 7          /* ... with three half-stage barriers per K-tile: LDS-DMA spread over the whole tile (round 5)  */
 } rf_gemm_schedule;
 
 typedef struct rf_kseg {

@@ -15,8 +15,7 @@ ABI_VERSION = 15
 
 RF_EPI_STORE, RF_EPI_GELU, RF_EPI_GATE_RES, RF_EPI_QKV, RF_EPI_QKV_GELU = range(5)
 # rf_gemm_schedule (rf_gemm_desc.schedule): how ONE launch is cut into workgroups; AUTO everywhere in the product
-(RF_SCHED_AUTO, RF_SCHED_TILE128, RF_SCHED_TILE256, RF_SCHED_STREAMK, RF_SCHED_PERSISTENT, RF_SCHED_PLAIN256, RF_SCHED_W4, RF_SCHED_W4B,
- RF_SCHED_TILE256_PF, RF_SCHED_W4B_PF) = range(10)
+RF_SCHED_AUTO, RF_SCHED_TILE128, RF_SCHED_TILE256, RF_SCHED_STREAMK, RF_SCHED_PERSISTENT, RF_SCHED_PLAIN256, RF_SCHED_W4, RF_SCHED_W4B = range(8)
 # rf_attn_kernel (rf_attn_desc.kernel)
 RF_ATTN_AUTO, RF_ATTN_ONLINE128, RF_ATTN_ONLINE256 = 0, 1, 2
 RF_ATTN_BOUNDED32, RF_ATTN_BOUNDED16, RF_ATTN_BOUNDED16_SPLIT, RF_ATTN_LAGGED16, RF_ATTN_LAGGED16_SPLIT = 4, 5, 6, 8, 9

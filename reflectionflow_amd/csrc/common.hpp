@@ -28,15 +28,11 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define RF_MAKE_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, 0x7fffffff, 0x00020000)
-#define RF_MAKE_RSRC_N(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, (int)(bytes), 0x00020000)   // bounds-checked: out-of-range lanes are dropped
 #define RF_BUF_LOAD_LDS(r, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 16, voff, soff, 0, 0)
-#define RF_BUF_LOAD_LDS4(r, lds, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, 4, voff, soff, 0, 0)   // one dword per lane (cache-line touch)
 #else
 typedef int rsrc_t;
 #define RF_MAKE_RSRC(p) 0
-#define RF_MAKE_RSRC_N(p, bytes) 0
 #define RF_BUF_LOAD_LDS(r, lds, voff, soff) ((void)0)
-#define RF_BUF_LOAD_LDS4(r, lds, voff, soff) ((void)0)
 #endif
 
 

@@ -183,11 +183,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GemmGro
 // gives 8-byte runs along the key axis).
 constexpr int EPI_ROW = 528;                 // padded fp32 row: 128 cols * 4 B + 16 B
 constexpr int EPI_REGION = 32 * EPI_ROW;     // one wave's staging region
-// LDS scratch of the weight-panel touches (gemm_mainloop_pp3_m16<PFD>, gemm_mainloop_w4b<PFD>): 256 bytes per wave behind everything
-// else a 256 x 256 kernel keeps in the LDS (8 epilogue regions = 135168 B >= the 128 KiB of the two K-tile stages; W4B's padded images: 135168 B)
-constexpr int PP_PF_SCRATCH = 8 * EPI_REGION;
-constexpr int PF_SCRATCH_BYTES = 8 * 256;
-constexpr int GEMM_PFD = 3;   // K-tiles the weight-panel touch runs ahead of the LDS-DMA ring (which itself stages tile t + 2 during tile t)
 
 // Accumulator views: the epilogue touches a wave's accumulators in two ways only -- 4-token runs of one column (V^T,
 // straight from registers) and "stage the 32-row block i into the wave's LDS region" -- so the two MFMA shapes differ
@@ -876,16 +871,6 @@ __device__ __forceinline__ void gemm_mainloop_pp2_m16(const GemmGroupDev& G, con
 // THE SHIPPED bf16 LOOP (gemm_bf16_pp16e_kernel; the stream-K kernel's EVEN form): the evenly loaded 6/6/6/6 + 2/2/2/2 ping-pong
 // schedule on 16x16x32 MFMAs: the k-step-0 fragments of column tiles 0, 1 of each W half are read one phase early (e0 / e1), the other six
 // share one register set m; a phase starts with the four MFMAs that need only the early pair.
-//
-// PFD > 0 (round 6): WEIGHT-PANEL PREFETCH.  Inside the 57-block sequence 23.8 GB of weights pass between two uses of a panel, so every
-// W slice arrives from HBM, ~1 us away, while the LDS-DMA ring looks one to two K-tiles (1.2 - 2.5 us) ahead: a late piece holds a phase
-// barrier for all eight waves (kb_cold: 1-5 % on this loop, 3-11 % on the one-wave-per-SIMD loop).  Each wave therefore touches, once per
-// K-tile, one dword of each of its 32 W rows of K-tile (t + 2 + PFD) -- 32 cache lines, 256 per workgroup = the whole 32 KiB slice -- with a
-// 4-byte `buffer_load ... lds` into a 256-byte scratch nobody reads (no VGPR to keep alive, no data dependence), so the line is in this
-// XCD's L2 (and the Infinity Cache) when the ring's own DMA asks for it PFD tiles later.  The resource of the touch carries the operand's
-// real extent: a touch past the last row's K range is dropped by the bounds check.  One more entry in the in-order VMEM queue: the counted
-// waits of p0 / p2 grow from 8 to 9 and the prologue issues one touch so that the count holds from tile 0.
-template <int PFD = 0>
 __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int kt_begin,
                                                   const int nk, f32x4 (&acc)[4][8], char* smem, const int w, const int lane) {
   constexpr int ESZ = 2;  // bytes per element
@@ -903,16 +888,11 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
   // segment's buffer resources / row pitches in SGPRs (re-loaded only when a cursor crosses a segment boundary)
   // (the per-lane byte offsets row * pitch + chunk are formed HERE, once per segment: in the loop they were two
   // v_mad_u64_u32 per stage call = 16 quarter-rate VALU per K-tile in the load phases, which are the critical ones)
-  struct Cur { int seg, kk, nk; rsrc_t A, W, Wp; uint32_t offA[2][2], offB[2][2], pf; };
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t offA[2][2], offB[2][2]; };
   auto load_seg = [&](Cur& c) {
     const KSegDev& S = G.seg[c.seg];
     c.nk = S.nk; c.A = RF_MAKE_RSRC(S.A); c.W = RF_MAKE_RSRC(S.W);
     const uint32_t lda2 = (uint32_t)(S.lda * ESZ), ldw2 = (uint32_t)(S.ldw * ESZ);
-    if constexpr (PFD > 0) {   // the touch: W row n0 + 32 w + (lane & 31), bounds-checked against the segment's real extent
-      const int gp = n0 + 32 * w + (lane & 31);
-      c.Wp = RF_MAKE_RSRC_N(S.W, (int64_t)(N - 1) * ldw2 + (int64_t)S.nk * 128);
-      c.pf = (uint32_t)(gp < N ? gp : N - 1) * ldw2;
-    }
     // (rows are re-derived here, once per segment, instead of living in eight registers across the loop)
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
@@ -940,10 +920,6 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
       if (kind < 2) RF_BUF_LOAD_LDS(c.A, (lds_void*)(dst + i * 8192), c.offA[kind & 1][i], c.kk * 128);
       else RF_BUF_LOAD_LDS(c.W, (lds_void*)(dst + i * 8192), c.offB[kind & 1][i], c.kk * 128);
     }
-  };
-  // W rows of K-tile (c.kk + PFD) of c's segment into the L2: one 4-byte LDS-DMA per wave into the scratch behind the epilogue regions
-  auto touch = [&](const Cur& c) {
-    if constexpr (PFD > 0) RF_BUF_LOAD_LDS4(c.Wp, (lds_void*)(smem + PP_PF_SCRATCH + w * 256), c.pf, (c.kk + PFD) * 128);
   };
 
 #pragma unroll
@@ -1000,10 +976,8 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
   stage(0, c1, 0); stage(2, c1, 0); stage(1, c1, 0); stage(3, c1, 0);
   if (nk > 1) {
     next(c2);
-    if constexpr (PFD > 0) touch(c2);                  // (in queue order: where tile -1's p1 would have put it)
     stage(0, c2, 1); stage(2, c2, 1); stage(1, c2, 1);
-    if constexpr (PFD > 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) have landed
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) have landed
     c1 = c2;
     next(c2);
   } else {
@@ -1029,8 +1003,7 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
     __builtin_amdgcn_sched_barrier(0);
     if (more1) {
       stage(3, c1, (t + 1) & 1);
-      if constexpr (PFD > 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // B1(t+1) A1(t+1) B0(t+1) touch(t-1) A0(t+1) may fly
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1041,10 +1014,7 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
     rdA(Q, base + HT);
     rdBe(e1, base + HT);
     __builtin_amdgcn_sched_barrier(0);
-    if (more2) {
-      stage(0, c2, t & 1);
-      touch(c2);
-    }
+    if (more2) stage(0, c2, t & 1);
     RF_PP3_BAR();
     mma16s(2, 0, Q, e0, m);
     asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(m[4]), "+v"(m[5]));
@@ -1054,8 +1024,7 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
     __builtin_amdgcn_sched_barrier(0);
     if (more2) {
       stage(2, c2, t & 1);
-      if constexpr (PFD > 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // B0(t+2) touch(t) A0(t+2) B1(t+1) A1(t+1) may fly
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else if (more1) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
@@ -1128,7 +1097,6 @@ __device__ __forceinline__ void gemm_pp16_body(const GemmParams& p) {
   }
 }
 // bf16 launches, evenly loaded phases (gemm_mainloop_pp3_m16)
-template <int PFD>
 __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
@@ -1147,7 +1115,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_pp16e_kernel(const GemmParams p
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x4 acc[4][8];
-  gemm_mainloop_pp3_m16<PFD>(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
+  gemm_mainloop_pp3_m16(G, p.N, m0, n0, 0, nk, acc, smem, w, lane);
   if (p.probe) clk.end(g_clk_probe);
   __syncthreads();  // every wave is done reading the staged operands: the LDS is free
   gemm_epilogue_lds16<2, false>(p, G, acc, m0, n0, (w >> 1) * 64, (w & 1) * 128, lane, smem + w * EPI_REGION);
@@ -1268,7 +1236,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_sk_kernel(const GemmPar
     const bool g8 = W8 && G.w8;   // mixed-precision launch: multiply chosen per token group
     if constexpr (MI16) {
       if (g8) gemm_mainloop_pp2_m16<W8>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
-      else if constexpr (EVEN && !W8) gemm_mainloop_pp3_m16<0>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
+      else if constexpr (EVEN && !W8) gemm_mainloop_pp3_m16(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
       else gemm_mainloop_pp2_m16<false>(G, p.N, m0, n0, ub - ts, nk_u, acc, smem, w, lane_i);
     }
     static_assert(MI16, "librf_flux.so ships the 16x16 MFMA shapes only");
@@ -1381,41 +1349,33 @@ static int launch_gemm_w4m16(GemmParams& p, hipStream_t stream) {
   return RF_OK;
 }
 
-static int launch_gemm_w4b(GemmParams& p, hipStream_t stream, const bool prefetch = false) {
+static int launch_gemm_w4b(GemmParams& p, hipStream_t stream) {
   constexpr int LDS = 2 * 2 * 32 * (1024 + 32);   // two stages x {A, W} images of 32 padded wave pieces (gemm_w4b.hpp)
-  static_assert(PP_PF_SCRATCH >= LDS, "the touch scratch must lie behind the stages");
-  constexpr int LDS_PF = PP_PF_SCRATCH + PF_SCRATCH_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4b_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4b_kernel<GEMM_PFD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PF));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w4b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
-  if (prefetch) hipLaunchKernelGGL(gemm_bf16_w4b_kernel<GEMM_PFD>, dim3(p.total_tiles), dim3(256), LDS_PF, stream, p);
-  else hipLaunchKernelGGL(gemm_bf16_w4b_kernel<0>, dim3(p.total_tiles), dim3(256), LDS, stream, p);
+  hipLaunchKernelGGL(gemm_bf16_w4b_kernel, dim3(p.total_tiles), dim3(256), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
 
-static int launch_gemm_pp(GemmParams& p, hipStream_t stream, const bool prefetch = false) {
+static int launch_gemm_pp(GemmParams& p, hipStream_t stream) {
   constexpr int LDS_MAIN = 2 * 4 * 128 * 128, LDS_EPI = 8 * EPI_REGION;
   constexpr int LDS = LDS_EPI > LDS_MAIN ? LDS_EPI : LDS_MAIN;
-  static_assert(PP_PF_SCRATCH >= LDS, "the touch scratch must lie behind the stages and the epilogue regions");
-  constexpr int LDS_PF = PP_PF_SCRATCH + PF_SCRATCH_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
     RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_w8_pp16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel<GEMM_PFD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_PF));
+    RF_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16e_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     attr_set = true;
   }
   layout_tiles<256, 256>(p);
   if (p.total_tiles == 0) return RF_OK;
   if (p.w8) hipLaunchKernelGGL(gemm_w8_pp16_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
-  else if (prefetch) hipLaunchKernelGGL(gemm_bf16_pp16e_kernel<GEMM_PFD>, dim3(p.total_tiles), dim3(512), LDS_PF, stream, p);
-  else hipLaunchKernelGGL(gemm_bf16_pp16e_kernel<0>, dim3(p.total_tiles), dim3(512), LDS, stream, p);
+  else hipLaunchKernelGGL(gemm_bf16_pp16e_kernel, dim3(p.total_tiles), dim3(512), LDS, stream, p);
   RF_LAUNCH_CHECK();
   return RF_OK;
 }
@@ -1585,7 +1545,7 @@ static int build_params(const rf_gemm_desc* d, GemmParams& p, const bool w8 = fa
   memset(&p, 0, sizeof(p));
   p.w8 = w8 ? 1 : 0;
   p.N = d->N; p.epi = d->epilogue; p.n_split = d->n_split;
-  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_W4B_PF, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
+  RF_REQUIRE(d->schedule >= RF_SCHED_AUTO && d->schedule <= RF_SCHED_W4B, RF_ERR_SHAPE, "rf_gemm: schedule=%d", d->schedule);
   p.sched = d->schedule;
   p.heads = d->heads; p.s_pad = d->s_pad;
   p.q = (bf16_t*)d->q; p.k = (bf16_t*)d->k; p.vt = (bf16_t*)d->vt;
@@ -1689,8 +1649,6 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
       case RF_SCHED_PLAIN256: tile = 257; break;
       case RF_SCHED_W4: tile = 260; break;
       case RF_SCHED_W4B: tile = 261; break;
-      case RF_SCHED_TILE256_PF: tile = 262; break;
-      case RF_SCHED_W4B_PF: tile = 263; break;
       default: {
         // 256^2 tiles pay from ~half a round of the 256 CUs (plain or stream-K: 144-192 tiles measured 15-30 % ahead of 128^2,
         // tools/kb_gemm_midsize.py / profiles/r04_gemm_midsize.md); below that only as stream-K and only with a long K
@@ -1716,8 +1674,8 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   const int64_t ws_bytes = ws_total > WS_FLAG_BYTES ? ws_total - WS_FLAG_BYTES : 0;
   p.ws = ws_base != nullptr ? (float*)((char*)ws_base + WS_FLAG_BYTES) : nullptr;
   p.ksplit = 1; p.ws_slice = 0;
-  if (tile >= 260 && tile <= 263)
-    RF_REQUIRE(p.vec_ok && !p.w8, RF_ERR_UNSUPPORTED, "rf_gemm: RF_SCHED_W4 / W4B / *_PF need bf16 operands and the 16-byte aligned epilogue path");
+  if (tile == 260 || tile == 261)
+    RF_REQUIRE(p.vec_ok && !p.w8, RF_ERR_UNSUPPORTED, "rf_gemm: RF_SCHED_W4 / W4B need bf16 operands and the 16-byte aligned epilogue path");
   if (tile >= 257 && (!p.vec_ok || p.w8)) tile = 256;
   if (p.w8) tile = 256;  // fp8 operands: only the 256x256 ping-pong / stream-K kernels exist (build_params checked vec_ok)
   if (tile == 256 && p.vec_ok && sk_mode(p) != 0) {   // (the plain reference loop / experimental kernels skip the stream-K paths)
@@ -1756,8 +1714,6 @@ static int dispatch(GemmParams& p, hipStream_t stream) {
   if (tile == 257) return launch_gemm<256, 256, 4, 2, true>(p, stream);  // plain loop (bit-exact reference)
   if (tile == 260) return launch_gemm_w4m16(p, stream);                   // one wave per SIMD, 128 x 128 wave tiles
   if (tile == 261) return launch_gemm_w4b(p, stream);                     // ... with three half-stage barriers per K-tile
-  if (tile == 262) return launch_gemm_pp(p, stream, true);                // the 8-wave loop + weight-panel touches
-  if (tile == 263) return launch_gemm_w4b(p, stream, true);               // W4B + weight-panel touches
   // (AUTO never picks RF_SCHED_W4B: with warm operands it is 0..4 % ahead of the 8-wave loop on plain-store launches and 8 % on the
   //  K = 15360 single-block projection, but inside the 57-block sequence, where every weight panel arrives HBM-cold, the same
   //  launches are 0.5..10 % SLOWER -- one wave per SIMD has nothing to run while a late LDS-DMA piece holds barrier 3;

@@ -23,7 +23,11 @@
 // check returns zeros for them.
 #pragma once
 
-// (RF_MAKE_RSRC_N: common.hpp)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RF_MAKE_RSRC_N(p, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(p), 0, (int)(bytes), 0x00020000)
+#else
+#define RF_MAKE_RSRC_N(p, bytes) 0
+#endif
 
 __device__ __forceinline__ void gemm_mainloop_w4m16(const GemmGroupDev& G, const int N, const int m0, const int n0, const int nk,
                                                     f32x4 (&acc)[8][8], char* smem, const int w, const int lane) {

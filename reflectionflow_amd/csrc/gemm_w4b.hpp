@@ -57,12 +57,6 @@ constexpr W4bPlan w4b_plan() {
   return p;
 }
 
-// PFD > 0 (round 6): the weight-panel touch of gemm_mainloop_pp3_m16 -- each of the 4 waves touches one dword of its 64 W rows of K-tile
-// (t + 2 + PFD) right behind barrier 3 (slot 94), a 4-byte LDS-DMA into a scratch nobody reads.  It is OLDER than the four pieces issued
-// behind it in that tile and than the twelve of the next tile in front of barrier 3, so `vmcnt(12)` there still means what it meant, and
-// the touch has a whole K-tile to come back.  This loop needs it most: one wave per SIMD has nothing to run while an HBM-cold piece
-// holds barrier 3 (profiles/r05_gemm_w4b.md section 5: 3-11 % cold vs warm).
-template <int PFD = 0>
 __device__ __forceinline__ void gemm_mainloop_w4b(const GemmGroupDev& G, const int N, const int m0, const int n0, const int nk,
                                                   f32x4 (&acc)[8][8], char* smem, const int w, const int lane) {
   constexpr int PIECE = 1024 + 32;   // one wave piece (8 rows x 128 B) + padding: 66 sixteen-byte slots, = 2 (mod 16)
@@ -76,7 +70,7 @@ __device__ __forceinline__ void gemm_mainloop_w4b(const GemmGroupDev& G, const i
   // LDS-DMA geometry: piece j (0..7) of wave w is wave piece 4 j + w of an image = rows 32 j + 8 w + lane / 8, chunk lane % 8
   const int r8 = lane >> 3;
   const uint32_t chunk_b = (uint32_t)((lane & 7) * 16);
-  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t voA, voB, stA, stB, pf; };
+  struct Cur { int seg, kk, nk; rsrc_t A, W; uint32_t voA, voB, stA, stB; };
   auto load_seg = [&](Cur& c) {
     const KSegDev& S = G.seg[c.seg];
     const uint32_t lda2 = (uint32_t)(S.lda * 2), ldw2 = (uint32_t)(S.ldw * 2);
@@ -87,10 +81,6 @@ __device__ __forceinline__ void gemm_mainloop_w4b(const GemmGroupDev& G, const i
     c.voB = (uint32_t)(n0 + 8 * w + r8) * ldw2 + chunk_b;
     c.stA = 32 * lda2;
     c.stB = 32 * ldw2;
-    if constexpr (PFD > 0) {
-      const int gp = n0 + 64 * w + lane;
-      c.pf = (uint32_t)(gp < N ? gp : N - 1) * ldw2;
-    }
   };
   auto next = [&](Cur& c) {
     ++c.kk;
@@ -162,7 +152,6 @@ __device__ __forceinline__ void gemm_mainloop_w4b(const GemmGroupDev& G, const i
     else if constexpr (r_ >= 16 && r_ < 24 && NEXT) B0[r_ & 7] = *(const bf16x8*)(oth + fb0 + (r_ & 7) * 128); \
     else if constexpr (r_ >= 24 && NEXT) A0[r_ & 7] = *(const bf16x8*)(oth + fa0 + (r_ & 7) * 128);         \
     if constexpr (DMA && d_ >= 0) piece(c, dstage, d_ & 15);                                                 \
-    if constexpr (DMA && PFD > 0 && (m) == 94) RF_BUF_LOAD_LDS4(c.W, (lds_void*)(smem + PP_PF_SCRATCH + w * 256), c.pf, (c.kk + PFD) * 128); \
     if constexpr ((m) < 64) RF_W4B_MFMA(acc[((m) >> 3) & 7][(m) & 7], A0[((m) >> 3) & 7], B0[(m) & 7]);      \
     else RF_W4B_MFMA(acc[((m) >> 3) & 7][(m) & 7], A1[((m) >> 3) & 7], B1[(m) & 7]);                         \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -345,7 +334,6 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
 
 // (no packed-fp32 VALU ops in this kernel either: its register-direct epilogue runs the RMSNorm + RoPE arithmetic that misbehaved
 //  in the 128 x 128 kernel, see gemm_bf16_kernel, and the guide prices packed f32 beside MFMAs as an anti-lever anyway)
-template <int PFD>
 RF_NO_PACKED_FP32 __global__ __launch_bounds__(256) void gemm_bf16_w4b_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   ClkProbe clk;
@@ -364,7 +352,7 @@ RF_NO_PACKED_FP32 __global__ __launch_bounds__(256) void gemm_bf16_w4b_kernel(co
   const int m0 = tm * 256, n0 = tn * 256;
   const int nk = G.seg[0].nk + G.seg[1].nk + G.seg[2].nk;
   f32x4 acc[8][8];
-  gemm_mainloop_w4b<PFD>(G, p.N, m0, n0, nk, acc, smem, w, lane);
+  gemm_mainloop_w4b(G, p.N, m0, n0, nk, acc, smem, w, lane);
   if (p.probe) clk.end(g_clk_probe);
   gemm_epilogue_direct(p, G, acc, m0, n0, (w >> 1) * 128, (w & 1) * 128, lane);
 }

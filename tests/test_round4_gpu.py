@@ -25,15 +25,10 @@ def _both(fn):
     gives the W4 result bit for bit too"""
     from reflectionflow_amd import _lib as L, ops
     outs = []
-    for sched in (L.RF_SCHED_TILE256, L.RF_SCHED_W4, L.RF_SCHED_W4B, L.RF_SCHED_TILE256_PF, L.RF_SCHED_W4B_PF):
+    for sched in (L.RF_SCHED_TILE256, L.RF_SCHED_W4, L.RF_SCHED_W4B):
         with ops.gemm_schedule(sched):
             outs.append(fn())
     assert torch.equal(outs[1], outs[2]), "W4B and W4 disagree"
-    # round 6: the weight-panel touches (a 4-byte LDS-DMA per wave and K-tile into a scratch nobody reads, one more entry in the counted
-    # VMEM queue) must not change a bit -- on ragged N (clamped rows, bounds-checked resource), K of 1-16 tiles (touches past the
-    # segment's end), several K-segments and token groups
-    assert torch.equal(outs[3], outs[0]), "TILE256_PF and TILE256 disagree"
-    assert torch.equal(outs[4], outs[2]), "W4B_PF and W4B disagree"
     return outs[:2]
 
 

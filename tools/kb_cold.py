@@ -8,9 +8,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 r = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)   # noqa
 flush_src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
 flush_dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-SCHED = {"t256": L.RF_SCHED_TILE256, "t256_pf": L.RF_SCHED_TILE256_PF, "w4b": L.RF_SCHED_W4B, "w4b_pf": L.RF_SCHED_W4B_PF}
-for name, M, N, K in (("sgl_out", 4608, 3072, 15360), ("dbl_ff2", 4608, 3072, 12288), ("sgl_in", 4608, 21504, 3072), ("dbl_ff1", 4608, 12288, 3072),
-                      ("dbl_qkv", 4608, 9216, 3072), ("dbl_out", 4608, 3072, 3072)):
+SCHED = {"t256": L.RF_SCHED_TILE256, "w4b": L.RF_SCHED_W4B}
+for name, M, N, K in (("sgl_out", 4608, 3072, 15360), ("dbl_ff2", 4608, 3072, 12288), ("sgl_in", 4608, 21504, 3072), ("dbl_ff1", 4608, 12288, 3072)):
     x, W, b = r(M, K), r(N, K, sc=0.02), r(N)
     out = torch.empty(M, N, dtype=BF, device=dev)
     grp = [ops.Group([ops.Seg(x, W)], bias=b, out=out)]

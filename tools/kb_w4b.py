@@ -19,7 +19,7 @@ BF = torch.bfloat16
 g = torch.Generator(device=dev).manual_seed(0)
 r = lambda *s, sc=1.0: (torch.randn(*s, generator=g, device=dev) * sc).to(BF)   # noqa
 SCHED = {"auto": L.RF_SCHED_AUTO, "t256": L.RF_SCHED_TILE256, "w4": L.RF_SCHED_W4, "w4b": L.RF_SCHED_W4B, "sk": L.RF_SCHED_STREAMK,
-         "persist": L.RF_SCHED_PERSISTENT, "t256_pf": L.RF_SCHED_TILE256_PF, "w4b_pf": L.RF_SCHED_W4B_PF}
+         "persist": L.RF_SCHED_PERSISTENT}
 shapes = [("dbl_qkv", 4608, 9216, 3072), ("dbl_out", 4608, 3072, 3072), ("dbl_ff1", 4608, 12288, 3072), ("dbl_ff2", 4608, 3072, 12288),
           ("sgl_in", 4608, 21504, 3072), ("sgl_out", 4608, 3072, 15360), ("sq8192", 8192, 8192, 8192)]
 res = {}
@@ -38,7 +38,7 @@ for name, M, N, K in shapes:
                 o = out.clone()
                 if ref is None:
                     ref = o
-                elif sname in ("w4", "w4b", "t256", "sk", "persist", "t256_pf", "w4b_pf"):
+                elif sname in ("w4", "w4b", "t256", "sk", "persist"):
                     row[sname + "_bit_equal_to_first"] = bool(torch.equal(o, ref))
         # hipBLASLt
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
