@@ -895,6 +895,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world_size}")
     backend = torch.distributed.get_backend() if shard.world_size > 1 else None
     dev = torch.device("cuda", local)
+    numa = search.bind_host_threads_to_gpu_numa_node(local) if shard.world_size > 1 else None
+    ranks = search.describe_ranks(shard, local, numa)       # (a collective: every rank calls it)
 
     cfg = dict(num_layers=2, num_single_layers=2) if args.small else {}
     pipe = build_model(dev, cfg, seed=0)
@@ -1058,7 +1060,9 @@ def main():
             "timed_latent_parity": parity,
             "per_rank": per_rank,
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "dist": {"backend": backend, "ranks_share_gpu": bool(args.ranks_share_gpu)} if shard.world_size > 1 else None,
+            # N > 1: the world size as the BACKEND reports it, the collective library's version and every rank's device (name, PCI bus id,
+            # uuid, host) -- what proves that N ranks on N devices produced this line; host threads pinned to the GPU's NUMA node
+            "dist": dict(ranks, ranks_share_gpu=bool(args.ranks_share_gpu)) if shard.world_size > 1 else None,
         }
         if args.ranks_share_gpu:
             res["INVALID"] = "rehearsal: all ranks on one GPU (plumbing check, not a scaling measurement)"

@@ -30,6 +30,9 @@ def parse_cli_args(argv=None):
     p.add_argument("--meta_path", type=str, default="meta.jsonl")
     p.add_argument("--synthetic", action="store_true", help="random-init FLUX.1-dev-shaped weights (no checkpoint offline)")
     p.add_argument("--small", action="store_true", help="with --synthetic: 2+2-block model for plumbing tests")
+    p.add_argument("--dist_backend", choices=["nccl", "gloo"], default=None, help="process-group backend for WORLD_SIZE > 1 (default: nccl = RCCL)")
+    p.add_argument("--ranks_share_gpu", action="store_true",
+                   help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --dist_backend gloo: RCCL refuses two ranks on one device)")
     return p.parse_args(argv)
 
 
@@ -41,9 +44,14 @@ def main(mode: str, argv=None):
     with open(args.pipeline_config_path) as f:
         config = json.load(f)
     config.update(vars(args))
-    shard = search.init_distributed()
+    if args.ranks_share_gpu:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.dist_backend != "gloo":
+            raise SystemExit("--ranks_share_gpu needs --dist_backend gloo (RCCL refuses two ranks on one device)")
+        os.environ["LOCAL_RANK"] = "0"                # init_distributed() binds the rank to cuda:LOCAL_RANK for nccl
+    shard = search.init_distributed(args.dist_backend)
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    search.bind_host_threads_to_gpu_numa_node(dev.index)
     pipe = runner.build_pipeline(config, dev, synthetic=args.synthetic, small=args.small)
     os.makedirs(args.output_dir, exist_ok=True)
     if mode == "reflection" and args.imgpath:

@@ -54,6 +54,76 @@ def init_distributed(backend: Optional[str] = None) -> Shard:
     return Shard(rank, world)
 
 
+def gpu_numa_node(index: int) -> Optional[int]:
+    """NUMA node of GPU `index` from sysfs (its PCI function's `numa_node`), or None when the platform does not say (-1, containers
+    without /sys/bus/pci, CPU-only hosts)."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            n = int(f.read().strip())
+        return n if n >= 0 else None
+    except Exception:
+        return None
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_host_threads_to_gpu_numa_node(index: int) -> Dict[str, object]:
+    """One process per GPU: pin this rank's host threads to the CPUs of its GPU's NUMA node (8 ranks of a node otherwise enqueue
+    15 000 launches per candidate from wherever the scheduler put them, across the socket interconnect).  Only narrows the current
+    affinity mask (a launcher's / container's own restriction is kept); a platform that does not expose the node is left alone.
+    Returns what was done, for the bench line's `dist.per_rank`."""
+    info: Dict[str, object] = {"numa_node": None, "cpus_bound": None}
+    node = gpu_numa_node(index)
+    if node is None or not hasattr(os, "sched_setaffinity"):
+        return info
+    try:
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            want = set(_parse_cpulist(f.read()))
+        now = set(os.sched_getaffinity(0))
+        cpus = sorted(want & now)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info.update(numa_node=node, cpus_bound=len(cpus))
+    except Exception:
+        pass
+    return info
+
+
+def describe_ranks(shard: "Shard", device_index: int, numa: Optional[Dict[str, object]] = None) -> Optional[dict]:
+    """What an N > 1 line must carry so that a reader can PROVE N ranks on N devices ran it: the world size the backend itself
+    reports, the collective library's version, and per rank {device index, name, PCI bus id, uuid, host, NUMA binding}."""
+    if shard.world_size == 1:
+        return None
+    import socket
+    mine = {"rank": shard.rank, "device_index": device_index, "device_name": None, "gcn_arch": None, "pci": None, "uuid": None,
+            "host": socket.gethostname(), "pid": os.getpid(), **(numa or {})}
+    if torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(device_index)
+        mine.update(device_name=pr.name, gcn_arch=getattr(pr, "gcnArchName", None), uuid=str(getattr(pr, "uuid", "")),
+                    pci=f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}")
+    every: List[Optional[dict]] = [None] * shard.world_size
+    dist.all_gather_object(every, mine)
+    backend = dist.get_backend()
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+    return {"backend": backend, "world_size_seen_by_backend": dist.get_world_size(), "rccl_version": ver,
+            "distinct_devices": len({(r["host"], r["pci"]) for r in every}), "per_rank": every}
+
+
 def _collective_device(device=None):
     if device is not None:
         return torch.device(device)

@@ -295,3 +295,39 @@ def test_noise_scaling_cfg3_round_of_32_on_one_rank_feeds_the_reflection_driver(
     pools = runner.read_imgpath(out2)
     assert len(pools) == 1 and pools[0]["metadata"][0]["prompt"] == "four cats"
     assert [os.path.basename(p) for p in pools[0]["images"]] == sorted(f"1_round@{s}.png" for s in runner.candidate_seeds(0, 1, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_cfg3_shape_eight_ranks_share_the_gpu_through_the_cli(tmp_path):
+    """BASELINE cfg3's round, N = 32 candidates -> 4 per rank on 8 ranks, launched the way the 8-GPU node launches it
+    (`torch.distributed.run --nproc-per-node 8 -m reflectionflow_amd.tts.tts_t2i_noise_scaling`), here with all ranks on the one GPU
+    there is (`--ranks_share_gpu --dist_backend gloo --synthetic --small`): the tree is complete, has the reference's names, and
+    every candidate is BIT-EQUAL to the one a single rank generates for that seed (results do not depend on the world size)."""
+    import subprocess
+    import sys
+    cfg = _small_cfg(N=32, R=1, size=256, steps=2)
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg))
+    (tmp_path / "meta.jsonl").write_text(json.dumps({"prompt": "thirty-two cats", "tag": "counting"}) + "\n")
+    out = str(tmp_path / "out8")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(HERE)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "reflectionflow_amd.tts.tts_t2i_noise_scaling", "--pipeline_config_path", str(tmp_path / "cfg.json"),
+           "--meta_path", str(tmp_path / "meta.jsonl"), "--output_dir", out, "--synthetic", "--small", "--dist_backend", "gloo", "--ranks_share_gpu"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    seeds = runner.candidate_seeds(0, 1, 32)
+    files = sorted(os.listdir(os.path.join(out, "00000", "samples")))
+    assert files == sorted(f"1_round@{s}.pt" for s in seeds)
+    assert open(os.path.join(out, "00000", "metadata.jsonl")).read() == json.dumps({"prompt": "thirty-two cats", "tag": "counting"})
+    # the same round on ONE rank in this process
+    dev = torch.device("cuda", 0)
+    pipe = runner.build_pipeline(cfg, dev, synthetic=True, small=True)
+    out1 = str(tmp_path / "out1")
+    runner.run_noise_scaling(cfg, ["thirty-two cats"], out1, pipe, search.Shard(0, 1))
+    for f in files:
+        a, b = torch.load(os.path.join(out, "00000", "samples", f)), torch.load(os.path.join(out1, "00000", "samples", f))
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), f

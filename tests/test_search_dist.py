@@ -209,3 +209,66 @@ def test_round_boundary_serial_section_is_within_budget():
     budget = 0.02 * 3.1          # 2 % of a cfg2 candidate's denoise
     print(f"round boundary (stub verifier, gloo, 2 ranks, 8 candidates, topk 8): {1e3 * max(t0, t1):.2f} ms (budget {1e3 * budget:.0f} ms)")
     assert max(t0, t1) < budget
+
+
+# ------------------------------------------------------------------------------------------------ round 6: what an N > 1 line must prove
+def _describe_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    shard = search.init_distributed("gloo")
+    info = search.describe_ranks(shard, 0, {"numa_node": None, "cpus_bound": None})
+    q.put((rank, info))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_describe_ranks_reports_the_world_the_backend_sees():
+    """bench.py's `dist` block for N > 1: the world size as the BACKEND reports it, one record per rank (rank,
+    device, host, pid), identical on every rank; None at world size 1."""
+    assert search.describe_ranks(search.Shard(0, 1), 0) is None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_describe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    d = got[0]
+    assert d["backend"] == "gloo" and d["world_size_seen_by_backend"] == 2 and d["rccl_version"] is None
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and len({r["pid"] for r in d["per_rank"]}) == 2
+    assert all(set(r) >= {"device_index", "device_name", "pci", "uuid", "host", "numa_node", "cpus_bound"} for r in d["per_rank"])
+
+
+def test_numa_binding_narrows_the_affinity_mask_only(monkeypatch, tmp_path):
+    """`bind_host_threads_to_gpu_numa_node`: cpulist parsing, intersection with the CURRENT mask (a launcher's restriction survives), no-op
+    when the platform does not expose the node."""
+    assert search._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and search._parse_cpulist("") == []
+    assert set(search.bind_host_threads_to_gpu_numa_node(0)) == {"numa_node", "cpus_bound"}       # whatever this host says: no crash
+    have = sorted(os.sched_getaffinity(0))
+    monkeypatch.setattr(search, "gpu_numa_node", lambda i: 1)
+    real_open = open
+    listed = f"{have[0]}-{have[min(1, len(have) - 1)]},4000-4003"          # two CPUs we have + four this process may not use
+
+    def fake_open(path, *a, **k):
+        if str(path) == "/sys/devices/system/node/node1/cpulist":
+            p = tmp_path / "cpulist"
+            p.write_text(listed + "\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+    import builtins
+    monkeypatch.setattr(builtins, "open", fake_open)
+    try:
+        info = search.bind_host_threads_to_gpu_numa_node(0)
+        assert info == {"numa_node": 1, "cpus_bound": len(set(have[:2]))}
+        assert sorted(os.sched_getaffinity(0)) == sorted(set(have[:2]))
+    finally:
+        os.sched_setaffinity(0, have)
+    monkeypatch.setattr(search, "gpu_numa_node", lambda i: None)
+    assert search.bind_host_threads_to_gpu_numa_node(0) == {"numa_node": None, "cpus_bound": None}
+    assert sorted(os.sched_getaffinity(0)) == have
