@@ -300,20 +300,33 @@ def clock_probe(which):
 
 
 def pmc_traffic(S_txt, S_img, D, mlp):
-    """HBM/fabric bytes per launch cannot be measured from inside this process: they come from the committed
-    rocprofv3 --pmc passes over the same launches (tools/pmc_collect.sh -> profiles/rNN_pmc_kernels.json,
-    FETCH_SIZE doubled per the gfx950 correction), forward-weighted like `achieved`.  Newest round wins."""
+    """Fabric bytes per launch cannot be measured from inside this process: they come from the committed rocprofv3 --pmc passes over the
+    same launches (tools/pmc_collect.sh -> profiles/rNN_pmc_kernels.json, FETCH_SIZE doubled per the gfx950 correction),
+    forward-weighted like `achieved`.  Newest round wins.  The file carries the git sha it was measured at and a hash of the kernel
+    source: when csrc/gemm_bf16.hip has changed since, the number is REFUSED (traffic = None, `stale` says why) instead of being
+    reported for a kernel it was not measured on.
+    What the counter is: L2 <-> fabric requests INCLUDING Infinity-Cache hits (MI355X_MICROARCH.md, 'HBM'), i.e. L2-fill traffic -- an
+    upper bound on HBM bytes, not HBM bytes; a launch's operands (<= 235 MB) fit the 256 MiB Infinity Cache."""
     if (S_txt, S_img, D, mlp) != (512, 4096, 3072, 12288):
-        return None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        return None, None, None
+    import hashlib
+    cur = hashlib.sha256(open(os.path.join(ROOT, "reflectionflow_amd", "csrc", "gemm_bf16.hip"), "rb").read()).hexdigest()[:16]
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_kernels.json")
         if os.path.exists(pmc):
             pj = json.load(open(pmc))["_summary"]
-            src = (f"profiles/{rnd}_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; algorithmic "
-                   f"{round(pj['gemm_algorithmic_bytes_per_launch_avg'])} B/launch; MFMA busy "
+            at = pj.get("measured_at") or {}
+            stamp = {"file": f"profiles/{rnd}_pmc_kernels.json", "git_sha": at.get("git_sha"),
+                     "kernel_source_unchanged_since": at.get("gemm_bf16_hip_sha256_16") == cur}
+            if not stamp["kernel_source_unchanged_since"]:
+                stamp["stale"] = ("csrc/gemm_bf16.hip differs from the source these passes measured (or the file carries no stamp): "
+                                  "re-run tools/pmc_collect.sh")
+                return None, None, stamp
+            src = (f"profiles/{rnd}_pmc_kernels.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE = L2 <-> fabric bytes incl. Infinity-Cache hits; "
+                   f"algorithmic {round(pj['gemm_algorithmic_bytes_per_launch_avg'])} B/launch; MFMA busy "
                    f"{pj['gemm_mfma_busy_pct_weighted']:.1f} % of SIMD-cycles at the sustained clock)")
-            return round(pj["gemm_traffic_bytes_per_launch_avg"]), src
-    return None, None
+            return round(pj["gemm_traffic_bytes_per_launch_avg"]), src, stamp
+    return None, None, None
 
 
 def in_sequence_roofline(one_latent_steps, T_prof, ms_per_forward_timed, dims):
@@ -344,7 +357,7 @@ def in_sequence_roofline(one_latent_steps, T_prof, ms_per_forward_timed, dims):
         per_fwd["rowop"]["GBps"] = round(cl["rowop"]["work"] / (cl["rowop"]["us"] * 1e-6) / 1e9, 1)
     per_fwd["gemm_main"]["tflops"] = round(ach, 1)
     sum_ms = sum(v["us"] for v in cl.values()) / T_prof / 1e3
-    traffic, traffic_src = pmc_traffic(*dims)
+    traffic, traffic_src, traffic_stamp = pmc_traffic(*dims)
     sustained = None
     if clk_gemm:
         # MI355X throttles under dense MFMA + LDS + L2 traffic: `frac` is against the 2.4 GHz peak as the contract
@@ -358,7 +371,7 @@ def in_sequence_roofline(one_latent_steps, T_prof, ms_per_forward_timed, dims):
             "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4), "sustained_clock": sustained,
             "traffic": traffic, "traffic_unit": "bytes/launch",
-            "traffic_source": traffic_src,
+            "traffic_source": traffic_src, "traffic_measured_at": traffic_stamp,
             "method": f"one hipEvent in front of every launch inside {T_prof} real forwards, duration = event-to-event "
                       "(kernel + the gap behind it; rf_profile_begin/_end), run right after the timed region in the "
                       "same process on the same box",

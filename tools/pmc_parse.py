@@ -63,6 +63,14 @@ summary = dict(gemm_traffic_bytes_per_launch_avg=sum(v['launches_per_forward'] *
                gemm_algorithmic_bytes_per_launch_avg=sum(v['launches_per_forward'] * v['algorithmic_bytes'] for v in gem) / tot_n,
                gemm_mfma_busy_pct_weighted=sum(v['launches_per_forward'] * v['us_profiled'] * v['mfma_busy_pct'] for v in gem) /
                sum(v['launches_per_forward'] * v['us_profiled'] for v in gem))
+# stamp: which kernel source these passes measured (bench.py refuses `roofline.traffic` when csrc/gemm_bf16.hip has changed since)
+import hashlib, subprocess
+try:
+    git_sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or os.environ.get("RF_GIT_SHA", "")
+except Exception:
+    git_sha = os.environ.get("RF_GIT_SHA", "")
+summary["measured_at"] = {"git_sha": git_sha or None,
+                          "gemm_bf16_hip_sha256_16": hashlib.sha256(open(os.path.join(ROOT, "reflectionflow_amd/csrc/gemm_bf16.hip"), "rb").read()).hexdigest()[:16]}
 out['_summary'] = summary
 md += ["", f"GEMM kernel, forward-weighted: traffic {summary['gemm_traffic_bytes_per_launch_avg']/1e6:.0f} MB/launch vs algorithmic "
            f"{summary['gemm_algorithmic_bytes_per_launch_avg']/1e6:.0f} MB/launch; MFMA pipe busy {summary['gemm_mfma_busy_pct_weighted']:.1f} % of SIMD-cycles "
