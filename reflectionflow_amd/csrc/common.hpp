@@ -146,4 +146,11 @@ struct ClkProbe {
 int read_clk_probe_gemm(unsigned long long* h);   // gemm_bf16.hip
 int read_clk_probe_attn(unsigned long long* h);   // attention.hip
 
+// LayerNorm + modulate of up to three token streams (text / image / condition) in ONE launch (rowops.hip; the engine's AdaLN stages).
+// Row for row the arithmetic of rf_layernorm_modulate: bit-identical outputs.
+struct LnModStream {
+  const bf16_t* x; bf16_t* out; const bf16_t* scale; const bf16_t* shift; int rows;
+};
+int ln_mod_grouped(const LnModStream* streams, int n, int64_t ldx, int64_t ldo, int D, float eps, hipStream_t stream);
+
 }  // namespace rf

@@ -178,6 +178,8 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
   };
   // LayerNorm + modulate of every stream with (scale, shift) = mod rows (r_scale, r_shift)
   auto ln_mod = [&](int r_scale, int r_shift) -> int {
+    LnModStream bf[3];
+    int nbf = 0;
     for (int i = 0; i < 3; ++i) {
       const Stream& s = sx[i];
       if (s.rows <= 0) continue;
@@ -185,10 +187,9 @@ extern "C" int rf_double_block_fwd(const rf_flux_dims* dims, const rf_double_blo
         RF_TRY(rf_layernorm_modulate_fp8(s.x, ldx, XN8 + (int64_t)s.off * D, D, sXN + s.off, s.rows, D, s.mod + r_scale * D,
                                          s.mod + r_shift * D, 1e-6f, st));
       else
-        RF_TRY(rf_layernorm_modulate(s.x, ldx, XN + (int64_t)s.off * D, D, s.rows, D, s.mod + r_scale * D, s.mod + r_shift * D,
-                                     1e-6f, st));
+        bf[nbf++] = LnModStream{s.x, XN + (int64_t)s.off * D, s.mod + r_scale * D, s.mod + r_shift * D, s.rows};
     }
-    return RF_OK;
+    return ln_mod_grouped(bf, nbf, ldx, D, D, 1e-6f, st);   // every bf16 stream in ONE launch (row for row rf_layernorm_modulate)
   };
   // per-token fp8 copy of the rows [off, off+rows) of a bf16 [S][K] buffer into A8 (leading dimension K)
   auto quant_rows = [&](const bf16_t* src, int K) -> int {
@@ -381,14 +382,19 @@ extern "C" int rf_single_block_fwd(const rf_flux_dims* dims, const rf_single_blo
   };
 
   // 1. AdaLN-Zero-Single: mod rows 0 shift, 1 scale, 2 gate
-  for (int i = 0; i < 2; ++i) {
-    const Stream& s = sx[i];
-    if (s.rows <= 0) continue;
-    if (use8[i])
-      RF_TRY(rf_layernorm_modulate_fp8(s.x, ldx, XN8 + (int64_t)s.off * D, D, sXN + s.off, s.rows, D, s.mod + 1 * D, s.mod + 0 * D,
-                                       1e-6f, st));
-    else
-      RF_TRY(rf_layernorm_modulate(s.x, ldx, XN + (int64_t)s.off * D, D, s.rows, D, s.mod + 1 * D, s.mod + 0 * D, 1e-6f, st));
+  {
+    LnModStream bf[2];
+    int nbf = 0;
+    for (int i = 0; i < 2; ++i) {
+      const Stream& s = sx[i];
+      if (s.rows <= 0) continue;
+      if (use8[i])
+        RF_TRY(rf_layernorm_modulate_fp8(s.x, ldx, XN8 + (int64_t)s.off * D, D, sXN + s.off, s.rows, D, s.mod + 1 * D, s.mod + 0 * D,
+                                         1e-6f, st));
+      else
+        bf[nbf++] = LnModStream{s.x, XN + (int64_t)s.off * D, s.mod + 1 * D, s.mod + 0 * D, s.rows};
+    }
+    RF_TRY(ln_mod_grouped(bf, nbf, ldx, D, D, 1e-6f, st));
   }
   // 2. fused [to_q|to_k|to_v|proj_mlp]: QKV head-major, MLP branch through GELU(tanh) into HID
   {

@@ -68,6 +68,100 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// The same row kernel over up to three streams in one launch: block b serves the stream whose 4-row-block prefix covers it (a text
+// stream of 512 rows is a 4 us launch of its own otherwise, plus the launch boundary: 38 of them per cfg2 forward).
+struct LnModGroup {
+  LnModStream s[3];
+  int blk_end[3];   // exclusive prefix of 4-row blocks
+  int n;
+};
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_mod_grouped_kernel(const LnModGroup g, int64_t ldx, int64_t ldo, int D, float eps) {
+  int gi = 0;
+  if (g.n > 1 && (int)blockIdx.x >= g.blk_end[0]) gi = 1;
+  if (g.n > 2 && (int)blockIdx.x >= g.blk_end[1]) gi = 2;
+  const LnModStream& S = g.s[gi];
+  const int b0 = gi == 0 ? 0 : g.blk_end[gi - 1];
+  const int lane = threadIdx.x & 63;
+  const int row = ((int)blockIdx.x - b0) * 4 + (threadIdx.x >> 6);
+  if (row >= S.rows) return;
+  const bf16_t* xr = S.x + (int64_t)row * ldx;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      const u32x4 raw = *(const u32x4*)(xr + col);
+      unpack8(raw, v[c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float dlt = v[c][j] - mean;
+        q += dlt * dlt;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  bf16_t* orow = S.out + (int64_t)row * ldo;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < D) {
+      float sc[8], sh[8], o[8];
+      unpack8(*(const u32x4*)(S.scale + col), sc);
+      unpack8(*(const u32x4*)(S.shift + col), sh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * (1.0f + sc[j]) + sh[j];
+      *(u32x4*)(orow + col) = pack8(o);
+    }
+  }
+}
+
+int ln_mod_grouped(const LnModStream* streams, int n, int64_t ldx, int64_t ldo, int D, float eps, hipStream_t stream) {
+  LnModGroup g;
+  g.n = 0;
+  int blocks = 0;
+  double bytes = 0.0;
+  for (int i = 0; i < n && g.n < 3; ++i) {
+    if (streams[i].rows <= 0) continue;
+    RF_REQUIRE(streams[i].x && streams[i].out && streams[i].scale && streams[i].shift, RF_ERR_NULL, "ln_mod_grouped: NULL pointer");
+    RF_REQUIRE(aligned16(streams[i].x) && aligned16(streams[i].out) && aligned16(streams[i].scale) && aligned16(streams[i].shift),
+               RF_ERR_ALIGN, "ln_mod_grouped: operands must be 16-byte aligned");
+    g.s[g.n] = streams[i];
+    blocks += cdiv(streams[i].rows, 4);
+    g.blk_end[g.n] = blocks;
+    bytes += 4.0 * streams[i].rows * (double)D;
+    ++g.n;
+  }
+  if (g.n == 0) return RF_OK;
+  RF_REQUIRE(D > 0 && D % 8 == 0 && D <= 8 * 512 && ldx % 8 == 0 && ldo % 8 == 0, RF_ERR_SHAPE, "ln_mod_grouped: D=%d", D);
+  for (int i = g.n; i < 3; ++i) g.s[i] = g.s[0], g.blk_end[i] = blocks;
+  ProfScope prof(RF_KC_ROWOP, bytes, stream);
+  const int nch = cdiv(D, 512);
+#define RF_LNG_CASE(N) \
+  case N: hipLaunchKernelGGL(ln_mod_grouped_kernel<N>, dim3(blocks), dim3(256), 0, stream, g, ldx, ldo, D, eps); break;
+  switch (nch) {
+    RF_LNG_CASE(1) RF_LNG_CASE(2) RF_LNG_CASE(3) RF_LNG_CASE(4) RF_LNG_CASE(5) RF_LNG_CASE(6) RF_LNG_CASE(7) RF_LNG_CASE(8)
+    default: RF_REQUIRE(false, RF_ERR_SHAPE, "ln_mod_grouped: D too large");
+  }
+#undef RF_LNG_CASE
+  RF_LAUNCH_CHECK();
+  return RF_OK;
+}
+
 // ---- per-head RMSNorm(q,k) + RoPE, in place on [heads][s_pad][128] ------------------------------
 // 16 lanes x 8 elements cover one 128-wide head row; a wave handles 4 rows per iteration.
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(bf16_t* __restrict__ q, bf16_t* __restrict__ k,
