@@ -126,6 +126,7 @@ class FluxTrainer:
         self.eng = E.engine_for(transformer)
         self.latent_lora = bool(self.cfg.get("latent_lora", False))
         self.optimizer = None
+        self._auto_fell_back = False                        # "auto" ran out of memory once: every block re-computes from then on
 
     def configure_optimizers(self, optimizer_config: Optional[dict] = None, state_dtype: torch.dtype = BF):
         """train/model.py:94-117 (`configure_optimizers`): the optimizer over the LoRA factors, built from the reference's
@@ -153,6 +154,26 @@ class FluxTrainer:
         draws of t and x_1 are made for the whole batch first, exactly as step() makes them."""
         if self.optimizer is None:
             raise ops.RFError("FluxTrainer.training_step: call configure_optimizers() first")
+        opt = self.optimizer
+        if self.gradient_checkpointing == "auto" and not self._auto_fell_back:
+            # "auto" sizes what it keeps from a per-block cost model against the free HBM; if the model is wrong for this geometry (or
+            # another process took the memory) the step must not die: ONE retry with the reference's recompute for every block, which
+            # then stays on for this trainer (ADVICE r5).  The draws are made before the attempt so that both attempts see the same batch.
+            batch = dict(batch)
+            with torch.no_grad():
+                Bn0 = batch["x_0"].shape[0]
+                if batch.get("t") is None:
+                    batch["t"] = torch.sigmoid(torch.randn((Bn0,), device=batch["x_0"].device, generator=generator))
+                if batch.get("x_1") is None:
+                    batch["x_1"] = torch.randn(batch["x_0"].shape, device=batch["x_0"].device, dtype=batch["x_0"].dtype, generator=generator)
+            try:
+                return self._training_step(batch, world_size, group, generator, sample_by_sample)
+            except torch.cuda.OutOfMemoryError:
+                self._auto_fell_back = True
+                torch.cuda.empty_cache()
+        return self._training_step(batch, world_size, group, generator, sample_by_sample)
+
+    def _training_step(self, batch, world_size, group, generator, sample_by_sample) -> torch.Tensor:
         opt = self.optimizer
         opt.zero_grad()
         Bn = batch["x_0"].shape[0]
@@ -271,7 +292,7 @@ class FluxTrainer:
         cost_d = 2 * S_all * (24 * D + 2 * mlp)
         cost_s = 2 * S_all * (20 * D + 3 * mlp)
         budget = 0
-        if self.gradient_checkpointing == "auto" and torch.is_grad_enabled():
+        if self.gradient_checkpointing == "auto" and torch.is_grad_enabled() and not self._auto_fell_back:
             free = torch.cuda.mem_get_info(hidden_states.device)[0] + torch.cuda.memory_reserved(hidden_states.device) \
                 - torch.cuda.memory_allocated(hidden_states.device)
             budget = int(0.85 * free) - (16 << 30)

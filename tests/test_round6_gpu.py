@@ -207,3 +207,34 @@ def test_prodigy_with_lr_zero_moves_nothing(dev):
     ds = opt.d_state()
     assert torch.equal(opt.bucket.param, p0) and ds["k"] == 0 and ds["d"] == 1e-6 and ds["d_denom"] == 0.0
     assert float(opt.exp_avg.float().abs().max()) == 0.0 and float(opt.exp_avg_sq.float().abs().max()) == 0.0 and float(opt.s.float().abs().max()) == 0.0
+
+
+def test_auto_checkpointing_falls_back_to_recompute_on_oom(dev):
+    """gradient_checkpointing="auto" keeps what its cost model says fits; when that is wrong the step must not die: an
+    out-of-memory error inside the attempt -> ONE retry with every block re-computing (the reference's flag), which stays on.  The
+    update is bit-equal to a trainer built with gradient_checkpointing=True (the gradients are bit-equal in every mode)."""
+    from reflectionflow_amd.train.step import FluxTrainer
+    oc = {"type": "AdamW", "params": {"lr": 1e-3, "weight_decay": 0.0}}
+    pipe, batch = _hd128(dev)
+    tr = FluxTrainer(pipe.transformer, CFG)
+    opt = tr.configure_optimizers(oc)
+    real, calls = tr.step, []
+
+    def flaky(b, generator=None):
+        calls.append(tr._auto_fell_back)
+        if not tr._auto_fell_back:
+            loss = real(b, generator=generator)          # the attempt allocates, then dies
+            assert tr.kept_blocks > 0
+            raise torch.cuda.OutOfMemoryError("simulated")
+        return real(b, generator=generator)
+    tr.step = flaky
+    loss = tr.training_step(batch, sample_by_sample=False)
+    assert calls == [False, True] and tr._auto_fell_back and tr.kept_blocks == 0 and torch.isfinite(loss.float())
+    got = opt.bucket.param.clone()
+    tr.training_step(batch, sample_by_sample=False)
+    assert calls == [False, True, True] and tr.kept_blocks == 0
+    pipe2, batch2 = _hd128(dev)
+    tr2 = FluxTrainer(pipe2.transformer, CFG, gradient_checkpointing=True)
+    opt2 = tr2.configure_optimizers(oc)
+    tr2.training_step(batch2, sample_by_sample=False)
+    assert torch.equal(got, opt2.bucket.param)
