@@ -127,6 +127,8 @@ class FluxTrainer:
         self.latent_lora = bool(self.cfg.get("latent_lora", False))
         self.optimizer = None
         self._auto_fell_back = False                        # "auto" ran out of memory once: every block re-computes from then on
+        self._keep_plan_frozen: Optional[List[bool]] = None
+        self._last_keep_plan: List[bool] = []
 
     def configure_optimizers(self, optimizer_config: Optional[dict] = None, state_dtype: torch.dtype = BF):
         """train/model.py:94-117 (`configure_optimizers`): the optimizer over the LoRA factors, built from the reference's
@@ -174,6 +176,76 @@ class FluxTrainer:
         return self._training_step(batch, world_size, group, generator, sample_by_sample)
 
     def _training_step(self, batch, world_size, group, generator, sample_by_sample) -> torch.Tensor:
+        loss = self._forward_backward(batch, generator, sample_by_sample)
+        self._reduce_clip_update(world_size, group)
+        return loss.detach()
+
+    def _reduce_clip_update(self, world_size, group) -> None:
+        opt = self.optimizer
+        if world_size > 1:
+            opt.bucket.all_reduce(world_size, group)
+            opt.grad_scale = 1.0 / world_size
+        if self.gradient_clip_val:
+            opt.clip_grad_norm_(self.gradient_clip_val)      # norm of the averaged gradient, on the device
+        opt.step()
+
+    def capture_training_step(self, batch: Dict[str, torch.Tensor], world_size: int = 1, group=None, warmup: int = 2,
+                              sample_by_sample: Optional[bool] = None):
+        """The step as ONE hipGraph: zero_grad + forward + backward of `training_step` (~2700 launches at FLUX size, 230 ms of host
+        enqueue per 270 ms step in eager mode -- GPU-bound, but one slow Python day from host-bound) are captured once and replayed;
+        the tail -- gradient all-reduce (world_size > 1), clip, optimizer update: <= 8 launches whose scalar arguments change per step
+        (AdamW's bias corrections) -- stays eager.  Returns `run(batch) -> loss`: the tensors of `batch` are copied into the captured
+        step's static inputs (same shapes and the same optional keys as the example; without `t` / `x_1` the step draws them inside
+        the graph from the default generator, which hipGraph replay advances), the graph is replayed, the tail runs.
+
+        The warm-up steps run for real on a side stream (workspaces, per-stream scratch, the rope-table cache and, for
+        gradient_checkpointing="auto", the keep-or-recompute plan are fixed there); parameters and optimizer state are restored
+        afterwards, so capturing does not train.  Results are bit-equal to the eager step (tests/test_round6_gpu.py).  The step's
+        activations live in the graph's private pool from then on (what the eager step peaks at)."""
+        if self.optimizer is None:
+            raise ops.RFError("FluxTrainer.capture_training_step: call configure_optimizers() first")
+        opt = self.optimizer
+        static = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+        p0 = opt.bucket.param.detach().clone()
+        sd0 = {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in opt.state_dict().items()}
+
+        def restore():
+            with torch.no_grad():
+                opt.bucket.param.copy_(p0)
+            opt.load_state_dict(sd0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._training_step(static, world_size, group, None, sample_by_sample)
+            torch.cuda.current_stream().synchronize()
+            restore()
+            self._keep_plan_frozen = list(self._last_keep_plan) if self.gradient_checkpointing == "auto" else None
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph, stream=side):
+                    loss = self._forward_backward(static, None, sample_by_sample)
+            finally:
+                self._keep_plan_frozen = None
+        torch.cuda.current_stream().wait_stream(side)
+        tensor_keys = [k for k, v in static.items() if isinstance(v, torch.Tensor)]
+
+        def run(new_batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+            if sorted(k for k, v in new_batch.items() if isinstance(v, torch.Tensor)) != sorted(tensor_keys):
+                raise ops.RFError(f"captured training step: the batch must carry the tensors {sorted(tensor_keys)}")
+            with torch.no_grad():
+                for k in tensor_keys:
+                    if new_batch[k] is not static[k]:
+                        if new_batch[k].shape != static[k].shape:
+                            raise ops.RFError(f"captured training step: {k} has shape {tuple(new_batch[k].shape)}, captured {tuple(static[k].shape)}")
+                        static[k].copy_(new_batch[k])
+            graph.replay()
+            self._reduce_clip_update(world_size, group)
+            return loss.detach()
+        run.graph, run.static_batch = graph, static
+        return run
+
+    def _forward_backward(self, batch, generator, sample_by_sample) -> torch.Tensor:
         opt = self.optimizer
         opt.zero_grad()
         Bn = batch["x_0"].shape[0]
@@ -198,12 +270,6 @@ class FluxTrainer:
         else:
             loss = self.step(batch, generator=generator)
             loss.backward()
-        if world_size > 1:
-            opt.bucket.all_reduce(world_size, group)
-            opt.grad_scale = 1.0 / world_size
-        if self.gradient_clip_val:
-            opt.clip_grad_norm_(self.gradient_clip_val)      # norm of the averaged gradient, on the device; opt.last_clip() reads it back
-        opt.step()
         return loss.detach()
 
     # -------------------------------------------------------------------------------------------------- checkpoints
@@ -292,7 +358,9 @@ class FluxTrainer:
         cost_d = 2 * S_all * (24 * D + 2 * mlp)
         cost_s = 2 * S_all * (20 * D + 3 * mlp)
         budget = 0
-        if self.gradient_checkpointing == "auto" and torch.is_grad_enabled() and not self._auto_fell_back:
+        frozen = self._keep_plan_frozen            # a captured step replays the decisions of its warm-up forward (no driver query in a capture)
+        plan: List[bool] = []
+        if frozen is None and self.gradient_checkpointing == "auto" and torch.is_grad_enabled() and not self._auto_fell_back:
             free = torch.cuda.mem_get_info(hidden_states.device)[0] + torch.cuda.memory_reserved(hidden_states.device) \
                 - torch.cuda.memory_allocated(hidden_states.device)
             budget = int(0.85 * free) - (16 << 30)
@@ -300,7 +368,11 @@ class FluxTrainer:
 
         def opts(cost):
             nonlocal budget
-            keep = torch.is_grad_enabled() and (self.gradient_checkpointing is False or (self.gradient_checkpointing == "auto" and budget >= cost))
+            if frozen is not None:
+                keep = torch.is_grad_enabled() and frozen[len(plan)]
+            else:
+                keep = torch.is_grad_enabled() and (self.gradient_checkpointing is False or (self.gradient_checkpointing == "auto" and budget >= cost))
+            plan.append(bool(keep))
             if keep:
                 budget -= cost
                 self.kept_blocks += 1
@@ -330,6 +402,7 @@ class FluxTrainer:
             scale, shift = m_out[:D], m_out[D:]
             xn = (F.layer_norm(x_img.float(), (D,), eps=1e-6) * (1.0 + scale.float()) + shift.float()).to(dtype)
             outs.append(F.linear(xn, tr.proj_out.weight, tr.proj_out.bias))
+        self._last_keep_plan = plan
         return torch.stack(outs, 0)
 
     # -------------------------------------------------------------------------------------------------- the step

@@ -238,3 +238,53 @@ def test_auto_checkpointing_falls_back_to_recompute_on_oom(dev):
     opt2 = tr2.configure_optimizers(oc)
     tr2.training_step(batch2, sample_by_sample=False)
     assert torch.equal(got, opt2.bucket.param)
+
+
+@pytest.mark.parametrize("kind,mode", [("AdamW", "auto"), ("Prodigy", "auto"), ("AdamW", True)])
+def test_captured_training_step_is_bit_equal_to_the_eager_step(dev, kind, mode):
+    """`FluxTrainer.capture_training_step`: zero_grad + forward + backward as ONE hipGraph, the clip + optimizer tail eager.  Capturing
+    must not train (parameters / optimizer state restored after its warm-up steps), and three replays on three different batches must
+    leave bit-equal parameters, optimizer state and losses to three eager `training_step` calls from the same start -- with AdamW
+    (host-computed bias corrections: the reason the tail stays eager), with Prodigy (device-resident distance estimate), with kept
+    activations ("auto": the keep plan of the warm-up is replayed) and with the reference's per-block recompute."""
+    from reflectionflow_amd.train.step import FluxTrainer
+    oc = {"type": kind, "params": {"lr": 2e-3, "weight_decay": 0.01} if kind == "AdamW" else
+          {"lr": 1.0, "use_bias_correction": True, "safeguard_warmup": True, "weight_decay": 0.01}}
+
+    def batches(batch):
+        g = torch.Generator(device=dev).manual_seed(5)
+        out = []
+        for i in range(3):
+            b = dict(batch)
+            b["x_0"] = (batch["x_0"].float() + 0.1 * i * torch.randn(batch["x_0"].shape, generator=g, device=dev)).to(BF)
+            b["t"] = torch.sigmoid(torch.randn(batch["t"].shape, generator=g, device=dev))
+            out.append(b)
+        return out
+    pipe_e, batch_e = _hd128(dev)
+    tr_e = FluxTrainer(pipe_e.transformer, CFG, gradient_checkpointing=mode)
+    opt_e = tr_e.configure_optimizers(oc)
+    start = opt_e.bucket.param.clone()
+    losses_e = [tr_e.training_step(b, sample_by_sample=False).clone() for b in batches(batch_e)]
+
+    pipe_g, batch_g = _hd128(dev)
+    tr_g = FluxTrainer(pipe_g.transformer, CFG, gradient_checkpointing=mode)
+    opt_g = tr_g.configure_optimizers(oc)
+    assert torch.equal(opt_g.bucket.param, start)
+    run = tr_g.capture_training_step(batch_g, sample_by_sample=False)
+    assert torch.equal(opt_g.bucket.param, start), "capturing (its warm-up steps) must not train"
+    assert float(opt_g.exp_avg.float().abs().max()) == 0.0
+    if kind == "Prodigy":
+        assert opt_g.d_state()["k"] == 0
+    else:
+        assert opt_g.step_count == 0
+    losses_g = [run(b).clone() for b in batches(batch_g)]
+    torch.cuda.synchronize()
+    for a, b in zip(losses_e, losses_g):
+        assert torch.equal(a, b), (float(a), float(b))
+    assert torch.equal(opt_e.bucket.param, opt_g.bucket.param)
+    assert torch.equal(opt_e.exp_avg, opt_g.exp_avg) and torch.equal(opt_e.exp_avg_sq, opt_g.exp_avg_sq)
+    assert not torch.equal(opt_g.bucket.param, start)
+    if kind == "Prodigy":
+        assert opt_e.d_state() == opt_g.d_state() and opt_g.d_state()["k"] == 3
+    with pytest.raises(Exception):
+        run({k: v for k, v in batch_g.items() if k != "t"})            # the captured step's inputs are fixed
