@@ -750,6 +750,42 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
     trainer.gradient_checkpointing = "auto"
     assert keep_equal, "gradients with kept activations != gradients with per-block recompute"
     del g_auto
+    # (3) the same step replayed as ONE hipGraph (zero_grad + forward + backward captured; clip + optimizer update eager): what the host
+    #     has to do per step shrinks from ~2700 enqueues to one replay + <= 8 launches.  Checked bit-equal to the eager step first.
+    def snapshot():
+        return opt.bucket.param.detach().clone(), {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in opt.state_dict().items()}
+
+    def restore(snap):
+        with torch.no_grad():
+            opt.bucket.param.copy_(snap[0])
+        opt.load_state_dict(snap[1])
+    hipgraph = None
+    if Bn == 1:
+        snap = snapshot()
+        l_eager = trainer.training_step(batch).clone()
+        p_eager = opt.bucket.param.clone()
+        restore(snap)
+        run = trainer.capture_training_step(batch)
+        l_graph = run(batch).clone()
+        graph_equal = bool(torch.equal(p_eager, opt.bucket.param) and torch.equal(l_eager, l_graph))
+        assert graph_equal, "the captured training step differs from the eager step"
+        del p_eager
+        for _ in range(max(1, warmup - 1)):
+            run(batch)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        hg0 = time.perf_counter()
+        g0.record()
+        for _ in range(steps):
+            run(batch)
+        g1.record()
+        host_graph = (time.perf_counter() - hg0) * 1000.0 / steps
+        torch.cuda.synchronize()
+        hipgraph = {"what": "FluxTrainer.capture_training_step: zero_grad + forward + backward as one hipGraph replay, clip + optimizer update eager",
+                    "ms_per_step": round(g0.elapsed_time(g1) / steps, 2), "host_enqueue_ms_per_step": round(host_graph, 2),
+                    "bit_equal_to_the_eager_step": graph_equal}
+        del run
+        torch.cuda.empty_cache()
     o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     o0.record()
     for _ in range(4):
@@ -775,6 +811,7 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
                        " (samples run sequentially; one optimizer update per batch)"),
             "batch_size": Bn, "ms_per_sample": round(ms / Bn, 2),
             "ms_per_step": round(ms, 2), "host_enqueue_ms_per_step": round(host_ms, 2), "steps": steps, "warmup": warmup,
+            "hipgraph": hipgraph, "gradient_clip_val": trainer.gradient_clip_val,
             "activations": {"what": "FluxTrainer(gradient_checkpointing='auto'): a block keeps its forward intermediates while they fit the free HBM "
                                     "(~0.8 GB per block at 5632 tokens) instead of re-running its forward inside the backward; ms_per_step, the "
                                     "class table and tflops_model are this mode",
