@@ -765,6 +765,7 @@ def training_table(dev, pipe, target=1024, cond=512, rank=32, steps=4, warmup=2,
         l_eager = trainer.training_step(batch).clone()
         p_eager = opt.bucket.param.clone()
         restore(snap)
+        torch.cuda.empty_cache()
         run = trainer.capture_training_step(batch)
         l_graph = run(batch).clone()
         graph_equal = bool(torch.equal(p_eager, opt.bucket.param) and torch.equal(l_eager, l_graph))

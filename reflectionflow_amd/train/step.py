@@ -221,6 +221,9 @@ class FluxTrainer:
             torch.cuda.current_stream().synchronize()
             restore()
             self._keep_plan_frozen = list(self._last_keep_plan) if self.gradient_checkpointing == "auto" else None
+            # the warm-up's activations sit in the caching allocator's per-stream free lists (one set for the caller's stream if it ran
+            # eager steps before, one for this side stream); the graph's private pool is a third: hand the first two back first
+            torch.cuda.empty_cache()
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph, stream=side):
