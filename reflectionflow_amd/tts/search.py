@@ -92,7 +92,15 @@ def bind_host_threads_to_gpu_numa_node(index: int) -> Dict[str, object]:
         now = set(os.sched_getaffinity(0))
         cpus = sorted(want & now)
         if cpus:
-            os.sched_setaffinity(0, cpus)
+            os.sched_setaffinity(0, cpus)                 # this thread (threads created from here on inherit it) ...
+            try:                                           # ... and the ones that already run (the interpreter's / torch's pools, RCCL's proxies)
+                for tid in os.listdir("/proc/self/task"):
+                    try:
+                        os.sched_setaffinity(int(tid), cpus)
+                    except OSError:
+                        pass
+            except OSError:
+                pass
             info.update(numa_node=node, cpus_bound=len(cpus))
     except Exception:
         pass
