@@ -268,7 +268,11 @@ def test_numa_binding_narrows_the_affinity_mask_only(monkeypatch, tmp_path):
         assert info == {"numa_node": 1, "cpus_bound": len(set(have[:2]))}
         assert sorted(os.sched_getaffinity(0)) == sorted(set(have[:2]))
     finally:
-        os.sched_setaffinity(0, have)
+        for tid in os.listdir("/proc/self/task"):        # (the binding covers every thread of the process: give all of them their CPUs back)
+            try:
+                os.sched_setaffinity(int(tid), have)
+            except OSError:
+                pass
     monkeypatch.setattr(search, "gpu_numa_node", lambda i: None)
     assert search.bind_host_threads_to_gpu_numa_node(0) == {"numa_node": None, "cpus_bound": None}
     assert sorted(os.sched_getaffinity(0)) == have
