@@ -987,6 +987,9 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
   bf16x8 X[4], Y[4], e0[2], e1[2], m[6];
   rdA(X, smem);
   rdBe(e0, smem);
+  // static wave priority for group 0 for the whole loop (round 6, tools/kb_gemm_patch.py: +0.3-0.4 % on every cfg2 shape in 7 interleaved
+  // repetitions, bit-identical; per-phase priorities around the MFMAs or around the loads, and the same for group 1, measured +-0.2 %)
+  if (grp == 0) __builtin_amdgcn_s_setprio(1);
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
@@ -1053,6 +1056,7 @@ __device__ __forceinline__ void gemm_mainloop_pp3_m16(const GemmGroupDev& G, con
     if (t + 1 < nk) tile(t + 1, Y, X);
   }
 #undef RF_PP3_BAR
+  __builtin_amdgcn_s_setprio(0);
   if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier
 }
 

@@ -56,11 +56,11 @@ def p_prio_load(b):     # the opposite: priority to the wave that reads / stages
     return b
 
 
-def _static(g):
+def _static(g, prio=1):
     @in_pp3
     def f(b):
         b = sub(b, "  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0\n",
-                f"  if (grp == {g}) __builtin_amdgcn_s_setprio(1);\n  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0\n", 1)
+                f"  if (grp == {g}) __builtin_amdgcn_s_setprio({prio});\n  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs half a phase behind group 0\n", 1)
         return sub(b, "  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier\n",
                    "  __builtin_amdgcn_s_setprio(0);\n  if (grp == 0) __builtin_amdgcn_s_barrier();  // match group 1's extra barrier\n", 1)
     return f
@@ -73,6 +73,7 @@ def p_mfma_rt_outer(b):  # MFMA order inside a phase: row tile outermost (consec
 
 
 VARIANTS = {"base": [], "prio_mfma": [p_prio_mfma], "prio_load": [p_prio_load], "prio_static_group1": [_static(1)], "prio_static_group0": [_static(0)],
+            "prio_static_group0_p2": [_static(0, 2)], "prio_static_group0_p3": [_static(0, 3)], "base_again": [],
             "mfma_rt_outer": [p_mfma_rt_outer]}
 SHAPES = [("dbl_qkv", 4608, 9216, 3072), ("dbl_out", 4608, 3072, 3072), ("dbl_ff1", 4608, 12288, 3072), ("dbl_ff2", 4608, 3072, 12288),
           ("sgl_in", 4608, 21504, 3072), ("sgl_out", 4608, 3072, 15360)]
