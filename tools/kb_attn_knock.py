@@ -75,6 +75,20 @@ def p_summ(s):  # row sums back on the VALU (what the kernel did before round 3'
     return sub(s, "constexpr int ATT5_VAR = 256 | 2048;", "constexpr int ATT5_VAR = 256;")
 
 
+def p_var(bits):   # another compile-time schedule option set of attn5_body (every one computes the same result)
+    return lambda s: sub(s, "constexpr int ATT5_VAR = 256 | 2048;", f"constexpr int ATT5_VAR = {bits};")
+
+
+def p_small_cost(c):   # the mixed-size launch's cost model: a 192-query workgroup's time relative to a 256-query one's
+    return lambda s: sub(s, "constexpr float ATT5_SMALL_COST = 0.9f;", f"constexpr float ATT5_SMALL_COST = {c}f;")
+
+
+TUNING = {
+    "full_again": [],
+    "prio_scheme1": [p_var("128 | 2048")], "prio_scheme3": [p_var("384 | 2048")], "prio_scheme6": [p_var("768 | 2048")],
+    "reads_1_group_ahead": [p_var("256 | 2048 | 4")], "reads_3_groups_ahead": [p_var("256 | 2048 | 32")],
+    "small_cost_0.80": [p_small_cost("0.80")], "small_cost_0.85": [p_small_cost("0.85")], "small_cost_0.95": [p_small_cost("0.95")],
+}
 VARIANTS = {
     "full": [],
     "no_exp": [p_exp],
@@ -90,6 +104,8 @@ VARIANTS = {
     "rowsum_on_valu": [p_summ],
     "mfma_only": [p_exp, p_pack, p_dma, p_reads, p_bar],
 }
+KNOCKOUTS = list(VARIANTS)
+VARIANTS.update(TUNING)
 
 
 def build(name, patches, work):
@@ -121,7 +137,7 @@ def main():
     ap.add_argument("--heads", type=int, default=24)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--variants", default=",".join(KNOCKOUTS), help="default: the knock-outs; `--variants full," + ",".join(TUNING) + "` = the tuning sweep")
     ap.add_argument("--kernel", type=int, default=L.RF_ATTN_AUTO if hasattr(L, "RF_ATTN_AUTO") else 0)
     args = ap.parse_args()
     L.load()
