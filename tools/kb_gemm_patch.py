@@ -72,7 +72,12 @@ def p_mfma_rt_outer(b):  # MFMA order inside a phase: row tile outermost (consec
                "    for (int ks = 0; ks < 2; ++ks)\n#pragma unroll\n      for (int rt = 0; rt < 2; ++rt)\n#pragma unroll\n        for (int ct = 0; ct < 4; ++ct)\n", 1)
 
 
-VARIANTS = {"base": [], "prio_mfma": [p_prio_mfma], "prio_load": [p_prio_load], "prio_static_group1": [_static(1)], "prio_static_group0": [_static(0)],
+def p_gw(n):   # raster: width of the column bands a XCD's chunk of tiles walks (tile_coords)
+    return lambda s: sub(s, "  constexpr int GW = 8;\n", f"  constexpr int GW = {n};\n", 1)
+
+
+VARIANTS = {"gw4": [p_gw(4)], "gw6": [p_gw(6)], "gw12": [p_gw(12)], "gw16": [p_gw(16)], "gw2": [p_gw(2)],
+            "base": [], "prio_mfma": [p_prio_mfma], "prio_load": [p_prio_load], "prio_static_group1": [_static(1)], "prio_static_group0": [_static(0)],
             "prio_static_group0_p2": [_static(0, 2)], "prio_static_group0_p3": [_static(0, 3)], "base_again": [],
             "mfma_rt_outer": [p_mfma_rt_outer]}
 SHAPES = [("dbl_qkv", 4608, 9216, 3072), ("dbl_out", 4608, 3072, 3072), ("dbl_ff1", 4608, 12288, 3072), ("dbl_ff2", 4608, 3072, 12288),
