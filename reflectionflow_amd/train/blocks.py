@@ -79,10 +79,10 @@ def single_weights(block) -> TrainWeights:
 class _FuseLora(torch.autograd.Function):
     """(A_pad [r_pad, K], Bs_pad [N, r_pad]) from the LoRA parameters of sibling linears: A = the lora_A weights stacked along r,
     Bs = block-diagonal of scaling * lora_B (one block per linear along N, one column range per (linear, adapter) along r).  ONE launch
-    each way (rf_lora_fuse / rf_lora_unfuse_grads, ABI v14).  The backward ADDS the factors' gradients into their `.grad` itself (into
-    the views of the flat bucket when an optimizer of train/optim.py owns them) and hands autograd None for them: a scaled copy plus
-    two AccumulateGrad launches per linear and site were ~720 launches of a step; the arithmetic is that of `grad += dBs_block * scaling`
-    on bf16 tensors, rounding for rounding."""
+    each way (rf_lora_fuse / rf_lora_unfuse_grads, ABI v14).  When a flat bucket of train/optim.py owns the factors, the backward ADDS
+    their gradients into the bucket's `.grad` views itself and hands autograd None for them: a scaled copy plus two AccumulateGrad
+    launches per linear and site were ~720 launches of a step; the arithmetic is that of `grad += dBs_block * scaling` on bf16 tensors,
+    rounding for rounding.  Otherwise the gradients are returned to autograd like any other node's."""
 
     @staticmethod
     def _table(entries, params, grads: bool):
@@ -117,11 +117,27 @@ class _FuseLora(torch.autograd.Function):
     def backward(ctx, dA, dB):
         K_, N, r_pad, entries = ctx.layout
         dA, dB = dA.contiguous(), dB.contiguous()
+        params = ctx.params
+        # The in-place form (add into .grad, hand autograd None) is a contract between this node and the flat bucket that owns the
+        # factors (train/optim.py::FlatLoraBucket marks them): there `.grad` IS the view the optimizer reads.  Parameters nobody
+        # re-homed get the ordinary autograd contract -- the gradients are RETURNED (one launch, accumulate = 0, into fresh tensors),
+        # so torch.autograd.grad(), backward(inputs=...), tensor hooks and post-accumulate-grad hooks (DDP, hook-based clipping) see
+        # them.
+        owned = all(getattr(p_, "_rf_flat_bucket", None) is not None for p_ in params if p_.requires_grad)
         with torch.no_grad():
-            tab = _FuseLora._table(entries, ctx.params, True)
-            L.check(L.load().rf_lora_unfuse_grads(tab, len(entries), K_, N, r_pad, dA.data_ptr(), dB.data_ptr(), 1, ops.stream_ptr()),
+            if owned:
+                tab = _FuseLora._table(entries, params, True)
+                L.check(L.load().rf_lora_unfuse_grads(tab, len(entries), K_, N, r_pad, dA.data_ptr(), dB.data_ptr(), 1, ops.stream_ptr()),
+                        "rf_lora_unfuse_grads")
+                return (None,) * (1 + len(params))
+            tab = _FuseLora._table(entries, params, False)
+            grads = [torch.empty_like(p_) if (p_.requires_grad and ctx.needs_input_grad[1 + i]) else None for i, p_ in enumerate(params)]
+            for i in range(len(entries)):
+                tab[i].dA = grads[2 * i].data_ptr() if grads[2 * i] is not None else None
+                tab[i].dB = grads[2 * i + 1].data_ptr() if grads[2 * i + 1] is not None else None
+            L.check(L.load().rf_lora_unfuse_grads(tab, len(entries), K_, N, r_pad, dA.data_ptr(), dB.data_ptr(), 0, ops.stream_ptr()),
                     "rf_lora_unfuse_grads")
-        return (None,) * (1 + len(ctx.params))
+        return (None, *grads)
 
 
 def fused_lora(linears, device=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:

@@ -52,6 +52,7 @@ class FlatLoraBucket:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
                 if old_grad is not None:
                     p.grad.copy_(old_grad)
+                p._rf_flat_bucket = True          # train/blocks.py::_FuseLora may add into .grad in place: it IS the optimizer's buffer
 
     def zero_grad(self) -> None:
         self.grad.zero_()

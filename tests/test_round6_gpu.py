@@ -288,3 +288,35 @@ def test_captured_training_step_is_bit_equal_to_the_eager_step(dev, kind, mode):
         assert opt_e.d_state() == opt_g.d_state() and opt_g.d_state()["k"] == 3
     with pytest.raises(Exception):
         run({k: v for k, v in batch_g.items() if k != "t"})            # the captured step's inputs are fixed
+
+
+def test_lora_gradients_reach_autograd_when_no_bucket_owns_the_factors(dev):
+    """the fused-LoRA node writes `.grad` in place only for factors a FlatLoraBucket owns (the optimizer's buffer); otherwise it
+    returns the gradients to autograd: `torch.autograd.grad(loss, factors)` yields them, bit-equal to what `.backward()` accumulates,
+    tensor hooks fire, and nothing is written into `.grad` as a side effect."""
+    from reflectionflow_amd.train.step import FluxTrainer, lora_parameters
+    pipe, batch = _hd128(dev)
+    tr = FluxTrainer(pipe.transformer, CFG)
+    ps = lora_parameters(pipe.transformer)
+    for p in ps:
+        p.grad = None
+    tr.step(batch).backward()
+    want = [None if p.grad is None else p.grad.clone() for p in ps]
+    assert sum(g is not None and float(g.float().abs().max()) > 0 for g in want) >= 44
+    for p in ps:
+        p.grad = None
+    fired = []
+    hooks = [p.register_hook(lambda g, i=i: fired.append(i)) for i, p in enumerate(ps)]
+    got = torch.autograd.grad(tr.step(batch), ps, allow_unused=True)
+    for h in hooks:
+        h.remove()
+    assert all(p.grad is None for p in ps), "torch.autograd.grad must not write .grad"
+    for a, b in zip(got, want):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert len(set(fired)) >= 44
+    # ... and the bucket-owned form is unchanged: after configure_optimizers the same step fills the bucket with the same gradients
+    opt = tr.configure_optimizers({"type": "AdamW", "params": {"lr": 0.0, "weight_decay": 0.0}})
+    opt.zero_grad()
+    tr.step(batch).backward()
+    for p, b in zip(ps, want):
+        assert b is None or torch.equal(p.grad, b)
