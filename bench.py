@@ -225,6 +225,10 @@ def text_table(dev):
         out[name] = round((time.perf_counter() - t0) / 10 * 1e3, 2)
     out["t5_weight_bytes_gb"] = 9.4
     out["t5_tflops"] = round(2 * 512 * (24 * (4 * 4096 * 4096 + 3 * 4096 * 10240)) / (out["t5_xxl_512_tokens_ms"] * 1e-3) / 1e12, 1)
+    # both rooflines of the B = 1 encode: the weights are streamed once per prompt
+    out["t5_weight_stream_GBps"] = round(9.4e9 / (out["t5_xxl_512_tokens_ms"] * 1e-3) / 1e9, 1)
+    out["t5_frac_of_hbm_8TBps"] = round(out["t5_weight_stream_GBps"] / 8000.0, 3)
+    out["t5_frac_of_bf16_mfma_peak"] = round(out["t5_tflops"] / PEAK_BF16_TFLOPS, 3)
     out["per_prompt_ms_in_a_batch_of_4"] = round((out["t5_xxl_4_prompts_ms"] + out["clip_l_4_prompts_ms"]) / 4, 2)
     out["frac_of_a_candidate"] = round((out["t5_xxl_512_tokens_ms"] + out["clip_l_77_tokens_ms"]) / 1e3 / 3.1, 4)
     del t5, clip, csd
